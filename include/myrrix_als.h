@@ -1,0 +1,183 @@
+/*
+ * myrrix_als.h -- C-ABI of the MI355X-native ALS matrix-factorization core (libmyrrix_als.so).
+ *
+ * This is the drop-in boundary behind myrrix-recommender's
+ *   net.myrrix.online.factorizer.MatrixFactorizer            (online/src/.../MatrixFactorizer.java:31-77)
+ *   net.myrrix.online.factorizer.als.AlternatingLeastSquares (online/src/.../als/AlternatingLeastSquares.java:66)
+ * Plain pointers and sizes only; no C++/torch types.  The reference has no FFI for this path (it is
+ * pure Java); the JNI stub a maintainer would add to bind these entry points is shown in
+ * INTEGRATION.md, next to the Java adapter that keeps the 5-argument constructor of
+ * AlternatingLeastSquares.java:132-136.  Abbreviations below: ALS = that file, MU =
+ * common/src/net/myrrix/common/math/MatrixUtils.java, CMLSS =
+ * common/src/net/myrrix/common/math/CommonsMathLinearSystemSolver.java.
+ *
+ * Data model.  The Java side keeps FastByIDMap<FastByIDFloatMap> RbyRow / RbyColumn and
+ * FastByIDMap<float[]> X / Y; the adapter maps 64-bit ids to dense row indices and hands the native
+ * side CSR arrays: "side X" = rows of R (users; its factor matrix is X, solved from Y), "side Y" =
+ * rows of R^T (items; factor matrix Y, solved from X).  Factor matrices are row-major fp32,
+ * n_rows_total x features, resident in HBM.  n_rows_total may exceed the number of matrix rows: Y may
+ * carry stale rows that are never re-solved but still count in Y^T Y (ALS:304-308,342), and a
+ * multi-GPU shard layout may pad each rank's slice.  One handle drives ONE GPU and holds the
+ * matrix rows [row_offset, row_offset+n_rows_local) of each side plus FULL replicas of X and Y;
+ * the caller exchanges freshly solved slices between handles (all-gather) -- see
+ * mals_factor_device_ptr / mals_bind_factors.
+ *
+ * Every function returns a status code and never throws across the ABI.
+ */
+#ifndef MYRRIX_ALS_H
+#define MYRRIX_ALS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MALS_ABI_VERSION 1
+
+typedef struct mals_handle_s* mals_handle;
+
+/* Status codes.  Java adapter mapping (ALS:349, CMLSS:46-54, MatrixFactorizer.java:41-47):
+ * SINGULAR -> ExecutionException(SingularMatrixSolverException(apparentRank)),
+ * CANCELLED -> InterruptedException, everything else -> ExecutionException(IllegalStateException). */
+enum {
+  MALS_OK = 0,
+  MALS_SINGULAR = 1,
+  MALS_INVALID_ARG = 2,
+  MALS_HIP_ERROR = 3,
+  MALS_COMM_ERROR = 4,
+  MALS_CANCELLED = 5,
+  MALS_OOM = 6
+};
+
+enum { MALS_SIDE_X = 0, MALS_SIDE_Y = 1 };
+
+/* ALS:85-91: model.reconstructRMatrix / model.lossIgnoresUnspecified (static finals there). */
+enum { MALS_FLAG_RECONSTRUCT_R = 1, MALS_FLAG_LOSS_IGNORES_UNSPECIFIED = 2 };
+
+enum { MALS_MEM_HOST = 0, MALS_MEM_DEVICE = 1 };
+
+typedef struct mals_config {
+  int32_t struct_size;          /* sizeof(mals_config), for ABI evolution                      */
+  int32_t features;             /* k; ALS:134 "features must be positive"; 1..128 supported    */
+  double alpha;                 /* model.als.alpha,  default 1.0 (ALS:71,506-509)              */
+  double lambda;                /* model.als.lambda, default 0.1 (ALS:73,511-514); the ridge
+                                   applied per row is lambda*alpha*n_u (ALS:435,488)           */
+  double singularity_threshold; /* common.matrix.singularityThreshold, default 1e-5
+                                   (LinearSystemSolver.java:33-34)                             */
+  int32_t flags;                /* MALS_FLAG_*                                                 */
+  int32_t device;               /* HIP device ordinal                                          */
+  int32_t segment_nnz;          /* rows longer than this are split across waves; 0 = default   */
+  int32_t reserved;
+} mals_config;
+
+typedef struct mals_stats {
+  int32_t struct_size;
+  int32_t reserved;
+  /* accumulated since mals_reset_stats; times are HIP-event milliseconds measured on the handle's
+   * stream around each launch group, only while timing is enabled (mals_enable_timing).         */
+  double gather_solve_ms;   /* K2/K3: per-row gather + Gramian + Cholesky kernels               */
+  double gramian_ms;        /* K1: M^T M kernels                                                */
+  int64_t gather_solve_launches; /* number of timed K2 launch groups (= solve_side calls)       */
+  int64_t gramian_launches;
+  int64_t rows_solved;
+  int64_t nnz_gathered;
+  double algorithmic_bytes; /* sum over solve_side calls of N*(4k+8) + R*(4k+8), SURVEY 8(d)    */
+} mals_stats;
+
+int mals_abi_version(void);
+
+/* Fill cfg with the reference's defaults (k=30, alpha=1, lambda=0.1, threshold 1e-5;
+ * MatrixFactorizer.java:34, ALS:71-75). */
+int mals_default_config(mals_config* cfg);
+
+/* Create a handle on cfg->device.  Replaces `new AlternatingLeastSquares(...)` (ALS:132-147). */
+int mals_create(const mals_config* cfg, mals_handle* out);
+int mals_destroy(mals_handle h);
+
+/* Human-readable message for the last non-OK status on this handle ("" if none). */
+const char* mals_last_error(mals_handle h);
+
+/* Use an existing hipStream_t (e.g. the caller's current stream) for all work; NULL = default. */
+int mals_set_stream(mals_handle h, void* hip_stream);
+
+/* Declare the number of rows of a side's factor replica and (re)allocate it zero-filled, unless
+ * the caller binds its own device buffer with mals_bind_factors. */
+int mals_set_factor_rows(mals_handle h, int side, int64_t n_rows_total);
+
+/* Use caller-owned device memory (row-major n_rows_total x features fp32) as the factor replica
+ * of `side`.  The caller keeps it alive until mals_destroy or the next bind. */
+int mals_bind_factors(mals_handle h, int side, float* device_ptr, int64_t n_rows_total);
+
+/* Device pointer of the factor replica of `side` (for the caller's collective). */
+int mals_factor_device_ptr(mals_handle h, int side, void** out_device_ptr, int64_t* out_n_rows_total);
+
+/* Upload the local matrix rows of a side: rows [row_offset, row_offset+n_rows_local) of R (side X)
+ * or R^T (side Y) in CSR with local row_ptr (n_rows_local+1 entries, row_ptr[0]=0), col_idx indexing
+ * rows of the OPPOSITE side's factor replica.  This is what iterating RbyRow / RbyColumn delivers
+ * (ALS:399,455).  mem_kind = MALS_MEM_DEVICE borrows the caller's device arrays (no copy; keep
+ * them alive); MALS_MEM_HOST copies.  n_u of a row = its entry count (ALS:488 ru.size()). */
+int mals_set_matrix(mals_handle h, int side, int64_t row_offset, int64_t n_rows_local, int64_t nnz,
+                    const int64_t* row_ptr, const int32_t* col_idx, const float* val, int mem_kind);
+
+/* Chunked variant for callers that cannot hold one array per matrix (Java arrays are < 2^31):
+ * begin, then append consecutive row chunks (host memory; row_ptr_chunk has n_rows+1 entries
+ * starting at 0), then end. */
+int mals_begin_matrix(mals_handle h, int side, int64_t row_offset, int64_t n_rows_local, int64_t nnz);
+int mals_append_rows(mals_handle h, int side, int64_t n_rows, const int64_t* row_ptr_chunk,
+                     const int32_t* col_idx, const float* val);
+int mals_end_matrix(mals_handle h, int side);
+
+/* Host <-> device factor rows.  setPreviousY (ALS:172-174) = mals_set_factors(MALS_SIDE_Y, ...);
+ * getX()/getY() (ALS:149-157) = mals_get_factors. */
+int mals_set_factors(mals_handle h, int side, int64_t row_begin, int64_t n_rows, const float* host_rows);
+int mals_get_factors(mals_handle h, int side, int64_t row_begin, int64_t n_rows, float* host_out);
+int mals_get_rows(mals_handle h, int side, const int64_t* row_idx, int32_t n, float* host_out);
+
+/* K1.  G = M^T M over ALL rows of `side`'s factor replica (MU:219-239 as called at ALS:342,369),
+ * fp64, left on the device for the next mals_solve_side of the OTHER side; optionally copied to
+ * host_G (features*features doubles, row-major) when host_G != NULL. */
+int mals_gramian(mals_handle h, int side, double* host_G);
+
+/* Multi-GPU variant: partial Gramian of rows [row_begin,row_begin+n_rows) of `side`'s replica into
+ * device_out (features*features doubles); the caller all-reduces and installs the sum. */
+int mals_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_rows, double* device_out);
+int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind);
+
+/* K2+K3.  Solve the local rows of `side` from the opposite side's factors and Gramian
+ * (ALS:391-410 addWorkers + ALS:432-504 Worker.call): per row W = G + sum (c-1) y y^T +
+ * lambda*alpha*n_u I, b = sum_{r>0} c y, x = W^-1 b, written into rows
+ * [row_offset, row_offset+n_rows_local) of `side`'s factor replica.  Asynchronous on the handle's
+ * stream; errors (singular rows) are reported by the next mals_check. */
+int mals_solve_side(mals_handle h, int side);
+
+/* Synchronise the stream and report MALS_SINGULAR if any row solved since the last check had a
+ * non-positive-definite system (the reference throws SingularMatrixSolverException, CMLSS:46-54). */
+int mals_check(mals_handle h);
+int mals_singular_info(mals_handle h, int32_t* side, int64_t* row, int32_t* apparent_rank);
+
+/* iterateXFromY (ALS:340-362) for side X, iterateYFromX (ALS:367-389) for side Y:
+ * mals_gramian(opposite) + mals_solve_side(side) + mals_check. Single-GPU convenience. */
+int mals_half_iteration(mals_handle h, int side);
+
+/* call() (ALS:176-262) on one GPU: alternate half-iterations until the convergence rule fires.
+ * test_users / test_items: dense indices of the convergence sample (the adapter draws them with the
+ * reference's own RandomUtils.chooseAboutNFromStream, ALS:206-215).  random_y: Y was random
+ * (ALS:181,253).  iterate = 0: model.als.iterate=false (ALS:196-204).  max_iterations <= 0: no cap. */
+int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iterations,
+                   int32_t random_y, int32_t iterate, const int64_t* test_users, int32_t n_test_users,
+                   const int64_t* test_items, int32_t n_test_items, int32_t* iterations_out,
+                   double* convergence_out);
+
+/* Cooperative cancellation (InterruptedException path, MatrixFactorizer.java:43-44): checked
+ * between half-iterations of mals_factorize. */
+int mals_cancel(mals_handle h);
+
+int mals_enable_timing(mals_handle h, int32_t on);
+int mals_reset_stats(mals_handle h);
+int mals_get_stats(mals_handle h, mals_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYRRIX_ALS_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libmyrrix_als.so (the C-ABI of include/myrrix_als.h).
+
+There is deliberately no fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmyrrix_als.so")
+
+OK, SINGULAR, INVALID_ARG, HIP_ERROR, COMM_ERROR, CANCELLED, OOM = range(7)
+SIDE_X, SIDE_Y = 0, 1
+FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+
+STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
+                COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM"}
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("features", ctypes.c_int32),
+                ("alpha", ctypes.c_double), ("lam", ctypes.c_double),
+                ("singularity_threshold", ctypes.c_double), ("flags", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("segment_nnz", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("gather_solve_ms", ctypes.c_double), ("gramian_ms", ctypes.c_double),
+                ("gather_solve_launches", ctypes.c_int64), ("gramian_launches", ctypes.c_int64),
+                ("rows_solved", ctypes.c_int64), ("nnz_gathered", ctypes.c_int64),
+                ("algorithmic_bytes", ctypes.c_double)]
+
+
+# every symbol include/myrrix_als.h declares: name -> (restype, argtypes)
+_H = ctypes.c_void_p
+_I64 = ctypes.c_int64
+_I32 = ctypes.c_int32
+_P = ctypes.c_void_p
+SYMBOLS = {
+    "mals_abi_version": (ctypes.c_int, []),
+    "mals_default_config": (ctypes.c_int, [ctypes.POINTER(Config)]),
+    "mals_create": (ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(_H)]),
+    "mals_destroy": (ctypes.c_int, [_H]),
+    "mals_last_error": (ctypes.c_char_p, [_H]),
+    "mals_set_stream": (ctypes.c_int, [_H, _P]),
+    "mals_set_factor_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64]),
+    "mals_bind_factors": (ctypes.c_int, [_H, ctypes.c_int, _P, _I64]),
+    "mals_factor_device_ptr": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(_P), ctypes.POINTER(_I64)]),
+    "mals_set_matrix": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _I64, _P, _P, _P, ctypes.c_int]),
+    "mals_begin_matrix": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _I64]),
+    "mals_append_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64, _P, _P, _P]),
+    "mals_end_matrix": (ctypes.c_int, [_H, ctypes.c_int]),
+    "mals_set_factors": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),
+    "mals_get_factors": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),
+    "mals_get_rows": (ctypes.c_int, [_H, ctypes.c_int, _P, _I32, _P]),
+    "mals_gramian": (ctypes.c_int, [_H, ctypes.c_int, _P]),
+    "mals_gramian_partial": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),
+    "mals_set_gramian": (ctypes.c_int, [_H, ctypes.c_int, _P, ctypes.c_int]),
+    "mals_solve_side": (ctypes.c_int, [_H, ctypes.c_int]),
+    "mals_check": (ctypes.c_int, [_H]),
+    "mals_singular_info": (ctypes.c_int, [_H, ctypes.POINTER(_I32), ctypes.POINTER(_I64), ctypes.POINTER(_I32)]),
+    "mals_half_iteration": (ctypes.c_int, [_H, ctypes.c_int]),
+    "mals_factorize": (ctypes.c_int, [_H, ctypes.c_double, _I32, _I32, _I32, _P, _I32, _P, _I32,
+                                      ctypes.POINTER(_I32), ctypes.POINTER(ctypes.c_double)]),
+    "mals_cancel": (ctypes.c_int, [_H]),
+    "mals_enable_timing": (ctypes.c_int, [_H, _I32]),
+    "mals_reset_stats": (ctypes.c_int, [_H]),
+    "mals_get_stats": (ctypes.c_int, [_H, ctypes.POINTER(Stats)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmyrrix_als.so and declare every prototype.  Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libmyrrix_als.so not found at %s -- build it with __graft_entry__.build() or "
+                "`make -C myrrix-recommender_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if L.mals_abi_version() != 1:
+            raise ImportError("libmyrrix_als.so ABI version mismatch")
+        _lib = L
+    return _lib

@@ -1,0 +1,238 @@
+"""ALSCore: thin object wrapper over one mals_handle (one GPU).  Pure plumbing: every method is a
+single C-ABI call (include/myrrix_als.h); arrays are numpy (host) or torch CUDA tensors (device,
+borrowed -- a reference is kept so they stay alive)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import (FLAG_LOSS_IGNORES_UNSPECIFIED, FLAG_RECONSTRUCT_R, MEM_DEVICE, MEM_HOST, SIDE_X,
+                   SIDE_Y)
+
+
+class MalsError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (_lib.STATUS_NAMES.get(status, status), message))
+        self.status = status
+        self.message = message
+
+
+class SingularSystem(MalsError):
+    """MALS_SINGULAR: the reference throws SingularMatrixSolverException here (CMLSS:46-54)."""
+
+    def __init__(self, status, message, side, row, apparent_rank):
+        super().__init__(status, message)
+        self.side = side
+        self.row = row
+        self.apparent_rank = apparent_rank
+
+
+class Cancelled(MalsError):
+    pass
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _host(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class ALSCore:
+    def __init__(self, features, alpha=1.0, lam=0.1, flags=0, device=0, segment_nnz=0,
+                 singularity_threshold=1e-5):
+        self._L = _lib.load()
+        cfg = _lib.Config()
+        self._L.mals_default_config(ctypes.byref(cfg))
+        cfg.features = int(features)
+        cfg.alpha = float(alpha)
+        cfg.lam = float(lam)
+        cfg.flags = int(flags)
+        cfg.device = int(device)
+        cfg.segment_nnz = int(segment_nnz)
+        cfg.singularity_threshold = float(singularity_threshold)
+        self.features = int(features)
+        self._h = ctypes.c_void_p()
+        self._keep = {}
+        rc = self._L.mals_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != _lib.OK:
+            self._h = ctypes.c_void_p()
+            raise MalsError(rc, "mals_create failed (features=%d, device=%d): a HIP device is "
+                                "required, there is no CPU fallback" % (features, device))
+
+    # -- lifecycle --------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.mals_destroy(self._h)
+            self._h = ctypes.c_void_p()
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc == _lib.OK:
+            return
+        msg = (self._L.mals_last_error(self._h) or b"").decode("utf-8", "replace")
+        if rc == _lib.SINGULAR:
+            side, row, rank = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int32()
+            self._L.mals_singular_info(self._h, ctypes.byref(side), ctypes.byref(row), ctypes.byref(rank))
+            raise SingularSystem(rc, msg, side.value, row.value, rank.value)
+        if rc == _lib.CANCELLED:
+            raise Cancelled(rc, msg)
+        raise MalsError(rc, msg)
+
+    # -- configuration ----------------------------------------------------------------------------
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self._L.mals_set_stream(self._h, ctypes.c_void_p(int(hip_stream_ptr or 0))))
+
+    def set_factor_rows(self, side, n_rows_total):
+        self._keep.pop(("F", side), None)
+        self._chk(self._L.mals_set_factor_rows(self._h, side, int(n_rows_total)))
+
+    def bind_factors(self, side, tensor):
+        """tensor: contiguous fp32 torch CUDA tensor [n_rows_total, features]."""
+        assert _is_torch(tensor) and tensor.is_cuda and tensor.is_contiguous()
+        assert tensor.dim() == 2 and tensor.shape[1] == self.features and str(tensor.dtype) == "torch.float32"
+        self._keep[("F", side)] = tensor
+        self._chk(self._L.mals_bind_factors(self._h, side, ctypes.c_void_p(tensor.data_ptr()),
+                                            int(tensor.shape[0])))
+
+    def factor_device_ptr(self, side):
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        self._chk(self._L.mals_factor_device_ptr(self._h, side, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def set_matrix(self, side, row_ptr, col_idx, val, row_offset=0):
+        if _is_torch(row_ptr):
+            assert row_ptr.is_cuda and col_idx.is_cuda and val.is_cuda
+            assert str(row_ptr.dtype) == "torch.int64" and str(col_idx.dtype) == "torch.int32" \
+                and str(val.dtype) == "torch.float32"
+            row_ptr, col_idx, val = row_ptr.contiguous(), col_idx.contiguous(), val.contiguous()
+            self._keep[("M", side)] = (row_ptr, col_idx, val)
+            n_rows, nnz = int(row_ptr.shape[0]) - 1, int(col_idx.shape[0])
+            self._chk(self._L.mals_set_matrix(
+                self._h, side, int(row_offset), n_rows, nnz, ctypes.c_void_p(row_ptr.data_ptr()),
+                ctypes.c_void_p(col_idx.data_ptr()), ctypes.c_void_p(val.data_ptr()), MEM_DEVICE))
+        else:
+            row_ptr = _host(row_ptr, np.int64)
+            col_idx = _host(col_idx, np.int32)
+            val = _host(val, np.float32)
+            self._keep.pop(("M", side), None)
+            n_rows, nnz = len(row_ptr) - 1, len(col_idx)
+            self._chk(self._L.mals_set_matrix(
+                self._h, side, int(row_offset), n_rows, nnz, row_ptr.ctypes.data_as(ctypes.c_void_p),
+                col_idx.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p), MEM_HOST))
+
+    def set_matrix_chunked(self, side, row_ptr, col_idx, val, rows_per_chunk, row_offset=0):
+        """Same as set_matrix (host arrays) through the begin/append/end entry points."""
+        row_ptr = _host(row_ptr, np.int64)
+        col_idx = _host(col_idx, np.int32)
+        val = _host(val, np.float32)
+        n_rows, nnz = len(row_ptr) - 1, len(col_idx)
+        self._chk(self._L.mals_begin_matrix(self._h, side, int(row_offset), n_rows, nnz))
+        for r0 in range(0, max(n_rows, 1), rows_per_chunk):
+            r1 = min(n_rows, r0 + rows_per_chunk)
+            rp = np.ascontiguousarray(row_ptr[r0:r1 + 1] - row_ptr[r0])
+            c = np.ascontiguousarray(col_idx[row_ptr[r0]:row_ptr[r1]])
+            v = np.ascontiguousarray(val[row_ptr[r0]:row_ptr[r1]])
+            self._chk(self._L.mals_append_rows(
+                self._h, side, r1 - r0, rp.ctypes.data_as(ctypes.c_void_p),
+                c.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)))
+        self._chk(self._L.mals_end_matrix(self._h, side))
+
+    # -- factors ----------------------------------------------------------------------------------
+    def set_factors(self, side, rows, row_begin=0):
+        rows = _host(rows, np.float32)
+        assert rows.ndim == 2 and rows.shape[1] == self.features
+        self._chk(self._L.mals_set_factors(self._h, side, int(row_begin), rows.shape[0],
+                                           rows.ctypes.data_as(ctypes.c_void_p)))
+
+    def get_factors(self, side, row_begin=0, n_rows=None):
+        if n_rows is None:
+            n_rows = self.factor_device_ptr(side)[1] - row_begin
+        out = np.empty((n_rows, self.features), dtype=np.float32)
+        self._chk(self._L.mals_get_factors(self._h, side, int(row_begin), int(n_rows),
+                                           out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def get_rows(self, side, idx):
+        idx = _host(idx, np.int64)
+        out = np.empty((len(idx), self.features), dtype=np.float32)
+        self._chk(self._L.mals_get_rows(self._h, side, idx.ctypes.data_as(ctypes.c_void_p), len(idx),
+                                        out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    # -- compute ----------------------------------------------------------------------------------
+    def gramian(self, side, fetch=False):
+        if fetch:
+            G = np.empty((self.features, self.features), dtype=np.float64)
+            self._chk(self._L.mals_gramian(self._h, side, G.ctypes.data_as(ctypes.c_void_p)))
+            return G
+        self._chk(self._L.mals_gramian(self._h, side, None))
+        return None
+
+    def gramian_partial(self, side, row_begin, n_rows, out_tensor):
+        assert _is_torch(out_tensor) and out_tensor.is_cuda and str(out_tensor.dtype) == "torch.float64"
+        assert out_tensor.numel() == self.features * self.features and out_tensor.is_contiguous()
+        self._chk(self._L.mals_gramian_partial(self._h, side, int(row_begin), int(n_rows),
+                                               ctypes.c_void_p(out_tensor.data_ptr())))
+
+    def set_gramian(self, side, G):
+        if _is_torch(G):
+            assert G.is_cuda and str(G.dtype) == "torch.float64" and G.is_contiguous()
+            self._chk(self._L.mals_set_gramian(self._h, side, ctypes.c_void_p(G.data_ptr()), MEM_DEVICE))
+        else:
+            G = _host(G, np.float64)
+            self._chk(self._L.mals_set_gramian(self._h, side, G.ctypes.data_as(ctypes.c_void_p), MEM_HOST))
+
+    def solve_side(self, side):
+        self._chk(self._L.mals_solve_side(self._h, side))
+
+    def check(self):
+        self._chk(self._L.mals_check(self._h))
+
+    def half_iteration(self, side):
+        self._chk(self._L.mals_half_iteration(self._h, side))
+
+    def factorize(self, convergence_threshold, max_iterations, random_y, test_users, test_items,
+                  iterate=True):
+        tu = _host(test_users, np.int64)
+        ti = _host(test_items, np.int64)
+        iters, conv = ctypes.c_int32(0), ctypes.c_double(float("nan"))
+        rc = self._L.mals_factorize(self._h, float(convergence_threshold), int(max_iterations),
+                                    1 if random_y else 0, 1 if iterate else 0,
+                                    tu.ctypes.data_as(ctypes.c_void_p), len(tu),
+                                    ti.ctypes.data_as(ctypes.c_void_p), len(ti),
+                                    ctypes.byref(iters), ctypes.byref(conv))
+        self._chk(rc)
+        return iters.value, conv.value
+
+    def cancel(self):
+        self._chk(self._L.mals_cancel(self._h))
+
+    # -- stats ------------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._chk(self._L.mals_enable_timing(self._h, 1 if on else 0))
+
+    def reset_stats(self):
+        self._chk(self._L.mals_reset_stats(self._h))
+
+    def stats(self):
+        st = _lib.Stats()
+        self._chk(self._L.mals_get_stats(self._h, ctypes.byref(st)))
+        return {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name not in ("struct_size", "reserved")}
+
+
+__all__ = ["ALSCore", "MalsError", "SingularSystem", "Cancelled", "SIDE_X", "SIDE_Y",
+           "FLAG_RECONSTRUCT_R", "FLAG_LOSS_IGNORES_UNSPECIFIED"]

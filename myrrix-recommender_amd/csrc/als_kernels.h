@@ -1,0 +1,536 @@
+// als_kernels.h -- hand-written gfx950 (CDNA4, wave64) kernels of the ALS hot path.
+//
+// K1  gramian_partial_kernel / gramian_finalize_kernel : G = M^T M in fp64 on
+//     v_mfma_f64_16x16x4_f64 (replaces MatrixUtils.transposeTimesSelf, MU:219-239).
+// K2  gather + per-row weighted Gramian + RHS on v_mfma_f32_16x16x4_f32, one 64-lane wave per row
+//     (replaces the inner loop of AlternatingLeastSquares.Worker.call, ALS:447-492).
+// K3  blocked Cholesky + triangular solves on the accumulator tiles, in registers, fused behind K2
+//     (replaces MatrixUtils.getSolver(Wu).solveDToF, ALS:494 -> CMLSS:37-55, CMS:37-44).
+//
+// Fragment layouts (cdna_hip_programming.md section 3):
+//   v_mfma_f32_16x16x4_f32  : lane l supplies A[i=l&15][kk=l>>4], B[kk=l>>4][j=l&15];
+//                             C/D "acc layout": lane l reg r = D[row=4*(l>>4)+r][col=l&15].
+//   v_mfma_f64_16x16x4_f64  : same A/B; C/D lane l reg r = D[row=(l>>4)+4*r][col=l&15].
+// With g = lane>>4 (lane group) and c = lane&15: a feature vector of k floats is cut into
+// T = ceil(k/16) blocks of 16; W (k x k, symmetric) is held as its T(T+1)/2 upper 16x16 tiles in
+// acc layout, 4 VGPRs per tile per lane.  The lane-level choreography below is mirrored
+// one-to-one by tests/wave_emulation.py, which is checked against the oracle on CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mals {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int tri(int T) { return T * (T + 1) / 2; }
+// index of upper tile (i <= j), row-major over the upper triangle
+__host__ __device__ constexpr int tidx(int T, int i, int j) { return i * T - (i * (i - 1)) / 2 + (j - i); }
+
+struct SegB {       // one segment of a long row
+  int64_t begin;    // absolute offset into col/val
+  int32_t row;      // local row
+  int32_t len;      // entries in this segment (> 0)
+  int64_t slot;     // scratch slot
+};
+struct RowC {       // a long row to be finished from its segment partials
+  int64_t first_slot;
+  int32_t row;
+  int32_t nseg;
+};
+
+struct SolveParams {
+  const int64_t* row_ptr;   // local CSR
+  const int32_t* col;
+  const float* val;
+  const float* M;           // opposing factor replica (row-major, stride k)
+  const float* Gf;          // fp32 image of G, (16T x 16T) row-major, zero padded
+  float* out;               // this side's factor replica + row_offset*k
+  const int32_t* order;     // list A: short rows sorted by length (desc)
+  const SegB* segs;         // list B
+  const RowC* rowsC;        // list C
+  float* scratch;           // segment partials
+  unsigned long long* bad_row; // first (smallest) local row with a non-PD system
+  int64_t n_work;           // waves of work in the list this launch handles
+  int32_t k;
+  int32_t flags;            // bit0 reconstructR, bit1 lossIgnoresUnspecified
+  float alpha;
+  float lambda_alpha;       // lambda*alpha
+  float sing_threshold;
+};
+
+// ------------------------------------------------------------------------------------------------
+// cross-lane helpers
+__device__ __forceinline__ float bperm(int byte_idx, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_idx, __float_as_int(v)));
+}
+__device__ __forceinline__ float readlane(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {  // DPP rotate within each 16-lane row
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float reduce_row16(float x) {  // all 16 lanes of a row get the row sum
+  x += row_ror<8>(x);
+  x += row_ror<4>(x);
+  x += row_ror<2>(x);
+  x += row_ror<1>(x);
+  return x;
+}
+__device__ __forceinline__ float reduce_groups(float x, int lane) {  // sum over the 4 lane groups
+  x += bperm((lane ^ 16) << 2, x);
+  x += bperm((lane ^ 32) << 2, x);
+  return x;
+}
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// D = P^T Q accumulated onto C, for acc-layout tiles P, Q (contraction over the tile-row index)
+__device__ __forceinline__ f32x4 tile_ptq(const f32x4& P, const f32x4& Q, f32x4 C) {
+  C = mfma4(P[0], Q[0], C);
+  C = mfma4(P[1], Q[1], C);
+  C = mfma4(P[2], Q[2], C);
+  C = mfma4(P[3], Q[3], C);
+  return C;
+}
+__device__ __forceinline__ f32x4 tile_neg_ptq(const f32x4& P, const f32x4& Q, f32x4 C) {
+  C = mfma4(-P[0], Q[0], C);
+  C = mfma4(-P[1], Q[1], C);
+  C = mfma4(-P[2], Q[2], C);
+  C = mfma4(-P[3], Q[3], C);
+  return C;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3a: in-register Cholesky of one full symmetric 16x16 tile D (acc layout).  Returns
+// Uinv = U^{-1} (acc layout) where U^T U = D, by running the elimination on [D | I]: the row
+// operations turn I into L^{-1} = U^{-T}, which is then transposed across lanes.
+// `bad` is set when a pivot is <= thr or not finite (non-PD system).
+template <int M_>
+__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int g, float thr, bool& bad) {
+  constexpr int gm = M_ >> 2, rm = M_ & 3;
+  const float piv = readlane(D[rm], 16 * gm + M_);
+  bad = bad || !(piv > thr);
+  const float s = __builtin_amdgcn_rsqf(piv);
+  const int idx_row = ((16 * gm) | (lane & 15)) << 2;  // lane (gm, c)
+  const int idx_col = ((lane & 48) | M_) << 2;         // lane (g, m)
+  const float urow = bperm(idx_row, D[rm]) * s;        // U[m][c]
+  const float erow = bperm(idx_row, E[rm]) * s;        // (L^-1)[m][c]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float ucol = bperm(idx_col, D[r]) * s;             // U[m][4g+r] (by symmetry of the Schur block)
+    ucol = (4 * g + r > M_) ? ucol : 0.f;
+    D[r] = fmaf(-ucol, urow, D[r]);
+    E[r] = fmaf(-ucol, erow, E[r]);
+  }
+  E[rm] = (g == gm) ? erow : E[rm];
+}
+
+__device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float thr, bool& bad) {
+  const int g = lane >> 4, c = lane & 15;
+  f32x4 E;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) E[r] = (4 * g + r == c) ? 1.f : 0.f;
+  diag_step<0>(D, E, lane, g, thr, bad);
+  diag_step<1>(D, E, lane, g, thr, bad);
+  diag_step<2>(D, E, lane, g, thr, bad);
+  diag_step<3>(D, E, lane, g, thr, bad);
+  diag_step<4>(D, E, lane, g, thr, bad);
+  diag_step<5>(D, E, lane, g, thr, bad);
+  diag_step<6>(D, E, lane, g, thr, bad);
+  diag_step<7>(D, E, lane, g, thr, bad);
+  diag_step<8>(D, E, lane, g, thr, bad);
+  diag_step<9>(D, E, lane, g, thr, bad);
+  diag_step<10>(D, E, lane, g, thr, bad);
+  diag_step<11>(D, E, lane, g, thr, bad);
+  diag_step<12>(D, E, lane, g, thr, bad);
+  diag_step<13>(D, E, lane, g, thr, bad);
+  diag_step<14>(D, E, lane, g, thr, bad);
+  diag_step<15>(D, E, lane, g, thr, bad);
+  // Uinv = E^T : Uinv.reg[r](g,c) = E[c][4g+r] = E.reg[c&3] held by lane (c>>2, 4g+r)
+  f32x4 Uinv;
+  const int cq = c & 3;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int src = (16 * (c >> 2) + 4 * g + r) << 2;
+    const float t0 = bperm(src, E[0]), t1 = bperm(src, E[1]), t2 = bperm(src, E[2]), t3 = bperm(src, E[3]);
+    Uinv[r] = cq == 0 ? t0 : (cq == 1 ? t1 : (cq == 2 ? t2 : t3));
+  }
+  return Uinv;
+}
+
+// K3b: blocked right-looking Cholesky W = U^T U on the upper tiles.  On return the off-diagonal
+// tiles hold U_ij and the diagonal tiles hold U_ii^{-1}.  TRSM and SYRK run on the matrix cores.
+template <int T>
+__device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float thr, bool& bad) {
+#pragma unroll
+  for (int kb = 0; kb < T; ++kb) {
+    const f32x4 Uinv = factor_diag(acc[tidx(T, kb, kb)], lane, thr, bad);
+    acc[tidx(T, kb, kb)] = Uinv;
+#pragma unroll
+    for (int j = kb + 1; j < T; ++j) {  // U_kj = Uinv^T A_kj
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      acc[tidx(T, kb, j)] = tile_ptq(Uinv, acc[tidx(T, kb, j)], zero);
+    }
+#pragma unroll
+    for (int i = kb + 1; i < T; ++i) {
+#pragma unroll
+      for (int j = i; j < T; ++j)       // A_ij -= U_ki^T U_kj
+        acc[tidx(T, i, j)] = tile_neg_ptq(acc[tidx(T, kb, i)], acc[tidx(T, kb, j)], acc[tidx(T, i, j)]);
+    }
+  }
+}
+
+// vector layout conversions: "col layout" = lane (g,c) holds v[c]; "row layout" = lanes of group g
+// hold v[4g+r] in reg r.
+__device__ __forceinline__ f32x4 col_to_row(float vcol, int lane) {
+  const int g = lane >> 4;
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = bperm(((lane & 48) | (4 * g + r)) << 2, vcol);
+  return o;
+}
+__device__ __forceinline__ float row_to_col(const f32x4& vrow, int lane) {
+  const int c = lane & 15, cq = c & 3;
+  const int src = (16 * (c >> 2)) << 2;
+  const float t0 = bperm(src, vrow[0]), t1 = bperm(src, vrow[1]), t2 = bperm(src, vrow[2]), t3 = bperm(src, vrow[3]);
+  return cq == 0 ? t0 : (cq == 1 ? t1 : (cq == 2 ? t2 : t3));
+}
+
+// K3c: x = W^{-1} b using the factor tiles (forward z = U^{-T} b, backward x = U^{-1} z).
+template <int T>
+__device__ __forceinline__ void solve_tiles(const f32x4 (&acc)[tri(T)], const float (&bcol)[T], float (&xcol)[T], int lane) {
+  f32x4 zrow[T];
+#pragma unroll
+  for (int kb = 0; kb < T; ++kb) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < kb; ++i) {
+      const f32x4& U = acc[tidx(T, i, kb)];
+      t = fmaf(U[0], zrow[i][0], t);
+      t = fmaf(U[1], zrow[i][1], t);
+      t = fmaf(U[2], zrow[i][2], t);
+      t = fmaf(U[3], zrow[i][3], t);
+    }
+    float rhs = bcol[kb];
+    if (kb > 0) rhs -= reduce_groups(t, lane);
+    const f32x4 rr = col_to_row(rhs, lane);
+    const f32x4& Ui = acc[tidx(T, kb, kb)];
+    float zt = Ui[0] * rr[0];
+    zt = fmaf(Ui[1], rr[1], zt);
+    zt = fmaf(Ui[2], rr[2], zt);
+    zt = fmaf(Ui[3], rr[3], zt);
+    zrow[kb] = col_to_row(reduce_groups(zt, lane), lane);
+  }
+#pragma unroll
+  for (int kb = T - 1; kb >= 0; --kb) {
+    f32x4 rhs_row = zrow[kb];
+    if (kb < T - 1) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = kb + 1; j < T; ++j) {
+        const f32x4& U = acc[tidx(T, kb, j)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = fmaf(U[r], xcol[j], t[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rhs_row[r] -= reduce_row16(t[r]);
+    }
+    const float rhs_col = row_to_col(rhs_row, lane);
+    const f32x4& Ui = acc[tidx(T, kb, kb)];
+    f32x4 xr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xr[r] = reduce_row16(Ui[r] * rhs_col);
+    xcol[kb] = row_to_col(xr, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: gather phase.  One wave walks the entries [0,len) of a row (or row segment) four at a time:
+// lane (g,c) owns entry 4*step+g and feature block lanes c; per step it issues T 64-byte-coalesced
+// dword gathers of the opposing factor row straight into MFMA operand registers (no LDS hop: the
+// row is consumed once by this wave only), then T(T+1)/2 MFMAs  acc_ij += (w*y_i) y_j^T  and the
+// RHS update.  Entry (col,val) and row loads run 2D and D steps ahead of the MFMAs.
+struct Ent {
+  int col;
+  float w;   // Gramian weight: (c-1) = alpha*|r|   [+1 if lossIgnoresUnspecified; 0 if reconstructR]
+  float cb;  // RHS weight:     c if r>0 else 0      [r if reconstructR]
+};
+
+__device__ __forceinline__ Ent load_ent(const int32_t* cols, const float* vals, int len, int step, int g,
+                                        float alpha, int flags) {
+  const int n = 4 * step + g;
+  const bool ok = n < len;
+  const int nn = ok ? n : len - 1;
+  Ent e;
+  e.col = cols[nn];
+  const float r = vals[nn];
+  const float base_w = (flags & 2) ? 1.f : 0.f;
+  float w, cb;
+  if (flags & 1) {  // ALS:466-469
+    w = base_w;
+    cb = r;
+  } else {          // ALS:471-482
+    const float ar = alpha * fabsf(r);
+    w = base_w + ar;
+    cb = r > 0.f ? 1.f + ar : 0.f;
+  }
+  e.w = ok ? w : 0.f;
+  e.cb = ok ? cb : 0.f;
+  return e;
+}
+
+template <int T>
+__device__ __forceinline__ void load_rows(const float* __restrict__ M, int k, int col, int c, float (&y)[T]) {
+  const float* p = M + (int64_t)col * k + c;
+#pragma unroll
+  for (int v = 0; v < T - 1; ++v) y[v] = p[16 * v];
+  // last block may be partial: clamp the address, zero the value
+  const int f = 16 * (T - 1) + c;
+  const float last = M[(int64_t)col * k + (f < k ? f : k - 1)];
+  y[T - 1] = f < k ? last : 0.f;
+}
+
+template <int T>
+__device__ __forceinline__ void gram_step(const float (&y)[T], const Ent& e, f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
+  float a[T];
+#pragma unroll
+  for (int v = 0; v < T; ++v) a[v] = e.w * y[v];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma4(a[i], y[j], acc[tidx(T, i, j)]);
+#pragma unroll
+  for (int v = 0; v < T; ++v) bpart[v] = fmaf(e.cb, y[v], bpart[v]);
+}
+
+template <int T, int D>
+__device__ __forceinline__ void gather_accumulate(const SolveParams& p, int64_t begin, int len, int lane,
+                                                  f32x4 (&acc)[tri(T)], float (&bcol)[T]) {
+  const int g = lane >> 4, c = lane & 15;
+  const int32_t* cols = p.col + begin;
+  const float* vals = p.val + begin;
+  const int nsteps = (len + 3) >> 2;
+  float bpart[T];
+#pragma unroll
+  for (int v = 0; v < T; ++v) bpart[v] = 0.f;
+  Ent e[2 * D];
+  float y[D][T];
+#pragma unroll
+  for (int i = 0; i < 2 * D; ++i) e[i] = load_ent(cols, vals, len, i, g, p.alpha, p.flags);
+#pragma unroll
+  for (int i = 0; i < D; ++i) load_rows<T>(p.M, p.k, e[i].col, c, y[i]);
+  for (int s = 0; s < nsteps; s += 2 * D) {
+#pragma unroll
+    for (int i = 0; i < 2 * D; ++i) {
+      if (s + i < nsteps) gram_step<T>(y[i % D], e[i], acc, bpart);
+      load_rows<T>(p.M, p.k, e[(i + D) % (2 * D)].col, c, y[i % D]);
+      e[i] = load_ent(cols, vals, len, s + i + 2 * D, g, p.alpha, p.flags);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);
+}
+
+// add the shared Gramian, the ridge lambda*alpha*n_u (ALS:488-492), identity on the padding;
+// factor; solve; store the row (cast to fp32 is implicit: all arithmetic here is fp32).
+template <int T>
+__device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tri(T)], const float (&bcol)[T],
+                                           int n_u, int row, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  const int k = p.k;
+  if (!(p.flags & 2)) {  // ALS:447-450: start from YTY unless lossIgnoresUnspecified
+    const int ld = 16 * T;
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int j = i; j < T; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[tidx(T, i, j)][r] += p.Gf[(16 * i + 4 * g + r) * ld + 16 * j + c];
+  }
+  const float ridge = p.lambda_alpha * (float)n_u;
+#pragma unroll
+  for (int v = 0; v < T; ++v) {
+    const int feat = 16 * v + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (4 * g + r == c) acc[tidx(T, v, v)][r] = feat < k ? acc[tidx(T, v, v)][r] + ridge : 1.f;
+    }
+  }
+  bool bad = false;
+  cholesky_tiles<T>(acc, lane, p.sing_threshold, bad);
+  float xcol[T];
+  solve_tiles<T>(acc, bcol, xcol, lane);
+  if (bad) {
+    if (lane == 0) atomicMin(p.bad_row, (unsigned long long)row);
+#pragma unroll
+    for (int v = 0; v < T; ++v) xcol[v] = 0.f;
+  }
+  if (g == 0) {
+    float* o = p.out + (int64_t)row * k;
+#pragma unroll
+    for (int v = 0; v < T; ++v) {
+      const int feat = 16 * v + c;
+      if (feat < k) o[feat] = xcol[v];
+    }
+  }
+}
+
+// list A: one wave per short row, fully fused K2+K3
+template <int T, int D>
+__global__ __launch_bounds__(256) void als_rows_kernel(SolveParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= p.n_work) return;
+  const int row = p.order[wave];
+  const int64_t begin = p.row_ptr[row];
+  const int len = (int)(p.row_ptr[row + 1] - begin);
+  f32x4 acc[tri(T)];
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bcol[T];
+#pragma unroll
+  for (int v = 0; v < T; ++v) bcol[v] = 0.f;
+  if (len > 0) gather_accumulate<T, D>(p, begin, len, lane, acc, bcol);
+  finish_row<T>(p, acc, bcol, len, row, lane);
+}
+
+// list B: one wave per segment of a long row; partial tiles + RHS go to scratch
+template <int T, int D>
+__global__ __launch_bounds__(256) void als_segments_kernel(SolveParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= p.n_work) return;
+  const SegB sg = p.segs[wave];
+  f32x4 acc[tri(T)];
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bcol[T];
+  gather_accumulate<T, D>(p, sg.begin, sg.len, lane, acc, bcol);
+  float* s = p.scratch + sg.slot * (int64_t)((tri(T) * 4 + T) * 64) + lane;
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r];
+#pragma unroll
+  for (int v = 0; v < T; ++v) s[(tri(T) * 4 + v) * 64] = bcol[v];
+}
+
+// list C: one wave per long row: sum the segment partials in order, then K3
+template <int T>
+__global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= p.n_work) return;
+  const RowC rc = p.rowsC[wave];
+  f32x4 acc[tri(T)];
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bcol[T];
+#pragma unroll
+  for (int v = 0; v < T; ++v) bcol[v] = 0.f;
+  for (int sgi = 0; sgi < rc.nseg; ++sgi) {
+    const float* s = p.scratch + (rc.first_slot + sgi) * (int64_t)((tri(T) * 4 + T) * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < tri(T); ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] += s[(t * 4 + r) * 64];
+#pragma unroll
+    for (int v = 0; v < T; ++v) bcol[v] += s[(tri(T) * 4 + v) * 64];
+  }
+  const int n_u = (int)(p.row_ptr[rc.row + 1] - p.row_ptr[rc.row]);
+  finish_row<T>(p, acc, bcol, n_u, rc.row, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: G = M^T M, fp64 accumulate on the fp64 matrix cores.  Each wave owns a contiguous slab of
+// rows, walks it 4 rows per step (lane (g,c): row r0+g, features 16v+c), and keeps the T(T+1)/2
+// upper tiles in fp64 accumulators; partials are summed in a fixed order by the finalize kernel,
+// so the result is deterministic.  (The reference rounds each product to fp32 before widening,
+// MU:232; the exact fp64 product used here differs from that by < 2^-24 relative per term.)
+template <int T>
+__global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __restrict__ M, int64_t n_rows, int k,
+                                                              int64_t rows_per_wave, double* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t r0 = wave * rows_per_wave;
+  int64_t r1 = r0 + rows_per_wave;
+  if (r1 > n_rows) r1 = n_rows;
+  f64x4 acc[tri(T)];
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) acc[t] = f64x4{0., 0., 0., 0.};
+  for (int64_t r = r0; r < r1; r += 4) {
+    const int64_t row = r + g;
+    const bool ok = row < r1;
+    const float* p = M + (ok ? row : r0) * k;
+    double y[T];
+#pragma unroll
+    for (int v = 0; v < T; ++v) {
+      const int f = 16 * v + c;
+      const float x = p[f < k ? f : k - 1];
+      y[v] = (ok && f < k) ? (double)x : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int j = i; j < T; ++j)
+        acc[tidx(T, i, j)] = __builtin_amdgcn_mfma_f64_16x16x4f64(y[i], y[j], acc[tidx(T, i, j)], 0, 0, 0);
+  }
+  double* o = partial + wave * (int64_t)(tri(T) * 4 * 64) + lane;
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[(t * 4 + r) * 64] = acc[t][r];
+}
+
+// one thread per (tile, reg, lane) element: sums the wave partials in order; optionally adds into
+// an existing G (accumulate = 1) so that several row ranges can be combined.
+template <int T>
+__global__ void gramian_finalize_kernel(const double* __restrict__ partial, int64_t n_waves, int k, double* __restrict__ G,
+                                        float* __restrict__ Gf) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= tri(T) * 256) return;
+  const int t = e >> 8, reg = (e >> 6) & 3, lane = e & 63;
+  double s = 0.0;
+  for (int64_t w = 0; w < n_waves; ++w) s += partial[w * (int64_t)(tri(T) * 256) + e];
+  // decode tile (i,j) from t
+  int i = 0, rem = t;
+  while (rem >= T - i) {
+    rem -= T - i;
+    ++i;
+  }
+  const int j = i + rem;
+  const int row = 16 * i + (lane >> 4) + 4 * reg;  // f64 C/D layout
+  const int col = 16 * j + (lane & 15);
+  if (G && row < k && col < k) {
+    G[(int64_t)row * k + col] = s;
+    G[(int64_t)col * k + row] = s;
+  }
+  if (Gf) {
+    const int ld = 16 * T;
+    const float f = (row < k && col < k) ? (float)s : 0.f;
+    Gf[row * ld + col] = f;
+    Gf[col * ld + row] = f;
+  }
+}
+
+// G (k x k fp64 row-major) -> zero-padded fp32 image used by K2
+__global__ void gramian_pack_kernel(const double* __restrict__ G, int k, int ld, float* __restrict__ Gf) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ld * ld) return;
+  const int row = e / ld, col = e % ld;
+  Gf[e] = (row < k && col < k) ? (float)G[(int64_t)row * k + col] : 0.f;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ F, const int64_t* __restrict__ idx, int n, int k,
+                                   float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * k) return;
+  out[e] = F[idx[e / k] * (int64_t)k + (e % k)];
+}
+
+}  // namespace mals

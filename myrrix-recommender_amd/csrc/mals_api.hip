@@ -1,0 +1,833 @@
+// mals_api.hip -- host side of libmyrrix_als.so: the C-ABI declared in include/myrrix_als.h.
+// One handle = one GPU.  Holds the CSR shard of each side, the factor replicas, the Gramians and
+// the work lists, and launches the gfx950 kernels of als_kernels.h on the handle's stream.
+// No CPU fallback exists: every compute entry point needs a HIP device and fails with
+// MALS_HIP_ERROR otherwise.
+#include "../../include/myrrix_als.h"
+#include "als_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mals;
+
+namespace {
+
+struct SideState {
+  // factor replica
+  int64_t n_total = 0;
+  float* F = nullptr;
+  bool F_owned = false;
+  // local matrix shard
+  int64_t row_offset = 0, n_local = 0, nnz = 0;
+  int64_t* row_ptr = nullptr;
+  int32_t* col = nullptr;
+  float* val = nullptr;
+  bool m_owned = false;
+  bool has_matrix = false;
+  std::vector<int64_t> h_row_ptr;  // host copy (work-list construction, chunked upload)
+  int64_t append_rows = 0, append_nnz = 0;
+  bool appending = false;
+  // work lists
+  int32_t* orderA = nullptr;
+  int64_t nA = 0;
+  SegB* segs = nullptr;
+  int64_t nB = 0;
+  RowC* rowsC = nullptr;
+  int64_t nC = 0;
+  float* scratch = nullptr;
+  // Gramian of THIS side's factors (consumed when solving the other side)
+  double* G = nullptr;
+  float* Gf = nullptr;
+  double* partials = nullptr;
+  int64_t partial_waves = 0;
+  bool G_valid = false;
+};
+
+struct PendingEvent {
+  hipEvent_t a, b;
+  int kind;  // 0 = gather/solve, 1 = gramian
+};
+
+}  // namespace
+
+struct mals_handle_s {
+  mals_config cfg;
+  int T = 0;
+  SideState side[2];
+  hipStream_t stream = nullptr;
+  std::string err;
+  unsigned long long* d_bad = nullptr;   // [2] per side
+  unsigned long long* h_bad = nullptr;   // pinned
+  int32_t sing_side = -1;
+  int64_t sing_row = -1;
+  int32_t sing_rank = 0;
+  std::atomic<int> cancelled{0};
+  bool timing = false;
+  mals_stats stats;
+  std::vector<PendingEvent> pending;
+  int64_t* d_idx = nullptr;  // gather scratch
+  float* d_rows = nullptr;
+  int32_t idx_cap = 0;
+};
+
+namespace {
+
+int fail(mals_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                     \
+  do {                                                                                      \
+    hipError_t _e = (call);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      const int _code = (_e == hipErrorOutOfMemory) ? MALS_OOM : MALS_HIP_ERROR;            \
+      return fail(h, _code, std::string(#call) + ": " + hipGetErrorString(_e));             \
+    }                                                                                       \
+  } while (0)
+
+#define CHECK_SIDE(h, side)                                                  \
+  do {                                                                       \
+    if (!(h)) return MALS_INVALID_ARG;                                       \
+    if ((side) != MALS_SIDE_X && (side) != MALS_SIDE_Y)                      \
+      return fail(h, MALS_INVALID_ARG, "side must be MALS_SIDE_X or _Y");    \
+  } while (0)
+
+int use_device(mals_handle h) {
+  HIPCHK(h, hipSetDevice(h->cfg.device));
+  return MALS_OK;
+}
+
+template <typename P>
+void free_dev(P*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+void free_matrix(SideState& s) {
+  if (s.m_owned) {
+    free_dev(s.row_ptr);
+    free_dev(s.col);
+    free_dev(s.val);
+  }
+  s.row_ptr = nullptr;
+  s.col = nullptr;
+  s.val = nullptr;
+  s.m_owned = false;
+  s.has_matrix = false;
+  free_dev(s.orderA);
+  free_dev(s.segs);
+  free_dev(s.rowsC);
+  free_dev(s.scratch);
+  s.nA = s.nB = s.nC = 0;
+  s.h_row_ptr.clear();
+  s.h_row_ptr.shrink_to_fit();
+}
+
+int64_t slot_floats(int T) { return (int64_t)(tri(T) * 4 + T) * 64; }
+
+// Split the rows of a shard into the three work lists (DESIGN.md "work decomposition").
+int build_work_lists(mals_handle h, SideState& s) {
+  const int64_t n = s.n_local;
+  const int seg = h->cfg.segment_nnz;
+  const std::vector<int64_t>& rp = s.h_row_ptr;
+  std::vector<int32_t> order;
+  std::vector<SegB> segs;
+  std::vector<RowC> rowsC;
+  // counting sort of the short rows by length, longest first
+  std::vector<int64_t> count((size_t)seg + 2, 0);
+  int64_t n_short = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t len = rp[r + 1] - rp[r];
+    if (len < 0) return fail(h, MALS_INVALID_ARG, "row_ptr must be non-decreasing");
+    if (len <= seg) {
+      ++count[(size_t)(seg - len)];
+      ++n_short;
+    }
+  }
+  int64_t acc = 0;
+  for (size_t b = 0; b < count.size(); ++b) {
+    const int64_t c = count[b];
+    count[b] = acc;
+    acc += c;
+  }
+  order.resize((size_t)n_short);
+  int64_t slot = 0;
+  for (int64_t r = 0; r < n; ++r) {
+    const int64_t len = rp[r + 1] - rp[r];
+    if (len <= seg) {
+      order[(size_t)count[(size_t)(seg - len)]++] = (int32_t)r;
+    } else {
+      const int64_t nseg = (len + seg - 1) / seg;
+      int64_t per = (len + nseg - 1) / nseg;
+      per = (per + 3) & ~(int64_t)3;  // whole 4-entry steps
+      RowC rc;
+      rc.first_slot = slot;
+      rc.row = (int32_t)r;
+      rc.nseg = 0;
+      for (int64_t b = 0; b < len; b += per) {
+        SegB sg;
+        sg.begin = rp[r] + b;
+        sg.row = (int32_t)r;
+        sg.len = (int32_t)std::min(per, len - b);
+        sg.slot = slot++;
+        segs.push_back(sg);
+        ++rc.nseg;
+      }
+      rowsC.push_back(rc);
+    }
+  }
+  // longest segments first
+  std::stable_sort(segs.begin(), segs.end(), [](const SegB& a, const SegB& b) { return a.len > b.len; });
+  s.nA = (int64_t)order.size();
+  s.nB = (int64_t)segs.size();
+  s.nC = (int64_t)rowsC.size();
+  if (s.nA) {
+    HIPCHK(h, hipMalloc(&s.orderA, sizeof(int32_t) * order.size()));
+    HIPCHK(h, hipMemcpy(s.orderA, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
+  }
+  if (s.nB) {
+    HIPCHK(h, hipMalloc(&s.segs, sizeof(SegB) * segs.size()));
+    HIPCHK(h, hipMemcpy(s.segs, segs.data(), sizeof(SegB) * segs.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&s.rowsC, sizeof(RowC) * rowsC.size()));
+    HIPCHK(h, hipMemcpy(s.rowsC, rowsC.data(), sizeof(RowC) * rowsC.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&s.scratch, sizeof(float) * (size_t)(slot * slot_floats(h->T))));
+  }
+  return MALS_OK;
+}
+
+int validate_matrix(mals_handle h, int side) {
+  SideState& s = h->side[side];
+  const SideState& o = h->side[1 - side];
+  (void)o;
+  if (s.h_row_ptr.size() != (size_t)s.n_local + 1 || s.h_row_ptr[0] != 0 || s.h_row_ptr[(size_t)s.n_local] != s.nnz)
+    return fail(h, MALS_INVALID_ARG, "row_ptr must have n_rows_local+1 entries, start at 0 and end at nnz");
+  return MALS_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------
+int begin_timed(mals_handle h, int kind, PendingEvent& pe) {
+  pe.kind = kind;
+  pe.a = pe.b = nullptr;
+  if (!h->timing) return MALS_OK;
+  HIPCHK(h, hipEventCreate(&pe.a));
+  HIPCHK(h, hipEventCreate(&pe.b));
+  HIPCHK(h, hipEventRecord(pe.a, h->stream));
+  return MALS_OK;
+}
+int end_timed(mals_handle h, PendingEvent& pe) {
+  if (!h->timing) return MALS_OK;
+  HIPCHK(h, hipEventRecord(pe.b, h->stream));
+  h->pending.push_back(pe);
+  return MALS_OK;
+}
+int drain_events(mals_handle h) {
+  for (PendingEvent& pe : h->pending) {
+    HIPCHK(h, hipEventSynchronize(pe.b));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, pe.a, pe.b));
+    if (pe.kind == 0) {
+      h->stats.gather_solve_ms += ms;
+      h->stats.gather_solve_launches += 1;
+    } else {
+      h->stats.gramian_ms += ms;
+      h->stats.gramian_launches += 1;
+    }
+    (void)hipEventDestroy(pe.a);
+    (void)hipEventDestroy(pe.b);
+  }
+  h->pending.clear();
+  return MALS_OK;
+}
+
+// ---- kernel dispatch ---------------------------------------------------------------------------
+template <int T>
+int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows, double* G_out, float* Gf_out) {
+  const int k = h->cfg.features;
+  // waves: at least 64 rows each, at most 2048 waves
+  int64_t n_waves = std::min<int64_t>(2048, std::max<int64_t>(1, (n_rows + 255) / 256));
+  n_waves = (n_waves + 3) & ~(int64_t)3;
+  int64_t rows_per_wave = (n_rows + n_waves - 1) / n_waves;
+  rows_per_wave = std::max<int64_t>(4, (rows_per_wave + 3) & ~(int64_t)3);
+  if (s.partial_waves < n_waves) {
+    free_dev(s.partials);
+    HIPCHK(h, hipMalloc(&s.partials, sizeof(double) * (size_t)n_waves * tri(T) * 256));
+    s.partial_waves = n_waves;
+  }
+  hipLaunchKernelGGL((gramian_partial_kernel<T>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, h->stream, M, n_rows, k,
+                     rows_per_wave, s.partials);
+  const int elems = tri(T) * 256;
+  hipLaunchKernelGGL((gramian_finalize_kernel<T>), dim3((elems + 255) / 256), dim3(256), 0, h->stream, s.partials, n_waves,
+                     k, G_out, Gf_out);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+
+int launch_gramian(mals_handle h, SideState& s, const float* M, int64_t n_rows, double* G_out, float* Gf_out) {
+  switch (h->T) {
+    case 1: return launch_gramian_T<1>(h, s, M, n_rows, G_out, Gf_out);
+    case 2: return launch_gramian_T<2>(h, s, M, n_rows, G_out, Gf_out);
+    case 3: return launch_gramian_T<3>(h, s, M, n_rows, G_out, Gf_out);
+    case 4: return launch_gramian_T<4>(h, s, M, n_rows, G_out, Gf_out);
+    case 5: return launch_gramian_T<5>(h, s, M, n_rows, G_out, Gf_out);
+    case 6: return launch_gramian_T<6>(h, s, M, n_rows, G_out, Gf_out);
+    case 7: return launch_gramian_T<7>(h, s, M, n_rows, G_out, Gf_out);
+    case 8: return launch_gramian_T<8>(h, s, M, n_rows, G_out, Gf_out);
+  }
+  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
+template <int T, int D>
+int launch_solve_T(mals_handle h, SideState& s, SolveParams p) {
+  if (s.nB) {
+    p.n_work = s.nB;
+    hipLaunchKernelGGL((als_segments_kernel<T, D>), dim3((unsigned)((s.nB + 3) / 4)), dim3(256), 0, h->stream, p);
+  }
+  if (s.nA) {
+    p.n_work = s.nA;
+    hipLaunchKernelGGL((als_rows_kernel<T, D>), dim3((unsigned)((s.nA + 3) / 4)), dim3(256), 0, h->stream, p);
+  }
+  if (s.nC) {
+    p.n_work = s.nC;
+    hipLaunchKernelGGL((als_finish_kernel<T>), dim3((unsigned)((s.nC + 3) / 4)), dim3(256), 0, h->stream, p);
+  }
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+
+int launch_solve(mals_handle h, SideState& s, const SolveParams& p) {
+  switch (h->T) {
+    case 1: return launch_solve_T<1, 4>(h, s, p);
+    case 2: return launch_solve_T<2, 4>(h, s, p);
+    case 3: return launch_solve_T<3, 4>(h, s, p);
+    case 4: return launch_solve_T<4, 4>(h, s, p);
+    case 5: return launch_solve_T<5, 2>(h, s, p);
+    case 6: return launch_solve_T<6, 2>(h, s, p);
+    case 7: return launch_solve_T<7, 2>(h, s, p);
+    case 8: return launch_solve_T<8, 2>(h, s, p);
+  }
+  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
+int ensure_gramian_buffers(mals_handle h, SideState& s) {
+  const int k = h->cfg.features, ld = 16 * h->T;
+  if (!s.G) HIPCHK(h, hipMalloc(&s.G, sizeof(double) * (size_t)k * k));
+  if (!s.Gf) HIPCHK(h, hipMalloc(&s.Gf, sizeof(float) * (size_t)ld * ld));
+  return MALS_OK;
+}
+
+// DoubleWeightedMean.increment (common/src/net/myrrix/common/stats/DoubleWeightedMean.java:73-81)
+void dwm_increment(double& total_weight, double& mean, double datum, double weight) {
+  const double old = total_weight;
+  total_weight += weight;
+  if (old <= 0) {
+    mean = datum;
+  } else {
+    mean = mean * old / total_weight + datum * weight / total_weight;
+  }
+}
+
+// SimpleVectorMath.dot (common/src/net/myrrix/common/math/SimpleVectorMath.java:34-41):
+// float product, double accumulation
+double dot_f(const float* x, const float* y, int k) {
+  double d = 0.0;
+  for (int i = 0; i < k; ++i) {
+    const volatile float p = x[i] * y[i];
+    d += (double)p;
+  }
+  return d;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int mals_abi_version(void) { return MALS_ABI_VERSION; }
+
+int mals_default_config(mals_config* cfg) {
+  if (!cfg) return MALS_INVALID_ARG;
+  std::memset(cfg, 0, sizeof(*cfg));
+  cfg->struct_size = (int32_t)sizeof(mals_config);
+  cfg->features = 30;   // MatrixFactorizer.java:34 DEFAULT_FEATURES
+  cfg->alpha = 1.0;     // ALS:71
+  cfg->lambda = 0.1;    // ALS:73
+  cfg->singularity_threshold = 1.0e-5;
+  cfg->flags = 0;
+  cfg->device = 0;
+  cfg->segment_nnz = 0;
+  return MALS_OK;
+}
+
+int mals_create(const mals_config* cfg, mals_handle* out) {
+  if (!cfg || !out) return MALS_INVALID_ARG;
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(mals_config)) return MALS_INVALID_ARG;
+  if (cfg->features <= 0 || cfg->features > 128) return MALS_INVALID_ARG;  // ALS:139
+  if (!(cfg->lambda >= 0.0) || !std::isfinite(cfg->alpha)) return MALS_INVALID_ARG;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || cfg->device < 0 || cfg->device >= n_dev) return MALS_HIP_ERROR;
+  mals_handle h = new (std::nothrow) mals_handle_s();
+  if (!h) return MALS_OOM;
+  h->cfg = *cfg;
+  if (h->cfg.segment_nnz <= 0) h->cfg.segment_nnz = 4096;
+  h->cfg.segment_nnz = (h->cfg.segment_nnz + 3) & ~3;
+  h->T = (cfg->features + 15) / 16;
+  std::memset(&h->stats, 0, sizeof(h->stats));
+  h->stats.struct_size = (int32_t)sizeof(mals_stats);
+  if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc(&h->h_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(h->d_bad, 0xff, 2 * sizeof(unsigned long long)) != hipSuccess) {
+    delete h;
+    return MALS_HIP_ERROR;
+  }
+  *out = h;
+  return MALS_OK;
+}
+
+int mals_destroy(mals_handle h) {
+  if (!h) return MALS_INVALID_ARG;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipStreamSynchronize(h->stream);
+  for (PendingEvent& pe : h->pending) {
+    (void)hipEventDestroy(pe.a);
+    (void)hipEventDestroy(pe.b);
+  }
+  for (int sd = 0; sd < 2; ++sd) {
+    SideState& s = h->side[sd];
+    free_matrix(s);
+    if (s.F_owned) free_dev(s.F);
+    free_dev(s.G);
+    free_dev(s.Gf);
+    free_dev(s.partials);
+  }
+  free_dev(h->d_bad);
+  if (h->h_bad) (void)hipHostFree(h->h_bad);
+  free_dev(h->d_idx);
+  free_dev(h->d_rows);
+  delete h;
+  return MALS_OK;
+}
+
+const char* mals_last_error(mals_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int mals_set_stream(mals_handle h, void* hip_stream) {
+  if (!h) return MALS_INVALID_ARG;
+  h->stream = (hipStream_t)hip_stream;
+  return MALS_OK;
+}
+
+int mals_set_factor_rows(mals_handle h, int side, int64_t n_rows_total) {
+  CHECK_SIDE(h, side);
+  if (n_rows_total <= 0) return fail(h, MALS_INVALID_ARG, "n_rows_total must be positive");
+  if (int rc = use_device(h)) return rc;
+  SideState& s = h->side[side];
+  if (s.F_owned) free_dev(s.F);
+  s.F = nullptr;
+  const size_t bytes = sizeof(float) * (size_t)n_rows_total * (size_t)h->cfg.features;
+  HIPCHK(h, hipMalloc(&s.F, bytes));
+  HIPCHK(h, hipMemsetAsync(s.F, 0, bytes, h->stream));
+  s.F_owned = true;
+  s.n_total = n_rows_total;
+  s.G_valid = false;
+  return MALS_OK;
+}
+
+int mals_bind_factors(mals_handle h, int side, float* device_ptr, int64_t n_rows_total) {
+  CHECK_SIDE(h, side);
+  if (!device_ptr || n_rows_total <= 0) return fail(h, MALS_INVALID_ARG, "null buffer or non-positive row count");
+  if (int rc = use_device(h)) return rc;
+  SideState& s = h->side[side];
+  if (s.F_owned) free_dev(s.F);
+  s.F = device_ptr;
+  s.F_owned = false;
+  s.n_total = n_rows_total;
+  s.G_valid = false;
+  return MALS_OK;
+}
+
+int mals_factor_device_ptr(mals_handle h, int side, void** out_device_ptr, int64_t* out_n_rows_total) {
+  CHECK_SIDE(h, side);
+  if (out_device_ptr) *out_device_ptr = h->side[side].F;
+  if (out_n_rows_total) *out_n_rows_total = h->side[side].n_total;
+  return h->side[side].F ? MALS_OK : fail(h, MALS_INVALID_ARG, "factor replica not allocated");
+}
+
+int mals_set_matrix(mals_handle h, int side, int64_t row_offset, int64_t n_rows_local, int64_t nnz, const int64_t* row_ptr,
+                    const int32_t* col_idx, const float* val, int mem_kind) {
+  CHECK_SIDE(h, side);
+  if (row_offset < 0 || n_rows_local < 0 || nnz < 0 || !row_ptr || (nnz > 0 && (!col_idx || !val)))
+    return fail(h, MALS_INVALID_ARG, "bad matrix arguments");
+  if (n_rows_local > std::numeric_limits<int32_t>::max())
+    return fail(h, MALS_INVALID_ARG, "at most 2^31-1 local rows per handle");
+  if (int rc = use_device(h)) return rc;
+  SideState& s = h->side[side];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_matrix(s);
+  s.row_offset = row_offset;
+  s.n_local = n_rows_local;
+  s.nnz = nnz;
+  s.h_row_ptr.resize((size_t)n_rows_local + 1);
+  if (mem_kind == MALS_MEM_DEVICE) {
+    HIPCHK(h, hipMemcpy(s.h_row_ptr.data(), row_ptr, sizeof(int64_t) * (size_t)(n_rows_local + 1), hipMemcpyDeviceToHost));
+    s.row_ptr = const_cast<int64_t*>(row_ptr);
+    s.col = const_cast<int32_t*>(col_idx);
+    s.val = const_cast<float*>(val);
+    s.m_owned = false;
+  } else if (mem_kind == MALS_MEM_HOST) {
+    std::memcpy(s.h_row_ptr.data(), row_ptr, sizeof(int64_t) * (size_t)(n_rows_local + 1));
+    s.m_owned = true;
+    HIPCHK(h, hipMalloc(&s.row_ptr, sizeof(int64_t) * (size_t)(n_rows_local + 1)));
+    HIPCHK(h, hipMemcpy(s.row_ptr, row_ptr, sizeof(int64_t) * (size_t)(n_rows_local + 1), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&s.col, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+    HIPCHK(h, hipMalloc(&s.val, sizeof(float) * (size_t)std::max<int64_t>(nnz, 1)));
+    if (nnz) {
+      HIPCHK(h, hipMemcpy(s.col, col_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice));
+      HIPCHK(h, hipMemcpy(s.val, val, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
+    }
+  } else {
+    return fail(h, MALS_INVALID_ARG, "mem_kind must be MALS_MEM_HOST or MALS_MEM_DEVICE");
+  }
+  if (int rc = validate_matrix(h, side)) {
+    free_matrix(s);
+    return rc;
+  }
+  if (int rc = build_work_lists(h, s)) {
+    free_matrix(s);
+    return rc;
+  }
+  s.has_matrix = true;
+  return MALS_OK;
+}
+
+int mals_begin_matrix(mals_handle h, int side, int64_t row_offset, int64_t n_rows_local, int64_t nnz) {
+  CHECK_SIDE(h, side);
+  if (row_offset < 0 || n_rows_local < 0 || nnz < 0) return fail(h, MALS_INVALID_ARG, "bad matrix arguments");
+  if (n_rows_local > std::numeric_limits<int32_t>::max())
+    return fail(h, MALS_INVALID_ARG, "at most 2^31-1 local rows per handle");
+  if (int rc = use_device(h)) return rc;
+  SideState& s = h->side[side];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_matrix(s);
+  s.row_offset = row_offset;
+  s.n_local = n_rows_local;
+  s.nnz = nnz;
+  s.h_row_ptr.assign((size_t)n_rows_local + 1, 0);
+  s.m_owned = true;
+  HIPCHK(h, hipMalloc(&s.row_ptr, sizeof(int64_t) * (size_t)(n_rows_local + 1)));
+  HIPCHK(h, hipMalloc(&s.col, sizeof(int32_t) * (size_t)std::max<int64_t>(nnz, 1)));
+  HIPCHK(h, hipMalloc(&s.val, sizeof(float) * (size_t)std::max<int64_t>(nnz, 1)));
+  s.append_rows = 0;
+  s.append_nnz = 0;
+  s.appending = true;
+  return MALS_OK;
+}
+
+int mals_append_rows(mals_handle h, int side, int64_t n_rows, const int64_t* row_ptr_chunk, const int32_t* col_idx,
+                     const float* val) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  if (!s.appending) return fail(h, MALS_INVALID_ARG, "mals_append_rows without mals_begin_matrix");
+  if (n_rows < 0 || !row_ptr_chunk || row_ptr_chunk[0] != 0) return fail(h, MALS_INVALID_ARG, "bad chunk");
+  const int64_t cn = row_ptr_chunk[n_rows];
+  if (s.append_rows + n_rows > s.n_local || s.append_nnz + cn > s.nnz || (cn > 0 && (!col_idx || !val)))
+    return fail(h, MALS_INVALID_ARG, "chunk exceeds the declared matrix size");
+  if (int rc = use_device(h)) return rc;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    if (row_ptr_chunk[r + 1] < row_ptr_chunk[r]) return fail(h, MALS_INVALID_ARG, "row_ptr must be non-decreasing");
+    s.h_row_ptr[(size_t)(s.append_rows + r + 1)] = s.append_nnz + row_ptr_chunk[r + 1];
+  }
+  if (cn) {
+    HIPCHK(h, hipMemcpy(s.col + s.append_nnz, col_idx, sizeof(int32_t) * (size_t)cn, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(s.val + s.append_nnz, val, sizeof(float) * (size_t)cn, hipMemcpyHostToDevice));
+  }
+  s.append_rows += n_rows;
+  s.append_nnz += cn;
+  return MALS_OK;
+}
+
+int mals_end_matrix(mals_handle h, int side) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  if (!s.appending) return fail(h, MALS_INVALID_ARG, "mals_end_matrix without mals_begin_matrix");
+  s.appending = false;
+  if (s.append_rows != s.n_local || s.append_nnz != s.nnz) {
+    free_matrix(s);
+    return fail(h, MALS_INVALID_ARG, "appended rows/entries do not match the declared matrix size");
+  }
+  if (int rc = use_device(h)) return rc;
+  HIPCHK(h, hipMemcpy(s.row_ptr, s.h_row_ptr.data(), sizeof(int64_t) * (size_t)(s.n_local + 1), hipMemcpyHostToDevice));
+  if (int rc = build_work_lists(h, s)) {
+    free_matrix(s);
+    return rc;
+  }
+  s.has_matrix = true;
+  return MALS_OK;
+}
+
+int mals_set_factors(mals_handle h, int side, int64_t row_begin, int64_t n_rows, const float* host_rows) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  if (!s.F) return fail(h, MALS_INVALID_ARG, "factor replica not allocated");
+  if (row_begin < 0 || n_rows < 0 || row_begin + n_rows > s.n_total || !host_rows)
+    return fail(h, MALS_INVALID_ARG, "row range outside the factor replica");
+  if (int rc = use_device(h)) return rc;
+  const int k = h->cfg.features;
+  HIPCHK(h, hipMemcpyAsync(s.F + row_begin * k, host_rows, sizeof(float) * (size_t)n_rows * k, hipMemcpyHostToDevice,
+                           h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  s.G_valid = false;
+  return MALS_OK;
+}
+
+int mals_get_factors(mals_handle h, int side, int64_t row_begin, int64_t n_rows, float* host_out) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  if (!s.F) return fail(h, MALS_INVALID_ARG, "factor replica not allocated");
+  if (row_begin < 0 || n_rows < 0 || row_begin + n_rows > s.n_total || !host_out)
+    return fail(h, MALS_INVALID_ARG, "row range outside the factor replica");
+  if (int rc = use_device(h)) return rc;
+  const int k = h->cfg.features;
+  HIPCHK(h, hipMemcpyAsync(host_out, s.F + row_begin * k, sizeof(float) * (size_t)n_rows * k, hipMemcpyDeviceToHost,
+                           h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MALS_OK;
+}
+
+int mals_get_rows(mals_handle h, int side, const int64_t* row_idx, int32_t n, float* host_out) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  if (!s.F) return fail(h, MALS_INVALID_ARG, "factor replica not allocated");
+  if (n < 0 || (n > 0 && (!row_idx || !host_out))) return fail(h, MALS_INVALID_ARG, "bad row list");
+  if (n == 0) return MALS_OK;
+  for (int i = 0; i < n; ++i)
+    if (row_idx[i] < 0 || row_idx[i] >= s.n_total) return fail(h, MALS_INVALID_ARG, "row index outside the factor replica");
+  if (int rc = use_device(h)) return rc;
+  const int k = h->cfg.features;
+  if (h->idx_cap < n) {
+    free_dev(h->d_idx);
+    free_dev(h->d_rows);
+    HIPCHK(h, hipMalloc(&h->d_idx, sizeof(int64_t) * (size_t)n));
+    HIPCHK(h, hipMalloc(&h->d_rows, sizeof(float) * (size_t)n * k));
+    h->idx_cap = n;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->d_idx, row_idx, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, h->stream, s.F, h->d_idx, n, k,
+                     h->d_rows);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(host_out, h->d_rows, sizeof(float) * (size_t)n * k, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MALS_OK;
+}
+
+int mals_gramian(mals_handle h, int side, double* host_G) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  if (!s.F) return fail(h, MALS_INVALID_ARG, "factor replica not allocated");  // MU:220-222 null/empty M
+  if (int rc = use_device(h)) return rc;
+  if (int rc = ensure_gramian_buffers(h, s)) return rc;
+  PendingEvent pe;
+  if (int rc = begin_timed(h, 1, pe)) return rc;
+  if (int rc = launch_gramian(h, s, s.F, s.n_total, s.G, s.Gf)) return rc;
+  if (int rc = end_timed(h, pe)) return rc;
+  s.G_valid = true;
+  if (host_G) {
+    const int k = h->cfg.features;
+    HIPCHK(h, hipMemcpyAsync(host_G, s.G, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return MALS_OK;
+}
+
+int mals_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_rows, double* device_out) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  if (!s.F) return fail(h, MALS_INVALID_ARG, "factor replica not allocated");
+  if (row_begin < 0 || n_rows <= 0 || row_begin + n_rows > s.n_total || !device_out)
+    return fail(h, MALS_INVALID_ARG, "row range outside the factor replica");
+  if (int rc = use_device(h)) return rc;
+  PendingEvent pe;
+  if (int rc = begin_timed(h, 1, pe)) return rc;
+  if (int rc = launch_gramian(h, s, s.F + row_begin * h->cfg.features, n_rows, device_out, nullptr)) return rc;
+  return end_timed(h, pe);
+}
+
+int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) {
+  CHECK_SIDE(h, side);
+  if (!G) return fail(h, MALS_INVALID_ARG, "null Gramian");
+  SideState& s = h->side[side];
+  if (int rc = use_device(h)) return rc;
+  if (int rc = ensure_gramian_buffers(h, s)) return rc;
+  const int k = h->cfg.features, ld = 16 * h->T;
+  HIPCHK(h, hipMemcpyAsync(s.G, G, sizeof(double) * (size_t)k * k,
+                           mem_kind == MALS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(gramian_pack_kernel, dim3((unsigned)((ld * ld + 255) / 256)), dim3(256), 0, h->stream, s.G, k, ld, s.Gf);
+  HIPCHK(h, hipGetLastError());
+  if (mem_kind != MALS_MEM_DEVICE) HIPCHK(h, hipStreamSynchronize(h->stream));
+  s.G_valid = true;
+  return MALS_OK;
+}
+
+int mals_solve_side(mals_handle h, int side) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  SideState& o = h->side[1 - side];
+  if (!s.has_matrix) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
+  if (!s.F || !o.F) return fail(h, MALS_INVALID_ARG, "factor replicas not allocated");
+  if (s.row_offset + s.n_local > s.n_total) return fail(h, MALS_INVALID_ARG, "matrix rows exceed the factor replica");
+  const bool use_g = !(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED);
+  if (use_g && !o.G_valid) return fail(h, MALS_INVALID_ARG, "Gramian of the opposite side not computed");
+  if (int rc = use_device(h)) return rc;
+  if (s.n_local == 0) return MALS_OK;
+  const int k = h->cfg.features;
+  SolveParams p;
+  p.row_ptr = s.row_ptr;
+  p.col = s.col;
+  p.val = s.val;
+  p.M = o.F;
+  p.Gf = o.Gf;
+  p.out = s.F + s.row_offset * k;
+  p.order = s.orderA;
+  p.segs = s.segs;
+  p.rowsC = s.rowsC;
+  p.scratch = s.scratch;
+  p.bad_row = h->d_bad + side;
+  p.n_work = 0;
+  p.k = k;
+  p.flags = h->cfg.flags;
+  p.alpha = (float)h->cfg.alpha;
+  p.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);  // ALS:435
+  p.sing_threshold = (float)h->cfg.singularity_threshold;
+  PendingEvent pe;
+  if (int rc = begin_timed(h, 0, pe)) return rc;
+  if (int rc = launch_solve(h, s, p)) return rc;
+  if (int rc = end_timed(h, pe)) return rc;
+  s.G_valid = false;  // this side's factors changed
+  h->stats.rows_solved += s.n_local;
+  h->stats.nnz_gathered += s.nnz;
+  h->stats.algorithmic_bytes += (double)s.nnz * (4.0 * k + 8.0) + (double)s.n_local * (4.0 * k + 8.0);
+  return MALS_OK;
+}
+
+int mals_check(mals_handle h) {
+  if (!h) return MALS_INVALID_ARG;
+  if (int rc = use_device(h)) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->h_bad, h->d_bad, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int sd = 0; sd < 2; ++sd) {
+    if (h->h_bad[sd] != ~0ull) {
+      h->sing_side = sd;
+      h->sing_row = h->side[sd].row_offset + (int64_t)h->h_bad[sd];
+      // The reference reports RRQR's getRank(0.01) (CMLSS:47); no test pins that value.  The
+      // native core reports 0 = "unknown"; the adapter recomputes it in Java if it needs it.
+      h->sing_rank = 0;
+      HIPCHK(h, hipMemsetAsync(h->d_bad, 0xff, 2 * sizeof(unsigned long long), h->stream));
+      char buf[160];
+      std::snprintf(buf, sizeof(buf), "near-singular system (pivot <= %g) for row %lld of side %c", h->cfg.singularity_threshold,
+                    (long long)h->sing_row, sd == MALS_SIDE_X ? 'X' : 'Y');
+      return fail(h, MALS_SINGULAR, buf);
+    }
+  }
+  return MALS_OK;
+}
+
+int mals_singular_info(mals_handle h, int32_t* side, int64_t* row, int32_t* apparent_rank) {
+  if (!h) return MALS_INVALID_ARG;
+  if (side) *side = h->sing_side;
+  if (row) *row = h->sing_row;
+  if (apparent_rank) *apparent_rank = h->sing_rank;
+  return MALS_OK;
+}
+
+int mals_half_iteration(mals_handle h, int side) {
+  CHECK_SIDE(h, side);
+  if (!(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) || !h->side[1 - side].G_valid) {
+    if (int rc = mals_gramian(h, 1 - side, nullptr)) return rc;  // ALS:342 / ALS:369
+  }
+  if (int rc = mals_solve_side(h, side)) return rc;                // ALS:344 / ALS:371
+  return mals_check(h);                                            // ALS:346-361 f.get()
+}
+
+int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iterations, int32_t random_y, int32_t iterate,
+                   const int64_t* test_users, int32_t n_test_users, const int64_t* test_items, int32_t n_test_items,
+                   int32_t* iterations_out, double* convergence_out) {
+  if (!h) return MALS_INVALID_ARG;
+  if (iterations_out) *iterations_out = 0;
+  if (convergence_out) *convergence_out = std::numeric_limits<double>::quiet_NaN();
+  // ALS:140-141 threshold must be in (0,1)
+  if (!(convergence_threshold > 0.0 && convergence_threshold < 1.0))
+    return fail(h, MALS_INVALID_ARG, "threshold must be in (0,1)");
+  if (n_test_users < 0 || n_test_items < 0 || (n_test_users > 0 && !test_users) || (n_test_items > 0 && !test_items))
+    return fail(h, MALS_INVALID_ARG, "bad convergence sample");
+  h->cancelled.store(0);
+  if (!iterate) return mals_half_iteration(h, MALS_SIDE_X);  // ALS:196-204
+  const int k = h->cfg.features;
+  std::vector<double> est((size_t)n_test_users * (size_t)n_test_items, 0.0);  // ALS:215: X empty => 0
+  std::vector<float> xu((size_t)n_test_users * k), yi((size_t)n_test_items * k);
+  int it = 0;
+  for (;;) {
+    if (h->cancelled.load()) return fail(h, MALS_CANCELLED, "cancelled");
+    if (int rc = mals_half_iteration(h, MALS_SIDE_X)) return rc;  // ALS:228
+    if (h->cancelled.load()) return fail(h, MALS_CANCELLED, "cancelled");
+    if (int rc = mals_half_iteration(h, MALS_SIDE_Y)) return rc;  // ALS:229
+    if (int rc = mals_get_rows(h, MALS_SIDE_X, test_users, n_test_users, xu.data())) return rc;
+    if (int rc = mals_get_rows(h, MALS_SIDE_Y, test_items, n_test_items, yi.data())) return rc;
+    double tw = 0.0, mean = std::numeric_limits<double>::quiet_NaN();
+    for (int i = 0; i < n_test_users; ++i) {
+      for (int j = 0; j < n_test_items; ++j) {  // ALS:231-238
+        const double nv = dot_f(&xu[(size_t)i * k], &yi[(size_t)j * k], k);
+        const double ov = est[(size_t)i * n_test_items + j];
+        est[(size_t)i * n_test_items + j] = nv;
+        dwm_increment(tw, mean, std::fabs(nv - ov), nv > 0.0 ? nv : 0.0);
+      }
+    }
+    ++it;
+    if (iterations_out) *iterations_out = it;
+    if (convergence_out) *convergence_out = mean;
+    if (max_iterations > 0 && it >= max_iterations) break;                 // ALS:242-245
+    if (!std::isfinite(mean)) break;                                       // ALS:248-251
+    if (!(random_y && it == 1) && mean < convergence_threshold) break;     // ALS:253-256
+  }
+  return MALS_OK;
+}
+
+int mals_cancel(mals_handle h) {
+  if (!h) return MALS_INVALID_ARG;
+  h->cancelled.store(1);
+  return MALS_OK;
+}
+
+int mals_enable_timing(mals_handle h, int32_t on) {
+  if (!h) return MALS_INVALID_ARG;
+  h->timing = on != 0;
+  return MALS_OK;
+}
+
+int mals_reset_stats(mals_handle h) {
+  if (!h) return MALS_INVALID_ARG;
+  if (int rc = use_device(h)) return rc;
+  if (int rc = drain_events(h)) return rc;
+  std::memset(&h->stats, 0, sizeof(h->stats));
+  h->stats.struct_size = (int32_t)sizeof(mals_stats);
+  return MALS_OK;
+}
+
+int mals_get_stats(mals_handle h, mals_stats* out) {
+  if (!h || !out) return MALS_INVALID_ARG;
+  if (int rc = use_device(h)) return rc;
+  if (int rc = drain_events(h)) return rc;
+  *out = h->stats;
+  return MALS_OK;
+}
+
+}  // extern "C"

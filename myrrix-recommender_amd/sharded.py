@@ -1,0 +1,100 @@
+"""Row-sharded ALS across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI) for the single exchange step per half-iteration.
+
+Sharding: within a half-iteration rows are independent given the full
+opposite factor matrix and its Gramian -- exactly how the reference threads the work
+(ALS:391-410, one writer per output row ALS:497-499).  Each rank holds
+  * the CSR rows of its slice of users and the CSR rows (of R^T) of its slice of items,
+  * FULL replicas of X and Y (torch tensors bound into the handle with mals_bind_factors),
+and after solving its slice all-gathers it in place into every replica.  The shared Gramian
+M^T M is computed as per-rank partials over the rank's own slice + a k x k fp64 all-reduce.
+Slices are equal-sized (rows_per_rank = ceil(n/world), the tail of the last slice is zero padding
+that no column index references), so the all-gather is the plain in-place NCCL all-gather.
+
+torch.distributed is plumbing here (rendezvous, RCCL communicator, stream ordering); all compute
+is in libmyrrix_als.so.  `core` is duck-typed so that the world_size-2 gloo test on CPU can inject
+a checker-backed stand-in (tests/test_sharded_gloo.py); the product path passes an ALSCore.
+"""
+from ._lib import SIDE_X, SIDE_Y
+
+
+def rows_per_rank(n, world):
+    return (n + world - 1) // world
+
+
+class ShardedALS:
+    def __init__(self, core, n_users, n_items, features, rank=0, world=1, device="cuda",
+                 gramian_mode="allreduce"):
+        import torch
+        self.torch = torch
+        self.core = core
+        self.k = features
+        self.rank, self.world = rank, world
+        self.n = {SIDE_X: n_users, SIDE_Y: n_items}
+        self.per = {SIDE_X: rows_per_rank(n_users, world), SIDE_Y: rows_per_rank(n_items, world)}
+        self.device = device
+        self.gramian_mode = gramian_mode
+        self.F = {}
+        for side in (SIDE_X, SIDE_Y):
+            self.F[side] = torch.zeros(self.per[side] * world, features, dtype=torch.float32, device=device)
+            core.bind_factors(side, self.F[side])
+        self._gp = torch.zeros(features, features, dtype=torch.float64, device=device)
+
+    # -- data -------------------------------------------------------------------------------------
+    def slice_bounds(self, side, rank=None):
+        rank = self.rank if rank is None else rank
+        r0 = min(self.n[side], rank * self.per[side])
+        r1 = min(self.n[side], (rank + 1) * self.per[side])
+        return r0, r1
+
+    def set_matrix_from_full(self, side, row_ptr, col_idx, val):
+        """Keep this rank's rows of a full CSR (numpy arrays or torch tensors)."""
+        r0, r1 = self.slice_bounds(side)
+        e0, e1 = int(row_ptr[r0]), int(row_ptr[r1])
+        rp = row_ptr[r0:r1 + 1] - row_ptr[r0]
+        self.core.set_matrix(side, rp, col_idx[e0:e1], val[e0:e1], row_offset=r0)
+
+    def set_factors(self, side, rows):
+        """Install (replicated) factor rows [0, len(rows)) -- e.g. the initial Y."""
+        t = self.torch.as_tensor(rows, dtype=self.torch.float32).to(self.device)
+        self.F[side][:t.shape[0]].copy_(t)
+
+    def factors(self, side):
+        return self.F[side][:self.n[side]]
+
+    # -- one half-iteration -----------------------------------------------------------------------
+    def _gramian(self, side):
+        """Install G = M^T M of `side`'s factors for the next solve of the other side."""
+        if self.world == 1 or self.gramian_mode == "replicated":
+            self.core.gramian(side)
+            return
+        import torch.distributed as dist
+        r0 = self.rank * self.per[side]
+        self.core.gramian_partial(side, r0, self.per[side], self._gp)
+        dist.all_reduce(self._gp)
+        self.core.set_gramian(side, self._gp)
+
+    def _all_gather(self, side):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        full = self.F[side]
+        mine = full[self.rank * self.per[side]:(self.rank + 1) * self.per[side]]
+        try:
+            dist.all_gather_into_tensor(full, mine)
+        except (RuntimeError, NotImplementedError):
+            chunks = list(full.chunk(self.world, dim=0))
+            dist.all_gather(chunks, mine.clone())
+
+    def half_iteration(self, side):
+        """iterateXFromY (ALS:340-362) for SIDE_X / iterateYFromX (ALS:367-389) for SIDE_Y."""
+        self._gramian(1 - side)
+        self.core.solve_side(side)
+        self._all_gather(side)
+
+    def iterate(self, n=1, check=True):
+        for _ in range(n):
+            self.half_iteration(SIDE_X)
+            self.half_iteration(SIDE_Y)
+        if check:
+            self.core.check()

@@ -1,0 +1,85 @@
+"""Seeded synthetic interaction matrices (BASELINE.md section 3 / SURVEY.md section 8d).
+
+Item popularity is a power law (item = floor(I * u^3), i.e. density ~ rank^(-2/3)), user activity
+is log-normal (sigma 1), strengths are integers 1..5.  Duplicate (user,item) pairs are merged, so
+the realised nnz is slightly below the request.  Seed 1234567890 = RandomManager.java:52.
+`numpy_problem` is for tests (host arrays), `torch_problem` builds the large bench matrices on the
+GPU (CSR by user and CSR by item, int64 row_ptr / int32 col / fp32 val)."""
+import numpy as np
+
+SEED = 1234567890
+
+
+def _csr_from_sorted_keys(keys, n_rows, n_cols, xp, vals):
+    rows = keys // n_cols
+    cols = (keys % n_cols)
+    return rows, cols, vals
+
+
+def numpy_problem(n_users, n_items, nnz, k, seed=SEED, negatives=0.0):
+    """Returns (r_csr, c_csr, Y0): CSR by user, CSR by item (both (row_ptr, col, val)) and a
+    unit-norm random initial Y (plain N(0,1) rows normalised -- not the far-from sampler)."""
+    rng = np.random.default_rng(seed)
+    act = rng.lognormal(0.0, 1.0, n_users)
+    p_user = act / act.sum()
+    users = rng.choice(n_users, size=nnz, p=p_user)
+    items = np.minimum((n_items * rng.random(nnz) ** 3).astype(np.int64), n_items - 1)
+    keys = np.unique(users.astype(np.int64) * n_items + items)
+    u = (keys // n_items).astype(np.int64)
+    i = (keys % n_items).astype(np.int64)
+    vals = rng.integers(1, 6, size=len(keys)).astype(np.float32)
+    if negatives > 0:
+        vals = np.where(rng.random(len(keys)) < negatives, -vals, vals).astype(np.float32)
+
+    def csr(r, c, v, n):
+        order = np.lexsort((c, r))
+        r, c, v = r[order], c[order], v[order]
+        row_ptr = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(row_ptr, r + 1, 1)
+        return np.cumsum(row_ptr).astype(np.int64), c.astype(np.int32), v.astype(np.float32)
+
+    r_csr = csr(u, i, vals, n_users)
+    c_csr = csr(i, u, vals, n_items)
+    Y0 = rng.standard_normal((n_items, k)).astype(np.float32)
+    Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True).astype(np.float32)
+    return r_csr, c_csr, Y0
+
+
+def torch_problem(n_users, n_items, nnz, k, device, seed=SEED, chunk=1 << 27):
+    """Large problems, generated on `device`.  Returns dict with r_csr, c_csr (torch tensors on the
+    device), Y0 and the realised nnz."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    act = torch.exp(torch.randn(n_users, generator=g, device=device, dtype=torch.float32))
+    cdf = torch.cumsum(act.double(), 0)
+    cdf = (cdf / cdf[-1]).float()
+    keys = []
+    done = 0
+    while done < nnz:
+        m = min(chunk, nnz - done)
+        uu = torch.searchsorted(cdf, torch.rand(m, generator=g, device=device)).clamp_(max=n_users - 1)
+        ii = (n_items * torch.rand(m, generator=g, device=device, dtype=torch.float64) ** 3).long().clamp_(max=n_items - 1)
+        keys.append(uu * n_items + ii)
+        done += m
+        del uu, ii
+    keys = torch.unique(torch.cat(keys))          # sorted by (user, item)
+    n = keys.numel()
+    u = torch.div(keys, n_items, rounding_mode="floor")
+    i = keys - u * n_items
+    del keys
+    vals = torch.randint(1, 6, (n,), generator=g, device=device).float()
+
+    def row_ptr_of(r, n_rows):
+        counts = torch.bincount(r, minlength=n_rows)
+        rp = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
+        torch.cumsum(counts, 0, out=rp[1:])
+        return rp
+
+    r_csr = (row_ptr_of(u, n_users), i.int(), vals)
+    order = torch.argsort(i * n_users + u)        # by (item, user)
+    c_csr = (row_ptr_of(i, n_items), u[order].int(), vals[order])
+    del order, u, i
+    Y0 = torch.randn(n_items, k, generator=g, device=device, dtype=torch.float32)
+    Y0 /= Y0.norm(dim=1, keepdim=True)
+    return {"r_csr": r_csr, "c_csr": c_csr, "Y0": Y0, "nnz": n}

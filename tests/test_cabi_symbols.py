@@ -1,0 +1,66 @@
+"""The C-ABI library loads and exports every symbol include/myrrix_als.h declares (no compute
+calls here: this runs on the CPU-only box)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import myrrix_recommender_amd as pkg
+from myrrix_recommender_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "myrrix_als.h")).read()
+
+
+def declared_functions():
+    body = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    return sorted(set(re.findall(r"\b(mals_[a-z_]+)\s*\(", body)))
+
+
+def test_header_and_binding_agree():
+    assert set(declared_functions()) == set(_lib.SYMBOLS.keys())
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(L, name), name
+    assert _lib.load().mals_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # mals_config: 2 x int32, 3 x double, 4 x int32 ; mals_stats: 2 x int32, 2 x double, 4 x int64, double
+    assert ctypes.sizeof(_lib.Config) == 48
+    assert ctypes.sizeof(_lib.Stats) == 64
+    cfg = _lib.Config()
+    assert _lib.load().mals_default_config(ctypes.byref(cfg)) == _lib.OK
+    assert cfg.struct_size == 48 and cfg.features == 30            # MatrixFactorizer.java:34
+    assert cfg.alpha == 1.0 and abs(cfg.lam - 0.1) < 1e-15         # ALS:71-73
+    assert cfg.singularity_threshold == 1e-5                       # LinearSystemSolver.java:33-34
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    cfg = _lib.Config()
+    L.mals_default_config(ctypes.byref(cfg))
+    cfg.features = 0                                                # ALS:139 features must be positive
+    assert L.mals_create(ctypes.byref(cfg), ctypes.byref(h)) == _lib.INVALID_ARG
+    cfg.features = 129
+    assert L.mals_create(ctypes.byref(cfg), ctypes.byref(h)) == _lib.INVALID_ARG
+    assert L.mals_destroy(None) == _lib.INVALID_ARG
+    assert L.mals_solve_side(None, 0) == _lib.INVALID_ARG
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.MalsError) as ei:
+        pkg.ALSCore(30)
+    assert ei.value.status == _lib.HIP_ERROR
+    als = pkg.AlternatingLeastSquares({0: {0: 1.0}}, {0: {0: 1.0}}, 2, 0.001, 1)
+    with pytest.raises(pkg.ExecutionException):
+        als.call()

@@ -1,0 +1,230 @@
+"""Lane-level numpy emulation of the K2/K3 wave algorithm (one 64-lane wave per row).
+
+This is a design check, not product code and not the oracle: it executes the exact register/lane
+choreography the HIP kernel uses (myrrix-recommender_amd/csrc/als_kernels.hip) with numpy arrays
+of shape [64] standing in for VGPRs, so the MFMA fragment layouts, the blocked Cholesky and the
+triangular solves can be validated on a CPU-only box (tests/test_wave_emulation.py).
+
+Layouts (gfx950, cdna_hip_programming.md section 3):
+  v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][kk=l>>4] and B[kk=l>>4][j=l&15];
+  C/D "acc layout": lane l, reg r holds D[row=4*(l>>4)+r][col=l&15].
+"""
+import numpy as np
+
+L = np.arange(64)
+G_ = L >> 4   # lane group 0..3
+C_ = L & 15   # column within tile
+
+
+def mfma_16x16x4(a, b, acc):
+    """acc: [4][64] float32 in acc layout; a, b: [64].  Returns new acc (fp32 fma chain)."""
+    A = a.reshape(4, 16).T          # A[i][kk] = a[16*kk + i]
+    B = b.reshape(4, 16)            # B[kk][j] = b[16*kk + j]
+    D = np.zeros((16, 16), dtype=np.float32)
+    for row in range(16):
+        D[row] = acc[row & 3][16 * (row >> 2):16 * (row >> 2) + 16]
+    for kk in range(4):             # k-ordered fmaf chain (one rounding per product+add)
+        D = (D.astype(np.float64) + np.outer(A[:, kk], B[kk]).astype(np.float64)).astype(np.float32)
+    out = np.zeros((4, 64), dtype=np.float32)
+    for row in range(16):
+        out[row & 3][16 * (row >> 2):16 * (row >> 2) + 16] = D[row]
+    return out
+
+
+def shfl(x, idx):
+    return x[idx]
+
+
+def reduce_groups(x):
+    """sum over the 4 lane groups (same column): x += shfl_xor(x,16); x += shfl_xor(x,32)."""
+    x = x + x[L ^ 16]
+    x = x + x[L ^ 32]
+    return x
+
+
+def reduce_row16(x):
+    """sum over the 16 lanes of each lane row via DPP row_ror 8,4,2,1."""
+    for n in (8, 4, 2, 1):
+        x = x + x[(L & 48) | ((C_ + n) & 15)]
+    return x
+
+
+def tile_to_dense(t):
+    D = np.zeros((16, 16), dtype=np.float32)
+    for row in range(16):
+        D[row] = t[row & 3][16 * (row >> 2):16 * (row >> 2) + 16]
+    return D
+
+
+def dense_to_tile(D):
+    out = np.zeros((4, 64), dtype=np.float32)
+    for row in range(16):
+        out[row & 3][16 * (row >> 2):16 * (row >> 2) + 16] = D[row]
+    return out
+
+
+def wave_gram_rhs(Yg, w, cb, k):
+    """Gather phase.  Yg: [n_u][k] gathered opposing rows (fp32), w: [n_u] Gramian weights,
+    cb: [n_u] RHS weights.  Returns (acc[ti][tj] tiles for ti<=tj, bcol[v])."""
+    T = (k + 15) // 16
+    n_u = Yg.shape[0]
+    acc = {(i, j): np.zeros((4, 64), np.float32) for i in range(T) for j in range(i, T)}
+    bpart = [np.zeros(64, np.float32) for _ in range(T)]
+    steps = (n_u + 3) // 4
+    for s in range(steps):
+        n = 4 * s + G_
+        valid_n = n < n_u
+        nn = np.where(valid_n, n, 0)
+        wn = np.where(valid_n, w[nn] if n_u else 0.0, 0.0).astype(np.float32)
+        cbn = np.where(valid_n, cb[nn] if n_u else 0.0, 0.0).astype(np.float32)
+        yv = []
+        for v in range(T):
+            f = 16 * v + C_
+            ok = valid_n & (f < k)
+            yv.append(np.where(ok, Yg[nn, np.minimum(f, k - 1)] if n_u else 0.0, 0.0).astype(np.float32))
+        a = [(wn * yv[v]).astype(np.float32) for v in range(T)]
+        for i in range(T):
+            for j in range(i, T):
+                acc[(i, j)] = mfma_16x16x4(a[i], yv[j], acc[(i, j)])
+        for v in range(T):
+            bpart[v] = (bpart[v] + cbn * yv[v]).astype(np.float32)
+    bcol = [reduce_groups(bpart[v]) for v in range(T)]
+    return acc, bcol
+
+
+def wave_add_base(acc, Gd, ridge, k, use_g=True):
+    """acc += G (acc-layout image of the fp32 Gramian), += ridge on the diagonal, 1 on padding."""
+    T = (k + 15) // 16
+    Gp = np.zeros((16 * T, 16 * T), np.float32)
+    if use_g:
+        Gp[:k, :k] = Gd.astype(np.float32)
+    for i in range(T):
+        for j in range(i, T):
+            acc[(i, j)] = (acc[(i, j)] + dense_to_tile(Gp[16 * i:16 * i + 16, 16 * j:16 * j + 16])).astype(np.float32)
+    for v in range(T):
+        t = acc[(v, v)]
+        for r in range(4):
+            diag = (4 * G_ + r) == C_
+            feat = 16 * v + C_
+            t[r] = np.where(diag & (feat < k), t[r] + np.float32(ridge), t[r])
+            t[r] = np.where(diag & (feat >= k), np.float32(1.0), t[r])
+    return acc
+
+
+def wave_factor_diag(D):
+    """In-tile Cholesky of a full symmetric 16x16 tile D (acc layout).  Returns (U, Uinv, minpiv):
+    U upper triangular with U^T U = D, Uinv = U^{-1}, both in acc layout."""
+    D = D.copy()
+    E = np.zeros((4, 64), np.float32)
+    for r in range(4):
+        E[r] = np.where((4 * G_ + r) == C_, 1.0, 0.0)
+    minpiv = np.inf
+    for m in range(16):
+        gm, rm = m >> 2, m & 3
+        piv = D[rm][16 * gm + m]                   # v_readlane (static lane)
+        minpiv = min(minpiv, piv)
+        s = np.float32(1.0) / np.sqrt(np.float32(piv))
+        urow = (shfl(D[rm], 16 * gm + C_) * s).astype(np.float32)
+        urow = np.where(C_ >= m, urow, np.float32(0))
+        erow = (shfl(E[rm], 16 * gm + C_) * s).astype(np.float32)
+        for r in range(4):
+            row = 4 * G_ + r
+            ucol = (shfl(D[r], (L & 48) | m) * s).astype(np.float32)   # D[row][m]*s (symmetry)
+            ucol = np.where(row > m, ucol, np.float32(0))
+            D[r] = (D[r] - ucol * urow).astype(np.float32)
+            E[r] = (E[r] - ucol * erow).astype(np.float32)
+        D[rm] = np.where(G_ == gm, urow, D[rm])
+        E[rm] = np.where(G_ == gm, erow, E[rm])
+    # Uinv = E^T: Uinv.reg[r](g,c) = E[c][4g+r] = E.reg[c&3] at lane (c>>2, 4g+r)
+    Uinv = np.zeros((4, 64), np.float32)
+    for r in range(4):
+        src = 16 * (C_ >> 2) + 4 * G_ + r
+        t = [shfl(E[q], src) for q in range(4)]
+        Uinv[r] = np.select([(C_ & 3) == q for q in range(4)], t)
+    return D, Uinv, minpiv
+
+
+def wave_cholesky(acc, T):
+    """Blocked right-looking Cholesky on the upper tiles.  On return acc[(i,j)], i<j hold U tiles
+    and acc[(i,i)] hold Uinv_ii."""
+    minpiv = np.inf
+    zero = np.zeros((4, 64), np.float32)
+    for kb in range(T):
+        U, Uinv, mp = wave_factor_diag(acc[(kb, kb)])
+        minpiv = min(minpiv, mp)
+        acc[(kb, kb)] = Uinv
+        for j in range(kb + 1, T):                 # TRSM: U_kj = Uinv^T A_kj
+            Q = acc[(kb, j)]
+            new = zero.copy()
+            for r in range(4):
+                new = mfma_16x16x4(Uinv[r], Q[r], new)
+            acc[(kb, j)] = new
+        for i in range(kb + 1, T):                 # SYRK: A_ij -= U_ki^T U_kj
+            for j in range(i, T):
+                P, Q = acc[(kb, i)], acc[(kb, j)]
+                t = acc[(i, j)]
+                for r in range(4):
+                    t = mfma_16x16x4(-P[r], Q[r], t)
+                acc[(i, j)] = t
+    return acc, minpiv
+
+
+def col_to_row(vcol):
+    """col layout (lane c holds v[c]) -> row layout regs r: v[4g+r]."""
+    return [shfl(vcol, (L & 48) | (4 * G_ + r)) for r in range(4)]
+
+
+def row_to_col(vrow):
+    """row layout (all lanes of group g hold v[4g+r] in reg r) -> col layout."""
+    t = [shfl(vrow[q], 16 * (C_ >> 2)) for q in range(4)]
+    return np.select([(C_ & 3) == q for q in range(4)], t)
+
+
+def wave_solve(acc, bcol, T):
+    """x = W^{-1} b with W = U^T U; acc as returned by wave_cholesky.  Returns xcol[v]."""
+    zrow = []
+    for kb in range(T):                            # forward: z = U^{-T} b
+        t = np.zeros(64, np.float32)
+        for i in range(kb):
+            for r in range(4):
+                t = (t + acc[(i, kb)][r] * zrow[i][r]).astype(np.float32)
+        rhs = (bcol[kb] - reduce_groups(t)).astype(np.float32)
+        rr = col_to_row(rhs)
+        zt = np.zeros(64, np.float32)
+        for r in range(4):
+            zt = (zt + acc[(kb, kb)][r] * rr[r]).astype(np.float32)
+        zrow.append(col_to_row(reduce_groups(zt)))
+    xcol = [None] * T
+    for kb in range(T - 1, -1, -1):                # backward: x = U^{-1} z
+        rhs_row = []
+        for r in range(4):
+            t = np.zeros(64, np.float32)
+            for j in range(kb + 1, T):
+                t = (t + acc[(kb, j)][r] * xcol[j]).astype(np.float32)
+            rhs_row.append((zrow[kb][r] - reduce_row16(t)).astype(np.float32))
+        rhs_col = row_to_col(rhs_row)
+        xr = [reduce_row16((acc[(kb, kb)][r] * rhs_col).astype(np.float32)) for r in range(4)]
+        xcol[kb] = row_to_col(xr)
+    return xcol
+
+
+def wave_solve_row(Yg, vals, Gd, k, alpha=1.0, lam=0.1, reconstruct=False, loss_ignores=False):
+    """Full per-row pipeline; returns x[k] (fp32) and the smallest Cholesky pivot."""
+    vals = np.asarray(vals, np.float32)
+    n_u = len(vals)
+    base_w = 1.0 if loss_ignores else 0.0
+    if reconstruct:
+        w = np.full(n_u, base_w, np.float32)
+        cb = vals.copy()
+    else:
+        w = (base_w + alpha * np.abs(vals)).astype(np.float32)
+        cb = np.where(vals > 0, 1.0 + alpha * np.abs(vals), 0.0).astype(np.float32)
+    T = (k + 15) // 16
+    acc, bcol = wave_gram_rhs(np.asarray(Yg, np.float32).reshape(n_u, k), w, cb, k)
+    acc = wave_add_base(acc, Gd, lam * alpha * n_u, k, use_g=not loss_ignores)
+    acc, minpiv = wave_cholesky(acc, T)
+    xcol = wave_solve(acc, bcol, T)
+    x = np.zeros(16 * T, np.float32)
+    for v in range(T):
+        x[16 * v:16 * v + 16] = xcol[v][:16]
+    return x[:k], minpiv
