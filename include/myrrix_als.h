@@ -74,15 +74,24 @@ typedef struct mals_config {
 typedef struct mals_stats {
   int32_t struct_size;
   int32_t reserved;
-  /* accumulated since mals_reset_stats; times are HIP-event milliseconds measured on the handle's
-   * stream around each launch group, only while timing is enabled (mals_enable_timing).         */
-  double gather_solve_ms;   /* K2/K3: per-row gather + Gramian + Cholesky kernels               */
-  double gramian_ms;        /* K1: M^T M kernels                                                */
-  int64_t gather_solve_launches; /* number of timed K2 launch groups (= solve_side calls)       */
+  /* Accumulated since mals_reset_stats.  Times are HIP-event milliseconds measured on the handle's
+   * stream around each kernel launch, only while timing is enabled (mals_enable_timing); bytes are
+   * the ALGORITHMIC bytes of SURVEY.md section 8(d) attributed to that kernel's launches:
+   * entries*(4k+4+4) gathered + rows*(4k+8) written.                                            */
+  double rows_ms;           /* als_rows_kernel: fused gather+Gramian+Cholesky, rows <= segment_nnz */
+  double segments_ms;       /* als_segments_kernel: gather+Gramian partials of long rows           */
+  double finish_ms;         /* als_finish_kernel: partial sums + Cholesky of long rows             */
+  double gramian_ms;        /* gramian_partial_kernel + gramian_finalize_kernel (K1)               */
+  int64_t rows_launches;
+  int64_t segments_launches;
+  int64_t finish_launches;
   int64_t gramian_launches;
+  double rows_bytes;
+  double segments_bytes;
+  double finish_bytes;
+  double gramian_bytes;     /* rows*4k read                                                        */
   int64_t rows_solved;
   int64_t nnz_gathered;
-  double algorithmic_bytes; /* sum over solve_side calls of N*(4k+8) + R*(4k+8), SURVEY 8(d)    */
 } mals_stats;
 
 int mals_abi_version(void);

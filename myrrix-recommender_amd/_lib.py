@@ -27,10 +27,13 @@ class Config(ctypes.Structure):
 
 class Stats(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("reserved", ctypes.c_int32),
-                ("gather_solve_ms", ctypes.c_double), ("gramian_ms", ctypes.c_double),
-                ("gather_solve_launches", ctypes.c_int64), ("gramian_launches", ctypes.c_int64),
-                ("rows_solved", ctypes.c_int64), ("nnz_gathered", ctypes.c_int64),
-                ("algorithmic_bytes", ctypes.c_double)]
+                ("rows_ms", ctypes.c_double), ("segments_ms", ctypes.c_double),
+                ("finish_ms", ctypes.c_double), ("gramian_ms", ctypes.c_double),
+                ("rows_launches", ctypes.c_int64), ("segments_launches", ctypes.c_int64),
+                ("finish_launches", ctypes.c_int64), ("gramian_launches", ctypes.c_int64),
+                ("rows_bytes", ctypes.c_double), ("segments_bytes", ctypes.c_double),
+                ("finish_bytes", ctypes.c_double), ("gramian_bytes", ctypes.c_double),
+                ("rows_solved", ctypes.c_int64), ("nnz_gathered", ctypes.c_int64)]
 
 
 # every symbol include/myrrix_als.h declares: name -> (restype, argtypes)
@@ -81,6 +84,15 @@ def load():
             raise ImportError(
                 "libmyrrix_als.so not found at %s -- build it with __graft_entry__.build() or "
                 "`make -C myrrix-recommender_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64/libhsa, and
+        # a process that first binds /opt/rocm's copy (through this library) and then imports torch
+        # ends up with two runtimes, the second of which sees no device.  Importing torch first
+        # makes this library resolve libamdhip64.so.7 to the copy torch already mapped.  Without
+        # torch (the JVM deployment) the system runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

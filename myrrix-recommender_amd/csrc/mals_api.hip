@@ -40,6 +40,7 @@ struct SideState {
   // work lists
   int32_t* orderA = nullptr;
   int64_t nA = 0;
+  int64_t nnzA = 0, nnzB = 0;  // entries handled by the rows kernel / the segments kernel
   SegB* segs = nullptr;
   int64_t nB = 0;
   RowC* rowsC = nullptr;
@@ -55,7 +56,8 @@ struct SideState {
 
 struct PendingEvent {
   hipEvent_t a, b;
-  int kind;  // 0 = gather/solve, 1 = gramian
+  int kind;  // 0 = rows, 1 = segments, 2 = finish, 3 = gramian
+  double bytes;
 };
 
 }  // namespace
@@ -130,6 +132,7 @@ void free_matrix(SideState& s) {
   free_dev(s.rowsC);
   free_dev(s.scratch);
   s.nA = s.nB = s.nC = 0;
+  s.nnzA = s.nnzB = 0;
   s.h_row_ptr.clear();
   s.h_row_ptr.shrink_to_fit();
 }
@@ -153,6 +156,9 @@ int build_work_lists(mals_handle h, SideState& s) {
     if (len <= seg) {
       ++count[(size_t)(seg - len)];
       ++n_short;
+      s.nnzA += len;
+    } else {
+      s.nnzB += len;
     }
   }
   int64_t acc = 0;
@@ -216,8 +222,9 @@ int validate_matrix(mals_handle h, int side) {
 }
 
 // ---- timing ------------------------------------------------------------------------------------
-int begin_timed(mals_handle h, int kind, PendingEvent& pe) {
+int begin_timed(mals_handle h, int kind, double bytes, PendingEvent& pe) {
   pe.kind = kind;
+  pe.bytes = bytes;
   pe.a = pe.b = nullptr;
   if (!h->timing) return MALS_OK;
   HIPCHK(h, hipEventCreate(&pe.a));
@@ -236,12 +243,12 @@ int drain_events(mals_handle h) {
     HIPCHK(h, hipEventSynchronize(pe.b));
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, pe.a, pe.b));
-    if (pe.kind == 0) {
-      h->stats.gather_solve_ms += ms;
-      h->stats.gather_solve_launches += 1;
-    } else {
-      h->stats.gramian_ms += ms;
-      h->stats.gramian_launches += 1;
+    mals_stats& st = h->stats;
+    switch (pe.kind) {
+      case 0: st.rows_ms += ms; st.rows_launches += 1; st.rows_bytes += pe.bytes; break;
+      case 1: st.segments_ms += ms; st.segments_launches += 1; st.segments_bytes += pe.bytes; break;
+      case 2: st.finish_ms += ms; st.finish_launches += 1; st.finish_bytes += pe.bytes; break;
+      default: st.gramian_ms += ms; st.gramian_launches += 1; st.gramian_bytes += pe.bytes; break;
     }
     (void)hipEventDestroy(pe.a);
     (void)hipEventDestroy(pe.b);
@@ -289,17 +296,25 @@ int launch_gramian(mals_handle h, SideState& s, const float* M, int64_t n_rows, 
 
 template <int T, int D>
 int launch_solve_T(mals_handle h, SideState& s, SolveParams p) {
+  const double per = 4.0 * p.k + 8.0;  // gathered row + col idx + value; written row + row_ptr
+  PendingEvent pe;
   if (s.nB) {
     p.n_work = s.nB;
+    if (int rc = begin_timed(h, 1, (double)s.nnzB * per, pe)) return rc;
     hipLaunchKernelGGL((als_segments_kernel<T, D>), dim3((unsigned)((s.nB + 3) / 4)), dim3(256), 0, h->stream, p);
+    if (int rc = end_timed(h, pe)) return rc;
   }
   if (s.nA) {
     p.n_work = s.nA;
+    if (int rc = begin_timed(h, 0, (double)s.nnzA * per + (double)s.nA * per, pe)) return rc;
     hipLaunchKernelGGL((als_rows_kernel<T, D>), dim3((unsigned)((s.nA + 3) / 4)), dim3(256), 0, h->stream, p);
+    if (int rc = end_timed(h, pe)) return rc;
   }
   if (s.nC) {
     p.n_work = s.nC;
+    if (int rc = begin_timed(h, 2, (double)s.nC * per, pe)) return rc;
     hipLaunchKernelGGL((als_finish_kernel<T>), dim3((unsigned)((s.nC + 3) / 4)), dim3(256), 0, h->stream, p);
+    if (int rc = end_timed(h, pe)) return rc;
   }
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
@@ -637,7 +652,7 @@ int mals_gramian(mals_handle h, int side, double* host_G) {
   if (int rc = use_device(h)) return rc;
   if (int rc = ensure_gramian_buffers(h, s)) return rc;
   PendingEvent pe;
-  if (int rc = begin_timed(h, 1, pe)) return rc;
+  if (int rc = begin_timed(h, 3, (double)s.n_total * 4.0 * h->cfg.features, pe)) return rc;
   if (int rc = launch_gramian(h, s, s.F, s.n_total, s.G, s.Gf)) return rc;
   if (int rc = end_timed(h, pe)) return rc;
   s.G_valid = true;
@@ -657,7 +672,7 @@ int mals_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_r
     return fail(h, MALS_INVALID_ARG, "row range outside the factor replica");
   if (int rc = use_device(h)) return rc;
   PendingEvent pe;
-  if (int rc = begin_timed(h, 1, pe)) return rc;
+  if (int rc = begin_timed(h, 3, (double)n_rows * 4.0 * h->cfg.features, pe)) return rc;
   if (int rc = launch_gramian(h, s, s.F + row_begin * h->cfg.features, n_rows, device_out, nullptr)) return rc;
   return end_timed(h, pe);
 }
@@ -708,14 +723,10 @@ int mals_solve_side(mals_handle h, int side) {
   p.alpha = (float)h->cfg.alpha;
   p.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);  // ALS:435
   p.sing_threshold = (float)h->cfg.singularity_threshold;
-  PendingEvent pe;
-  if (int rc = begin_timed(h, 0, pe)) return rc;
   if (int rc = launch_solve(h, s, p)) return rc;
-  if (int rc = end_timed(h, pe)) return rc;
   s.G_valid = false;  // this side's factors changed
   h->stats.rows_solved += s.n_local;
   h->stats.nnz_gathered += s.nnz;
-  h->stats.algorithmic_bytes += (double)s.nnz * (4.0 * k + 8.0) + (double)s.n_local * (4.0 * k + 8.0);
   return MALS_OK;
 }
 

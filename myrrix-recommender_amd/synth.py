@@ -1,19 +1,14 @@
 """Seeded synthetic interaction matrices (BASELINE.md section 3 / SURVEY.md section 8d).
 
-Item popularity is a power law (item = floor(I * u^3), i.e. density ~ rank^(-2/3)), user activity
-is log-normal (sigma 1), strengths are integers 1..5.  Duplicate (user,item) pairs are merged, so
+Item popularity is a power law (popularity rank = floor(I * u^3), i.e. density ~ rank^(-2/3); ranks
+are mapped to item ids by a seeded random permutation so that id order carries no popularity
+information), user activity is log-normal (sigma 1), strengths are integers 1..5.  Duplicate (user,item) pairs are merged, so
 the realised nnz is slightly below the request.  Seed 1234567890 = RandomManager.java:52.
 `numpy_problem` is for tests (host arrays), `torch_problem` builds the large bench matrices on the
 GPU (CSR by user and CSR by item, int64 row_ptr / int32 col / fp32 val)."""
 import numpy as np
 
 SEED = 1234567890
-
-
-def _csr_from_sorted_keys(keys, n_rows, n_cols, xp, vals):
-    rows = keys // n_cols
-    cols = (keys % n_cols)
-    return rows, cols, vals
 
 
 def numpy_problem(n_users, n_items, nnz, k, seed=SEED, negatives=0.0):
@@ -24,6 +19,7 @@ def numpy_problem(n_users, n_items, nnz, k, seed=SEED, negatives=0.0):
     p_user = act / act.sum()
     users = rng.choice(n_users, size=nnz, p=p_user)
     items = np.minimum((n_items * rng.random(nnz) ** 3).astype(np.int64), n_items - 1)
+    items = rng.permutation(n_items)[items]
     keys = np.unique(users.astype(np.int64) * n_items + items)
     u = (keys // n_items).astype(np.int64)
     i = (keys % n_items).astype(np.int64)
@@ -54,12 +50,14 @@ def torch_problem(n_users, n_items, nnz, k, device, seed=SEED, chunk=1 << 27):
     act = torch.exp(torch.randn(n_users, generator=g, device=device, dtype=torch.float32))
     cdf = torch.cumsum(act.double(), 0)
     cdf = (cdf / cdf[-1]).float()
+    perm = torch.randperm(n_items, generator=g, device=device)
     keys = []
     done = 0
     while done < nnz:
         m = min(chunk, nnz - done)
         uu = torch.searchsorted(cdf, torch.rand(m, generator=g, device=device)).clamp_(max=n_users - 1)
         ii = (n_items * torch.rand(m, generator=g, device=device, dtype=torch.float64) ** 3).long().clamp_(max=n_items - 1)
+        ii = perm[ii]
         keys.append(uu * n_items + ii)
         done += m
         del uu, ii

@@ -31,9 +31,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # mals_config: 2 x int32, 3 x double, 4 x int32 ; mals_stats: 2 x int32, 2 x double, 4 x int64, double
+    # mals_config: 2 x int32, 3 x double, 4 x int32 ; mals_stats: 2 x int32, 4 x double, 4 x int64, 4 x double, 2 x int64
     assert ctypes.sizeof(_lib.Config) == 48
-    assert ctypes.sizeof(_lib.Stats) == 64
+    assert ctypes.sizeof(_lib.Stats) == 120
     cfg = _lib.Config()
     assert _lib.load().mals_default_config(ctypes.byref(cfg)) == _lib.OK
     assert cfg.struct_size == 48 and cfg.features == 30            # MatrixFactorizer.java:34
