@@ -45,7 +45,7 @@ struct SolveParams {
   const int32_t* col;
   const float* val;
   const float* M;           // opposing factor replica (row-major, stride k)
-  const float* Gf;          // fp32 image of G, (16T x 16T) row-major, zero padded
+  const float* Gf;          // fp32 image of G in acc layout: [upper tile][lane][reg]
   float* out;               // this side's factor replica + row_offset*k
   const int32_t* order;     // list A: short rows sorted by length (desc)
   const SegB* segs;         // list B
@@ -71,6 +71,10 @@ __device__ __forceinline__ float readlane(float v, int lane) {
 template <int N>
 __device__ __forceinline__ float row_ror(float v) {  // DPP rotate within each 16-lane row
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+template <int LANE>
+__device__ __forceinline__ float row_bcast(float v) {  // DPP row_newbcast: lane LANE of each 16-lane row
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + LANE, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float reduce_row16(float x) {  // all 16 lanes of a row get the row sum
   x += row_ror<8>(x);
@@ -108,48 +112,50 @@ __device__ __forceinline__ f32x4 tile_neg_ptq(const f32x4& P, const f32x4& Q, f3
 // K3a: in-register Cholesky of one full symmetric 16x16 tile D (acc layout).  Returns
 // Uinv = U^{-1} (acc layout) where U^T U = D, by running the elimination on [D | I]: the row
 // operations turn I into L^{-1} = U^{-T}, which is then transposed across lanes.
-// `bad` is set when a pivot is <= thr or not finite (non-PD system).
+// minpiv tracks the smallest pivot (a pivot <= singularity threshold flags a non-PD system).
 template <int M_>
-__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int g, float thr, bool& bad) {
+__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int g, float& minpiv) {
   constexpr int gm = M_ >> 2, rm = M_ & 3;
   const float piv = readlane(D[rm], 16 * gm + M_);
-  bad = bad || !(piv > thr);
+  minpiv = fminf(minpiv, piv);
   const float s = __builtin_amdgcn_rsqf(piv);
   const int idx_row = ((16 * gm) | (lane & 15)) << 2;  // lane (gm, c)
-  const int idx_col = ((lane & 48) | M_) << 2;         // lane (g, m)
   const float urow = bperm(idx_row, D[rm]) * s;        // U[m][c]
   const float erow = bperm(idx_row, E[rm]) * s;        // (L^-1)[m][c]
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float ucol = bperm(idx_col, D[r]) * s;             // U[m][4g+r] (by symmetry of the Schur block)
-    ucol = (4 * g + r > M_) ? ucol : 0.f;
+    // U[m][4g+r] = D[4g+r][m] * s by symmetry of the Schur block; rows < m of D were zeroed when
+    // they were finalised, so finished rows of E are left alone; row m itself is rewritten below.
+    const float ucol = row_bcast<M_>(D[r]) * s;
     D[r] = fmaf(-ucol, urow, D[r]);
     E[r] = fmaf(-ucol, erow, E[r]);
   }
-  E[rm] = (g == gm) ? erow : E[rm];
+  const bool mine = g == gm;
+  D[rm] = mine ? 0.f : D[rm];
+  E[rm] = mine ? erow : E[rm];
 }
 
-__device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float thr, bool& bad) {
+__device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   const int g = lane >> 4, c = lane & 15;
   f32x4 E;
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] = (4 * g + r == c) ? 1.f : 0.f;
-  diag_step<0>(D, E, lane, g, thr, bad);
-  diag_step<1>(D, E, lane, g, thr, bad);
-  diag_step<2>(D, E, lane, g, thr, bad);
-  diag_step<3>(D, E, lane, g, thr, bad);
-  diag_step<4>(D, E, lane, g, thr, bad);
-  diag_step<5>(D, E, lane, g, thr, bad);
-  diag_step<6>(D, E, lane, g, thr, bad);
-  diag_step<7>(D, E, lane, g, thr, bad);
-  diag_step<8>(D, E, lane, g, thr, bad);
-  diag_step<9>(D, E, lane, g, thr, bad);
-  diag_step<10>(D, E, lane, g, thr, bad);
-  diag_step<11>(D, E, lane, g, thr, bad);
-  diag_step<12>(D, E, lane, g, thr, bad);
-  diag_step<13>(D, E, lane, g, thr, bad);
-  diag_step<14>(D, E, lane, g, thr, bad);
-  diag_step<15>(D, E, lane, g, thr, bad);
+  diag_step<0>(D, E, lane, g, minpiv);
+  diag_step<1>(D, E, lane, g, minpiv);
+  diag_step<2>(D, E, lane, g, minpiv);
+  diag_step<3>(D, E, lane, g, minpiv);
+  diag_step<4>(D, E, lane, g, minpiv);
+  diag_step<5>(D, E, lane, g, minpiv);
+  diag_step<6>(D, E, lane, g, minpiv);
+  diag_step<7>(D, E, lane, g, minpiv);
+  diag_step<8>(D, E, lane, g, minpiv);
+  diag_step<9>(D, E, lane, g, minpiv);
+  diag_step<10>(D, E, lane, g, minpiv);
+  diag_step<11>(D, E, lane, g, minpiv);
+  diag_step<12>(D, E, lane, g, minpiv);
+  diag_step<13>(D, E, lane, g, minpiv);
+  diag_step<14>(D, E, lane, g, minpiv);
+  diag_step<15>(D, E, lane, g, minpiv);
   // Uinv = E^T : Uinv.reg[r](g,c) = E[c][4g+r] = E.reg[c&3] held by lane (c>>2, 4g+r)
   f32x4 Uinv;
   const int cq = c & 3;
@@ -165,10 +171,10 @@ __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float thr, bool&
 // K3b: blocked right-looking Cholesky W = U^T U on the upper tiles.  On return the off-diagonal
 // tiles hold U_ij and the diagonal tiles hold U_ii^{-1}.  TRSM and SYRK run on the matrix cores.
 template <int T>
-__device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float thr, bool& bad) {
+__device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
 #pragma unroll
   for (int kb = 0; kb < T; ++kb) {
-    const f32x4 Uinv = factor_diag(acc[tidx(T, kb, kb)], lane, thr, bad);
+    const f32x4 Uinv = factor_diag(acc[tidx(T, kb, kb)], lane, minpiv);
     acc[tidx(T, kb, kb)] = Uinv;
 #pragma unroll
     for (int j = kb + 1; j < T; ++j) {  // U_kj = Uinv^T A_kj
@@ -335,23 +341,27 @@ __device__ __forceinline__ void gather_accumulate(const SolveParams& p, int64_t 
   for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);
 }
 
-// add the shared Gramian, the ridge lambda*alpha*n_u (ALS:488-492), identity on the padding;
-// factor; solve; store the row (cast to fp32 is implicit: all arithmetic here is fp32).
+// acc <- shared Gramian image (ALS:447-450: start from YTY unless lossIgnoresUnspecified).  Gf is
+// stored in acc layout, [tile][lane] float4, so this is tri(T) 16-byte loads and no VALU.
+template <int T>
+__device__ __forceinline__ void init_acc(const SolveParams& p, f32x4 (&acc)[tri(T)], int lane) {
+  if (!(p.flags & 2)) {
+    const f32x4* G4 = reinterpret_cast<const f32x4*>(p.Gf) + lane;
+#pragma unroll
+    for (int t = 0; t < tri(T); ++t) acc[t] = G4[t * 64];
+  } else {
+#pragma unroll
+    for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// add the ridge lambda*alpha*n_u (ALS:488-492), identity on the padding; factor; solve; store the
+// row (the cast to fp32 of CMS:40-42 is implicit: all arithmetic here is fp32).
 template <int T>
 __device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tri(T)], const float (&bcol)[T],
                                            int n_u, int row, int lane) {
   const int g = lane >> 4, c = lane & 15;
   const int k = p.k;
-  if (!(p.flags & 2)) {  // ALS:447-450: start from YTY unless lossIgnoresUnspecified
-    const int ld = 16 * T;
-#pragma unroll
-    for (int i = 0; i < T; ++i)
-#pragma unroll
-      for (int j = i; j < T; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[tidx(T, i, j)][r] += p.Gf[(16 * i + 4 * g + r) * ld + 16 * j + c];
-  }
   const float ridge = p.lambda_alpha * (float)n_u;
 #pragma unroll
   for (int v = 0; v < T; ++v) {
@@ -361,11 +371,11 @@ __device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tr
       if (4 * g + r == c) acc[tidx(T, v, v)][r] = feat < k ? acc[tidx(T, v, v)][r] + ridge : 1.f;
     }
   }
-  bool bad = false;
-  cholesky_tiles<T>(acc, lane, p.sing_threshold, bad);
+  float minpiv = 3.0e38f;
+  cholesky_tiles<T>(acc, lane, minpiv);
   float xcol[T];
   solve_tiles<T>(acc, bcol, xcol, lane);
-  if (bad) {
+  if (!(minpiv > p.sing_threshold)) {
     if (lane == 0) atomicMin(p.bad_row, (unsigned long long)row);
 #pragma unroll
     for (int v = 0; v < T; ++v) xcol[v] = 0.f;
@@ -390,8 +400,7 @@ __global__ __launch_bounds__(256) void als_rows_kernel(SolveParams p) {
   const int64_t begin = p.row_ptr[row];
   const int len = (int)(p.row_ptr[row + 1] - begin);
   f32x4 acc[tri(T)];
-#pragma unroll
-  for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  init_acc<T>(p, acc, lane);
   float bcol[T];
 #pragma unroll
   for (int v = 0; v < T; ++v) bcol[v] = 0.f;
@@ -428,8 +437,7 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
   if (wave >= p.n_work) return;
   const RowC rc = p.rowsC[wave];
   f32x4 acc[tri(T)];
-#pragma unroll
-  for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  init_acc<T>(p, acc, lane);
   float bcol[T];
 #pragma unroll
   for (int v = 0; v < T; ++v) bcol[v] = 0.f;
@@ -511,18 +519,27 @@ __global__ void gramian_finalize_kernel(const double* __restrict__ partial, int6
     G[(int64_t)col * k + row] = s;
   }
   if (Gf) {
-    const int ld = 16 * T;
+    // fp32 image in the f32 MFMA acc layout, [tile][lane][reg]: element (row, col) of tile (i,j)
+    // lives at lane 16*((row%16)/4) + col%16, reg (row%16)%4.  Diagonal tiles are stored in full.
     const float f = (row < k && col < k) ? (float)s : 0.f;
-    Gf[row * ld + col] = f;
-    Gf[col * ld + row] = f;
+    const int lr = row - 16 * i, lc = col - 16 * j;
+    Gf[(t * 64 + 16 * (lr >> 2) + lc) * 4 + (lr & 3)] = f;
+    if (i == j) Gf[(t * 64 + 16 * (lc >> 2) + lr) * 4 + (lc & 3)] = f;
   }
 }
 
-// G (k x k fp64 row-major) -> zero-padded fp32 image used by K2
-__global__ void gramian_pack_kernel(const double* __restrict__ G, int k, int ld, float* __restrict__ Gf) {
+// G (k x k fp64 row-major) -> fp32 acc-layout image used by K2 (see gramian_finalize_kernel)
+__global__ void gramian_pack_kernel(const double* __restrict__ G, int k, int T, float* __restrict__ Gf) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ld * ld) return;
-  const int row = e / ld, col = e % ld;
+  if (e >= tri(T) * 256) return;
+  const int t = e >> 8, lane = (e >> 2) & 63, reg = e & 3;
+  int i = 0, rem = t;
+  while (rem >= T - i) {
+    rem -= T - i;
+    ++i;
+  }
+  const int j = i + rem;
+  const int row = 16 * i + 4 * (lane >> 4) + reg, col = 16 * j + (lane & 15);
   Gf[e] = (row < k && col < k) ? (float)G[(int64_t)row * k + col] : 0.f;
 }
 

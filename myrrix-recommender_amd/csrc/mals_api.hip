@@ -335,9 +335,9 @@ int launch_solve(mals_handle h, SideState& s, const SolveParams& p) {
 }
 
 int ensure_gramian_buffers(mals_handle h, SideState& s) {
-  const int k = h->cfg.features, ld = 16 * h->T;
+  const int k = h->cfg.features;
   if (!s.G) HIPCHK(h, hipMalloc(&s.G, sizeof(double) * (size_t)k * k));
-  if (!s.Gf) HIPCHK(h, hipMalloc(&s.Gf, sizeof(float) * (size_t)ld * ld));
+  if (!s.Gf) HIPCHK(h, hipMalloc(&s.Gf, sizeof(float) * (size_t)tri(h->T) * 256));
   return MALS_OK;
 }
 
@@ -683,10 +683,10 @@ int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) {
   SideState& s = h->side[side];
   if (int rc = use_device(h)) return rc;
   if (int rc = ensure_gramian_buffers(h, s)) return rc;
-  const int k = h->cfg.features, ld = 16 * h->T;
+  const int k = h->cfg.features;
   HIPCHK(h, hipMemcpyAsync(s.G, G, sizeof(double) * (size_t)k * k,
                            mem_kind == MALS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(gramian_pack_kernel, dim3((unsigned)((ld * ld + 255) / 256)), dim3(256), 0, h->stream, s.G, k, ld, s.Gf);
+  hipLaunchKernelGGL(gramian_pack_kernel, dim3((unsigned)tri(h->T)), dim3(256), 0, h->stream, s.G, k, h->T, s.Gf);
   HIPCHK(h, hipGetLastError());
   if (mem_kind != MALS_MEM_DEVICE) HIPCHK(h, hipStreamSynchronize(h->stream));
   s.G_valid = true;

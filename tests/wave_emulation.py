@@ -111,9 +111,14 @@ def wave_add_base(acc, Gd, ridge, k, use_g=True):
     return acc
 
 
+def row_bcast(x, lane_in_row):
+    """DPP row_newbcast: every lane of a 16-lane row reads lane `lane_in_row` of its own row."""
+    return x[(L & 48) | lane_in_row]
+
+
 def wave_factor_diag(D):
-    """In-tile Cholesky of a full symmetric 16x16 tile D (acc layout).  Returns (U, Uinv, minpiv):
-    U upper triangular with U^T U = D, Uinv = U^{-1}, both in acc layout."""
+    """In-tile Cholesky of a full symmetric 16x16 tile D (acc layout) by elimination on [D | I].
+    Returns (Uinv, minpiv): Uinv = U^{-1} in acc layout, where U^T U = D."""
     D = D.copy()
     E = np.zeros((4, 64), np.float32)
     for r in range(4):
@@ -125,15 +130,13 @@ def wave_factor_diag(D):
         minpiv = min(minpiv, piv)
         s = np.float32(1.0) / np.sqrt(np.float32(piv))
         urow = (shfl(D[rm], 16 * gm + C_) * s).astype(np.float32)
-        urow = np.where(C_ >= m, urow, np.float32(0))
         erow = (shfl(E[rm], 16 * gm + C_) * s).astype(np.float32)
         for r in range(4):
-            row = 4 * G_ + r
-            ucol = (shfl(D[r], (L & 48) | m) * s).astype(np.float32)   # D[row][m]*s (symmetry)
-            ucol = np.where(row > m, ucol, np.float32(0))
+            # D[4g+r][m]*s = U[m][4g+r] (symmetry); finished rows of D are zero, so they stay put
+            ucol = (row_bcast(D[r], m) * s).astype(np.float32)
             D[r] = (D[r] - ucol * urow).astype(np.float32)
             E[r] = (E[r] - ucol * erow).astype(np.float32)
-        D[rm] = np.where(G_ == gm, urow, D[rm])
+        D[rm] = np.where(G_ == gm, np.float32(0), D[rm])
         E[rm] = np.where(G_ == gm, erow, E[rm])
     # Uinv = E^T: Uinv.reg[r](g,c) = E[c][4g+r] = E.reg[c&3] at lane (c>>2, 4g+r)
     Uinv = np.zeros((4, 64), np.float32)
@@ -141,7 +144,7 @@ def wave_factor_diag(D):
         src = 16 * (C_ >> 2) + 4 * G_ + r
         t = [shfl(E[q], src) for q in range(4)]
         Uinv[r] = np.select([(C_ & 3) == q for q in range(4)], t)
-    return D, Uinv, minpiv
+    return Uinv, minpiv
 
 
 def wave_cholesky(acc, T):
@@ -150,7 +153,7 @@ def wave_cholesky(acc, T):
     minpiv = np.inf
     zero = np.zeros((4, 64), np.float32)
     for kb in range(T):
-        U, Uinv, mp = wave_factor_diag(acc[(kb, kb)])
+        Uinv, mp = wave_factor_diag(acc[(kb, kb)])
         minpiv = min(minpiv, mp)
         acc[(kb, kb)] = Uinv
         for j in range(kb + 1, T):                 # TRSM: U_kj = Uinv^T A_kj
