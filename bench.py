@@ -130,6 +130,18 @@ def main():
     core.check()
     st = core.stats()
     core.enable_timing(False)
+    # untimed diagnostic pass: per-half kernel times (not part of the measured region)
+    halves = {}
+    if os.environ.get("MALS_BENCH_SPLIT", "1") == "1":
+        core.enable_timing(True)
+        for side, name in ((pkg.SIDE_X, "x_half"), (pkg.SIDE_Y, "y_half")):
+            core.reset_stats()
+            als.half_iteration(side)
+            torch.cuda.synchronize()
+            h = core.stats()
+            halves[name] = {kk: round(h[kk + "_ms"], 3) for kk in ("rows", "segments", "finish", "gramian")}
+            halves[name]["rows_GBps"] = round(h["rows_bytes"] / max(h["rows_ms"], 1e-9) / 1e6, 1)
+        core.enable_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -160,6 +172,7 @@ def main():
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches": st["rows_launches"]},
             "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian")},
+            "half_iteration_kernel_ms": halves,
         }
         if world == 1 and not args.no_cpu_baseline:
             X = als.factors(pkg.SIDE_X)

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmyrrix_als.so")
+LIB_PATH = os.environ.get("MALS_LIB") or os.path.join(_HERE, "csrc", "libmyrrix_als.so")  # MALS_LIB: A/B builds
 
 OK, SINGULAR, INVALID_ARG, HIP_ERROR, COMM_ERROR, CANCELLED, OOM = range(7)
 SIDE_X, SIDE_Y = 0, 1

@@ -21,6 +21,10 @@
 
 namespace mals {
 
+#ifndef MALS_WAVES
+#define MALS_WAVES(T, MODE) ((T) <= 4 ? 4 : ((T) == 5 ? 3 : 2))
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -28,11 +32,10 @@ __host__ __device__ constexpr int tri(int T) { return T * (T + 1) / 2; }
 // index of upper tile (i <= j), row-major over the upper triangle
 __host__ __device__ constexpr int tidx(int T, int i, int j) { return i * T - (i * (i - 1)) / 2 + (j - i); }
 
-struct SegB {       // one segment of a long row
+struct WorkItem {   // one row (list A) or one segment of a long row (list B); 16 bytes, s_load_dwordx4
   int64_t begin;    // absolute offset into col/val
-  int32_t row;      // local row
-  int32_t len;      // entries in this segment (> 0)
-  int64_t slot;     // scratch slot
+  int32_t len;      // entries
+  int32_t id;       // list A: local row; list B: scratch slot
 };
 struct RowC {       // a long row to be finished from its segment partials
   int64_t first_slot;
@@ -47,8 +50,7 @@ struct SolveParams {
   const float* M;           // opposing factor replica (row-major, stride k)
   const float* Gf;          // fp32 image of G in acc layout: [upper tile][lane][reg]
   float* out;               // this side's factor replica + row_offset*k
-  const int32_t* order;     // list A: short rows sorted by length (desc)
-  const SegB* segs;         // list B
+  const WorkItem* items;    // list A or B (whichever this launch handles), sorted by length (desc)
   const RowC* rowsC;        // list C
   float* scratch;           // segment partials
   unsigned long long* bad_row; // first (smallest) local row with a non-PD system
@@ -58,6 +60,7 @@ struct SolveParams {
   float alpha;
   float lambda_alpha;       // lambda*alpha
   float sing_threshold;
+  unsigned long long* trace;  // profiling only (MALS_DEBUG_TRACE): per-phase s_memtime stamps
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -67,6 +70,19 @@ __device__ __forceinline__ float bperm(int byte_idx, float v) {
 }
 __device__ __forceinline__ float readlane(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// 4-way select on the two low bits of q, written as independent bit tests so that it lowers to three
+// v_cndmask (a ?: chain on q==0/1/2 becomes a switch, which hipcc lowers to exec-mask branches)
+__device__ __forceinline__ float select4(int q, float t0, float t1, float t2, float t3) {
+  const bool b0 = q & 1, b1 = q & 2;
+  const float lo = b0 ? t1 : t0, hi = b0 ? t3 : t2;
+  return b1 ? hi : lo;
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | lo;
 }
 template <int N>
 __device__ __forceinline__ float row_ror(float v) {  // DPP rotate within each 16-lane row
@@ -163,7 +179,7 @@ __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   for (int r = 0; r < 4; ++r) {
     const int src = (16 * (c >> 2) + 4 * g + r) << 2;
     const float t0 = bperm(src, E[0]), t1 = bperm(src, E[1]), t2 = bperm(src, E[2]), t3 = bperm(src, E[3]);
-    Uinv[r] = cq == 0 ? t0 : (cq == 1 ? t1 : (cq == 2 ? t2 : t3));
+    Uinv[r] = select4(cq, t0, t1, t2, t3);
   }
   return Uinv;
 }
@@ -203,7 +219,7 @@ __device__ __forceinline__ float row_to_col(const f32x4& vrow, int lane) {
   const int c = lane & 15, cq = c & 3;
   const int src = (16 * (c >> 2)) << 2;
   const float t0 = bperm(src, vrow[0]), t1 = bperm(src, vrow[1]), t2 = bperm(src, vrow[2]), t3 = bperm(src, vrow[3]);
-  return cq == 0 ? t0 : (cq == 1 ? t1 : (cq == 2 ? t2 : t3));
+  return select4(cq, t0, t1, t2, t3);
 }
 
 // K3c: x = W^{-1} b using the factor tiles (forward z = U^{-T} b, backward x = U^{-1} z).
@@ -256,89 +272,134 @@ __device__ __forceinline__ void solve_tiles(const f32x4 (&acc)[tri(T)], const fl
 
 // ------------------------------------------------------------------------------------------------
 // K2: gather phase.  One wave walks the entries [0,len) of a row (or row segment) four at a time:
-// lane (g,c) owns entry 4*step+g and feature block lanes c; per step it issues T 64-byte-coalesced
-// dword gathers of the opposing factor row straight into MFMA operand registers (no LDS hop: the
-// row is consumed once by this wave only), then T(T+1)/2 MFMAs  acc_ij += (w*y_i) y_j^T  and the
-// RHS update.  Entry (col,val) and row loads run 2D and D steps ahead of the MFMAs.
-struct Ent {
-  int col;
+// lane (g,c) owns entry 4*step+g and feature lanes c of every 16-block; per step it issues T
+// 64-byte-coalesced dword gathers of the opposing factor row straight into MFMA operand registers
+// (no LDS hop: a gathered row is consumed once, by this wave only), then T(T+1)/2 MFMAs
+// acc_ij += (w*y_i) y_j^T and the RHS update.
+//   * (col,val) are read 64 entries at a time, one entry per lane, fully coalesced; the weights
+//     w/cb are computed once per entry and handed to the lane group that needs them with
+//     ds_bpermute one step ahead of their use.
+//   * factor rows are gathered D-1 steps ahead into a ring of D register slots.
+//   * the waves are persistent: wave w owns work items w, w+W, w+2W, ... of a list sorted by length
+//     (longest first), and while it factors/solves row i it already has the first chunk and the
+//     first D-1 row gathers of row i+1 in flight, so the next gather starts with data on chip.
+struct Chunk {
+  int col;   // column index of this lane's entry (clamped inside the row)
   float w;   // Gramian weight: (c-1) = alpha*|r|   [+1 if lossIgnoresUnspecified; 0 if reconstructR]
   float cb;  // RHS weight:     c if r>0 else 0      [r if reconstructR]
 };
 
-__device__ __forceinline__ Ent load_ent(const int32_t* cols, const float* vals, int len, int step, int g,
-                                        float alpha, int flags) {
-  const int n = 4 * step + g;
-  const bool ok = n < len;
-  const int nn = ok ? n : len - 1;
-  Ent e;
-  e.col = cols[nn];
-  const float r = vals[nn];
-  const float base_w = (flags & 2) ? 1.f : 0.f;
+__device__ __forceinline__ int bperm_i(int byte_idx, int v) { return __builtin_amdgcn_ds_bpermute(byte_idx, v); }
+
+// Entry base+lane of a row with len > 0.  Issued in two halves so that no arithmetic waits on the
+// loads right after they are issued: chunk_issue only loads (col, raw value), chunk_weights turns
+// the raw value into the two weights when the chunk is about to be used.
+__device__ __forceinline__ Chunk chunk_issue(const SolveParams& p, int64_t begin, int len, int base, int lane) {
+  const int n = base + lane;
+  const int nn = n < len ? n : len - 1;
+  Chunk e;
+  e.col = p.col[begin + nn];
+  e.w = p.val[begin + nn];           // raw r_ui until chunk_weights
+  e.cb = n < len ? 1.f : 0.f;        // validity
+  return e;
+}
+__device__ __forceinline__ void chunk_weights(const SolveParams& p, Chunk& e) {
+  const float r = e.w, ok = e.cb;
+  const float base_w = (p.flags & 2) ? 1.f : 0.f;
   float w, cb;
-  if (flags & 1) {  // ALS:466-469
+  if (p.flags & 1) {  // ALS:466-469
     w = base_w;
     cb = r;
-  } else {          // ALS:471-482
-    const float ar = alpha * fabsf(r);
+  } else {            // ALS:471-482
+    const float ar = p.alpha * fabsf(r);
     w = base_w + ar;
     cb = r > 0.f ? 1.f + ar : 0.f;
   }
-  e.w = ok ? w : 0.f;
-  e.cb = ok ? cb : 0.f;
-  return e;
+  e.w = ok * w;
+  e.cb = ok * cb;
 }
 
-template <int T>
+// Gather one factor row: T dword loads, 16 lanes x 4 B = one 64-byte segment per lane group each.
+// No arithmetic may depend on the loaded values here (the loads must stay in flight), so the
+// partial last block (k % 16 != 0) is handled by not loading at all in the lanes past k: their ring
+// slot registers are zero-initialised once and never written.
+template <int T, bool FULL>
 __device__ __forceinline__ void load_rows(const float* __restrict__ M, int k, int col, int c, float (&y)[T]) {
-  const float* p = M + (int64_t)col * k + c;
+  const float* p = M + ((uint64_t)(uint32_t)col * (uint32_t)k + (uint32_t)c);  // one v_mad_u64_u32
 #pragma unroll
   for (int v = 0; v < T - 1; ++v) y[v] = p[16 * v];
-  // last block may be partial: clamp the address, zero the value
-  const int f = 16 * (T - 1) + c;
-  const float last = M[(int64_t)col * k + (f < k ? f : k - 1)];
-  y[T - 1] = f < k ? last : 0.f;
+  if (FULL || 16 * (T - 1) + c < k) y[T - 1] = p[16 * (T - 1)];
 }
 
 template <int T>
-__device__ __forceinline__ void gram_step(const float (&y)[T], const Ent& e, f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
+__device__ __forceinline__ void gram_step(const float (&y)[T], float w, float cb, f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
   float a[T];
 #pragma unroll
-  for (int v = 0; v < T; ++v) a[v] = e.w * y[v];
+  for (int v = 0; v < T; ++v) a[v] = w * y[v];
 #pragma unroll
   for (int i = 0; i < T; ++i)
 #pragma unroll
     for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma4(a[i], y[j], acc[tidx(T, i, j)]);
 #pragma unroll
-  for (int v = 0; v < T; ++v) bpart[v] = fmaf(e.cb, y[v], bpart[v]);
+  for (int v = 0; v < T; ++v) bpart[v] = fmaf(cb, y[v], bpart[v]);
 }
 
+// per-wave gather pipeline state (all in registers)
 template <int T, int D>
-__device__ __forceinline__ void gather_accumulate(const SolveParams& p, int64_t begin, int len, int lane,
-                                                  f32x4 (&acc)[tri(T)], float (&bcol)[T]) {
-  const int g = lane >> 4, c = lane & 15;
-  const int32_t* cols = p.col + begin;
-  const float* vals = p.val + begin;
+struct Pipe {
+  Chunk ch;       // current 64-entry chunk
+  float y[D][T];  // ring of gathered rows
+  float wcur, cbcur;  // weights of the next step to execute
+  int colpf;          // column of the next step to gather
+};
+
+// Start a row (len > 0): ch = chunk 0 already loaded; issue the gathers of steps 0..D-2 and fetch the
+// weights of step 0 and the column of step D-1.  Steps past the end of a short row gather a valid
+// (clamped) row that is never used.
+template <int T, int D, bool FULL>
+__device__ __forceinline__ void prime_row(const SolveParams& p, int lane, Pipe<T, D>& pp) {
+  const int c = lane & 15, gb = (lane >> 4) << 2;
+#pragma unroll
+  for (int i = 0; i < D - 1; ++i) load_rows<T, FULL>(p.M, p.k, bperm_i(gb + 16 * i, pp.ch.col), c, pp.y[i]);
+  pp.wcur = bperm(gb, pp.ch.w);
+  pp.cbcur = bperm(gb, pp.ch.cb);
+  pp.colpf = bperm_i(gb + 16 * (D - 1), pp.ch.col);
+}
+
+template <int T, int D, bool FULL>
+__device__ __forceinline__ void gather_row(const SolveParams& p, int64_t begin, int len, int lane, Pipe<T, D>& pp,
+                                           f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
+  static_assert(16 % D == 0, "ring depth must divide the chunk length in steps");
+  const int c = lane & 15, gb = (lane >> 4) << 2;
   const int nsteps = (len + 3) >> 2;
-  float bpart[T];
+  for (int q = 0; 16 * q < nsteps; ++q) {
+    // next chunk (clamped inside the row, so always safe to issue); lands during this chunk
+    Chunk chn = chunk_issue(p, begin, len, 64 * (q + 1), lane);
 #pragma unroll
-  for (int v = 0; v < T; ++v) bpart[v] = 0.f;
-  Ent e[2 * D];
-  float y[D][T];
-#pragma unroll
-  for (int i = 0; i < 2 * D; ++i) e[i] = load_ent(cols, vals, len, i, g, p.alpha, p.flags);
-#pragma unroll
-  for (int i = 0; i < D; ++i) load_rows<T>(p.M, p.k, e[i].col, c, y[i]);
-  for (int s = 0; s < nsteps; s += 2 * D) {
-#pragma unroll
-    for (int i = 0; i < 2 * D; ++i) {
-      if (s + i < nsteps) gram_step<T>(y[i % D], e[i], acc, bpart);
-      load_rows<T>(p.M, p.k, e[(i + D) % (2 * D)].col, c, y[i % D]);
-      e[i] = load_ent(cols, vals, len, s + i + 2 * D, g, p.alpha, p.flags);
+    for (int j = 0; j < 16; ++j) {
+      const int s = 16 * q + j;
+      if (s < nsteps) {
+        // (1) gather the rows of step s+D-1 into the slot step s-1 has just released
+        load_rows<T, FULL>(p.M, p.k, pp.colpf, c, pp.y[(j + D - 1) % D]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == 14) chunk_weights(p, chn);  // first use of the next chunk's weights is step 15
+        // (2) cross-lane fetches for the next step's weights and the next gather's column
+        const int jn = j + 1, jt = j + D;
+        const float wn = bperm(gb + 16 * (jn & 15), jn < 16 ? pp.ch.w : chn.w);
+        const float cbn = bperm(gb + 16 * (jn & 15), jn < 16 ? pp.ch.cb : chn.cb);
+        const int coln = bperm_i(gb + 16 * (jt & 15), jt < 16 ? pp.ch.col : chn.col);
+        // (3) the matrix-core work of step s
+        gram_step<T>(pp.y[j % D], pp.wcur, pp.cbcur, acc, bpart);
+        pp.wcur = wn;
+        pp.cbcur = cbn;
+        pp.colpf = coln;
+        // keep the hand-built pipeline: without this fence the scheduler hoists the gathers of all 16
+        // unrolled steps to the top of the chunk and the kernel needs > 200 VGPRs
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    pp.ch = chn;
   }
-#pragma unroll
-  for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);
 }
 
 // acc <- shared Gramian image (ALS:447-450: start from YTY unless lossIgnoresUnspecified).  Gf is
@@ -355,78 +416,164 @@ __device__ __forceinline__ void init_acc(const SolveParams& p, f32x4 (&acc)[tri(
   }
 }
 
-// add the ridge lambda*alpha*n_u (ALS:488-492), identity on the padding; factor; solve; store the
-// row (the cast to fp32 of CMS:40-42 is implicit: all arithmetic here is fp32).
+// W += lambda*alpha*n_u I (ALS:488-492); identity on the padding features
 template <int T>
-__device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tri(T)], const float (&bcol)[T],
-                                           int n_u, int row, int lane) {
+__device__ __forceinline__ void add_ridge(const SolveParams& p, f32x4 (&acc)[tri(T)], int n_u, int lane) {
   const int g = lane >> 4, c = lane & 15;
-  const int k = p.k;
   const float ridge = p.lambda_alpha * (float)n_u;
 #pragma unroll
   for (int v = 0; v < T; ++v) {
     const int feat = 16 * v + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (4 * g + r == c) acc[tidx(T, v, v)][r] = feat < k ? acc[tidx(T, v, v)][r] + ridge : 1.f;
+      if (4 * g + r == c) acc[tidx(T, v, v)][r] = feat < p.k ? acc[tidx(T, v, v)][r] + ridge : 1.f;
     }
   }
-  float minpiv = 3.0e38f;
-  cholesky_tiles<T>(acc, lane, minpiv);
-  float xcol[T];
-  solve_tiles<T>(acc, bcol, xcol, lane);
+}
+
+// store x (the cast to fp32 of CMS:40-42 is implicit: all arithmetic here is fp32); flag non-PD rows
+template <int T>
+__device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T], float minpiv, int row, int lane) {
   if (!(minpiv > p.sing_threshold)) {
     if (lane == 0) atomicMin(p.bad_row, (unsigned long long)row);
 #pragma unroll
     for (int v = 0; v < T; ++v) xcol[v] = 0.f;
   }
-  if (g == 0) {
-    float* o = p.out + (int64_t)row * k;
+  if (lane < 16) {
+    float* o = p.out + (int64_t)row * p.k;
 #pragma unroll
     for (int v = 0; v < T; ++v) {
-      const int feat = 16 * v + c;
-      if (feat < k) o[feat] = xcol[v];
+      const int feat = 16 * v + lane;
+      if (feat < p.k) o[feat] = xcol[v];
     }
   }
 }
 
-// list A: one wave per short row, fully fused K2+K3
-template <int T, int D>
-__global__ __launch_bounds__(256) void als_rows_kernel(SolveParams p) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= p.n_work) return;
-  const int row = p.order[wave];
-  const int64_t begin = p.row_ptr[row];
-  const int len = (int)(p.row_ptr[row + 1] - begin);
-  f32x4 acc[tri(T)];
-  init_acc<T>(p, acc, lane);
-  float bcol[T];
-#pragma unroll
-  for (int v = 0; v < T; ++v) bcol[v] = 0.f;
-  if (len > 0) gather_accumulate<T, D>(p, begin, len, lane, acc, bcol);
-  finish_row<T>(p, acc, bcol, len, row, lane);
+// ridge + factor + solve + store, no prefetch hook (used by the long-row finish kernel)
+template <int T>
+__device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tri(T)], const float (&bcol)[T],
+                                           int n_u, int row, int lane) {
+  add_ridge<T>(p, acc, n_u, lane);
+  float minpiv = 3.0e38f;
+  float xcol[T];
+  cholesky_tiles<T>(acc, lane, minpiv);
+  solve_tiles<T>(acc, bcol, xcol, lane);
+  store_row<T>(p, xcol, minpiv, row, lane);
 }
 
-// list B: one wave per segment of a long row; partial tiles + RHS go to scratch
-template <int T, int D>
-__global__ __launch_bounds__(256) void als_segments_kernel(SolveParams p) {
+__device__ __forceinline__ WorkItem load_item(const SolveParams& p, int64_t it) {
+  WorkItem w;
+  if (it < p.n_work) {
+    w = p.items[it];
+  } else {
+    w.begin = 0;
+    w.len = -1;  // sentinel: no more work
+    w.id = 0;
+  }
+  return w;
+}
+
+// Lists A (MODE 0: rows no longer than segment_nnz, fused K2+K3) and B (MODE 1: segments of long
+// rows, K2 only, partial tiles + RHS to scratch).  Persistent waves, see the K2 header comment.
+template <int T, int D, int MODE, bool FULL>
+__global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kernel(SolveParams p) {
+  __shared__ f32x4 sG[MODE == 0 ? tri(T) * 64 : 1];
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= p.n_work) return;
-  const SegB sg = p.segs[wave];
-  f32x4 acc[tri(T)];
+  const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  if (MODE == 0) {  // stage the acc-layout Gramian image once per workgroup
+    const f32x4* G4 = reinterpret_cast<const f32x4*>(p.Gf);
+    for (int e = threadIdx.x; e < tri(T) * 64; e += 256) sG[e] = (p.flags & 2) ? f32x4{0.f, 0.f, 0.f, 0.f} : G4[e];
+    __syncthreads();
+  }
+  int64_t it = wave;
+  if (it >= p.n_work) return;
+  WorkItem cur = load_item(p, it);
+  WorkItem nxt = load_item(p, it + n_waves);
+  Pipe<T, D> pp;
+  pp.wcur = pp.cbcur = 0.f;
+  pp.colpf = 0;
+  pp.ch.col = 0;
+  pp.ch.w = pp.ch.cb = 0.f;
 #pragma unroll
-  for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bcol[T];
-  gather_accumulate<T, D>(p, sg.begin, sg.len, lane, acc, bcol);
-  float* s = p.scratch + sg.slot * (int64_t)((tri(T) * 4 + T) * 64) + lane;
+  for (int i = 0; i < D; ++i)
 #pragma unroll
-  for (int t = 0; t < tri(T); ++t)
+    for (int v = 0; v < T; ++v) pp.y[i][v] = 0.f;
+  if (cur.len > 0) {
+    pp.ch = chunk_issue(p, cur.begin, cur.len, 0, lane);
+    chunk_weights(p, pp.ch);
+    prime_row<T, D, FULL>(p, lane, pp);
+  }
+  for (;;) {
+    f32x4 acc[tri(T)];
+    if (MODE == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r];
+      for (int t = 0; t < tri(T); ++t) acc[t] = sG[t * 64 + lane];
+    } else {
 #pragma unroll
-  for (int v = 0; v < T; ++v) s[(tri(T) * 4 + v) * 64] = bcol[v];
+      for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float bpart[T];
+#pragma unroll
+    for (int v = 0; v < T; ++v) bpart[v] = 0.f;
+    const bool tr = MODE == 0 && p.trace && wave < 64 && it < 64 * n_waves;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (tr) t0 = __builtin_readcyclecounter();
+    if (!(p.flags & 0x200)) gather_row<T, D, FULL>(p, cur.begin, cur.len, lane, pp, acc, bpart);
+    if (tr) t1 = __builtin_readcyclecounter();
+    float bcol[T];
+#pragma unroll
+    for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);
+    // next row: first chunk now, item after next (scalar load) now, row gathers after the factorization
+    const bool prime_next = nxt.len > 0;
+    if (prime_next) pp.ch = chunk_issue(p, nxt.begin, nxt.len, 0, lane);
+    const WorkItem nxt2 = load_item(p, it + 2 * n_waves);
+    if (MODE == 0) {
+      add_ridge<T>(p, acc, cur.len, lane);
+      float minpiv = 3.0e38f;
+      float xcol[T];
+      if (p.flags & 0x100) {  // profiling ablation (MALS_DEBUG_FLAGS): skip K3
+#pragma unroll
+        for (int v = 0; v < T; ++v) xcol[v] = 1e-3f + 1e-9f * (bcol[v] + acc[tidx(T, v, v)][0] + acc[tidx(T, 0, v)][1]);
+        if (prime_next) {
+          chunk_weights(p, pp.ch);
+          prime_row<T, D, FULL>(p, lane, pp);
+        }
+      } else {
+        cholesky_tiles<T>(acc, lane, minpiv);
+        if (tr) t2 = __builtin_readcyclecounter();
+        if (prime_next) {  // gathers land during the solves
+          chunk_weights(p, pp.ch);
+          prime_row<T, D, FULL>(p, lane, pp);
+        }
+        solve_tiles<T>(acc, bcol, xcol, lane);
+      }
+      store_row<T>(p, xcol, minpiv, cur.id, lane);
+      if (tr) {
+        t3 = __builtin_readcyclecounter();
+        if (lane == 0) {
+          unsigned long long* o = p.trace + ((it / n_waves) * 64 + wave) * 5;
+          o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = (unsigned long long)cur.len;
+        }
+      }
+    } else {
+      float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64) + lane;
+#pragma unroll
+      for (int t = 0; t < tri(T); ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r];
+#pragma unroll
+      for (int v = 0; v < T; ++v) s[(tri(T) * 4 + v) * 64] = bcol[v];
+      if (prime_next) {
+        chunk_weights(p, pp.ch);
+        prime_row<T, D, FULL>(p, lane, pp);
+      }
+    }
+    if (nxt.len < 0) break;
+    cur = nxt;
+    nxt = nxt2;
+    it += n_waves;
+  }
 }
 
 // list C: one wave per long row: sum the segment partials in order, then K3
@@ -435,7 +582,10 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wave >= p.n_work) return;
-  const RowC rc = p.rowsC[wave];
+  RowC rc = p.rowsC[wave];
+  rc.first_slot = uniform64(rc.first_slot);
+  rc.row = uniform(rc.row);
+  rc.nseg = uniform(rc.nseg);
   f32x4 acc[tri(T)];
   init_acc<T>(p, acc, lane);
   float bcol[T];
@@ -450,7 +600,7 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
 #pragma unroll
     for (int v = 0; v < T; ++v) bcol[v] += s[(tri(T) * 4 + v) * 64];
   }
-  const int n_u = (int)(p.row_ptr[rc.row + 1] - p.row_ptr[rc.row]);
+  const int n_u = uniform((int)(p.row_ptr[rc.row + 1] - p.row_ptr[rc.row]));
   finish_row<T>(p, acc, bcol, n_u, rc.row, lane);
 }
 

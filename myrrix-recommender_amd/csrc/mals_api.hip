@@ -12,12 +12,16 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
 #include <string>
 #include <vector>
 
+#ifndef MALS_D4
+#define MALS_D4 4
+#endif
 using namespace mals;
 
 namespace {
@@ -38,10 +42,10 @@ struct SideState {
   int64_t append_rows = 0, append_nnz = 0;
   bool appending = false;
   // work lists
-  int32_t* orderA = nullptr;
+  WorkItem* itemsA = nullptr;  // rows no longer than segment_nnz, longest first
   int64_t nA = 0;
   int64_t nnzA = 0, nnzB = 0;  // entries handled by the rows kernel / the segments kernel
-  SegB* segs = nullptr;
+  WorkItem* itemsB = nullptr;  // segments of the long rows, longest first
   int64_t nB = 0;
   RowC* rowsC = nullptr;
   int64_t nC = 0;
@@ -65,6 +69,7 @@ struct PendingEvent {
 struct mals_handle_s {
   mals_config cfg;
   int T = 0;
+  int n_cu = 256;
   SideState side[2];
   hipStream_t stream = nullptr;
   std::string err;
@@ -77,6 +82,7 @@ struct mals_handle_s {
   bool timing = false;
   mals_stats stats;
   std::vector<PendingEvent> pending;
+  unsigned long long* d_trace = nullptr;  // MALS_DEBUG_TRACE
   int64_t* d_idx = nullptr;  // gather scratch
   float* d_rows = nullptr;
   int32_t idx_cap = 0;
@@ -127,8 +133,8 @@ void free_matrix(SideState& s) {
   s.val = nullptr;
   s.m_owned = false;
   s.has_matrix = false;
-  free_dev(s.orderA);
-  free_dev(s.segs);
+  free_dev(s.itemsA);
+  free_dev(s.itemsB);
   free_dev(s.rowsC);
   free_dev(s.scratch);
   s.nA = s.nB = s.nC = 0;
@@ -144,8 +150,8 @@ int build_work_lists(mals_handle h, SideState& s) {
   const int64_t n = s.n_local;
   const int seg = h->cfg.segment_nnz;
   const std::vector<int64_t>& rp = s.h_row_ptr;
-  std::vector<int32_t> order;
-  std::vector<SegB> segs;
+  std::vector<WorkItem> order;
+  std::vector<WorkItem> segs;
   std::vector<RowC> rowsC;
   // counting sort of the short rows by length, longest first
   std::vector<int64_t> count((size_t)seg + 2, 0);
@@ -172,7 +178,10 @@ int build_work_lists(mals_handle h, SideState& s) {
   for (int64_t r = 0; r < n; ++r) {
     const int64_t len = rp[r + 1] - rp[r];
     if (len <= seg) {
-      order[(size_t)count[(size_t)(seg - len)]++] = (int32_t)r;
+      WorkItem& w = order[(size_t)count[(size_t)(seg - len)]++];
+      w.begin = rp[r];
+      w.len = (int32_t)len;
+      w.id = (int32_t)r;
     } else {
       const int64_t nseg = (len + seg - 1) / seg;
       int64_t per = (len + nseg - 1) / nseg;
@@ -182,11 +191,11 @@ int build_work_lists(mals_handle h, SideState& s) {
       rc.row = (int32_t)r;
       rc.nseg = 0;
       for (int64_t b = 0; b < len; b += per) {
-        SegB sg;
+        if (slot >= std::numeric_limits<int32_t>::max()) return fail(h, MALS_INVALID_ARG, "too many row segments");
+        WorkItem sg;
         sg.begin = rp[r] + b;
-        sg.row = (int32_t)r;
         sg.len = (int32_t)std::min(per, len - b);
-        sg.slot = slot++;
+        sg.id = (int32_t)slot++;
         segs.push_back(sg);
         ++rc.nseg;
       }
@@ -194,17 +203,17 @@ int build_work_lists(mals_handle h, SideState& s) {
     }
   }
   // longest segments first
-  std::stable_sort(segs.begin(), segs.end(), [](const SegB& a, const SegB& b) { return a.len > b.len; });
+  std::stable_sort(segs.begin(), segs.end(), [](const WorkItem& a, const WorkItem& b) { return a.len > b.len; });
   s.nA = (int64_t)order.size();
   s.nB = (int64_t)segs.size();
   s.nC = (int64_t)rowsC.size();
   if (s.nA) {
-    HIPCHK(h, hipMalloc(&s.orderA, sizeof(int32_t) * order.size()));
-    HIPCHK(h, hipMemcpy(s.orderA, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&s.itemsA, sizeof(WorkItem) * order.size()));
+    HIPCHK(h, hipMemcpy(s.itemsA, order.data(), sizeof(WorkItem) * order.size(), hipMemcpyHostToDevice));
   }
   if (s.nB) {
-    HIPCHK(h, hipMalloc(&s.segs, sizeof(SegB) * segs.size()));
-    HIPCHK(h, hipMemcpy(s.segs, segs.data(), sizeof(SegB) * segs.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMalloc(&s.itemsB, sizeof(WorkItem) * segs.size()));
+    HIPCHK(h, hipMemcpy(s.itemsB, segs.data(), sizeof(WorkItem) * segs.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMalloc(&s.rowsC, sizeof(RowC) * rowsC.size()));
     HIPCHK(h, hipMemcpy(s.rowsC, rowsC.data(), sizeof(RowC) * rowsC.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMalloc(&s.scratch, sizeof(float) * (size_t)(slot * slot_floats(h->T))));
@@ -294,20 +303,39 @@ int launch_gramian(mals_handle h, SideState& s, const float* M, int64_t n_rows, 
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
 }
 
-template <int T, int D>
-int launch_solve_T(mals_handle h, SideState& s, SolveParams p) {
+// Persistent grid: as many 256-thread workgroups as are resident at once (CUs x blocks per CU from
+// the occupancy query), never more than the work needs.  Work item i goes to wave i mod W, so with
+// the list sorted by length every wave gets the same mix and the waves finish together.
+template <typename K>
+int persistent_grid(mals_handle h, K kernel, int64_t n_work, unsigned* grid) {
+  int per_cu = 0;
+  HIPCHK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+  if (const char* e = std::getenv("MALS_BLOCKS_PER_CU")) per_cu = std::atoi(e);  // tuning override
+  if (per_cu < 1) per_cu = 1;
+  const int64_t cap = (int64_t)h->n_cu * per_cu;
+  *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_work + 3) / 4, cap));
+  return MALS_OK;
+}
+
+template <int T, int D, bool FULL>
+int launch_solve_TF(mals_handle h, SideState& s, SolveParams p) {
   const double per = 4.0 * p.k + 8.0;  // gathered row + col idx + value; written row + row_ptr
   PendingEvent pe;
+  unsigned grid = 1;
   if (s.nB) {
     p.n_work = s.nB;
+    p.items = s.itemsB;
+    if (int rc = persistent_grid(h, als_persistent_kernel<T, D, 1, FULL>, s.nB, &grid)) return rc;
     if (int rc = begin_timed(h, 1, (double)s.nnzB * per, pe)) return rc;
-    hipLaunchKernelGGL((als_segments_kernel<T, D>), dim3((unsigned)((s.nB + 3) / 4)), dim3(256), 0, h->stream, p);
+    hipLaunchKernelGGL((als_persistent_kernel<T, D, 1, FULL>), dim3(grid), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
   if (s.nA) {
     p.n_work = s.nA;
+    p.items = s.itemsA;
+    if (int rc = persistent_grid(h, als_persistent_kernel<T, D, 0, FULL>, s.nA, &grid)) return rc;
     if (int rc = begin_timed(h, 0, (double)s.nnzA * per + (double)s.nA * per, pe)) return rc;
-    hipLaunchKernelGGL((als_rows_kernel<T, D>), dim3((unsigned)((s.nA + 3) / 4)), dim3(256), 0, h->stream, p);
+    hipLaunchKernelGGL((als_persistent_kernel<T, D, 0, FULL>), dim3(grid), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
   if (s.nC) {
@@ -320,12 +348,17 @@ int launch_solve_T(mals_handle h, SideState& s, SolveParams p) {
   return MALS_OK;
 }
 
+template <int T, int D>
+int launch_solve_T(mals_handle h, SideState& s, const SolveParams& p) {
+  return p.k == 16 * T ? launch_solve_TF<T, D, true>(h, s, p) : launch_solve_TF<T, D, false>(h, s, p);
+}
+
 int launch_solve(mals_handle h, SideState& s, const SolveParams& p) {
   switch (h->T) {
     case 1: return launch_solve_T<1, 4>(h, s, p);
     case 2: return launch_solve_T<2, 4>(h, s, p);
     case 3: return launch_solve_T<3, 4>(h, s, p);
-    case 4: return launch_solve_T<4, 4>(h, s, p);
+    case 4: return launch_solve_T<4, MALS_D4>(h, s, p);
     case 5: return launch_solve_T<5, 2>(h, s, p);
     case 6: return launch_solve_T<6, 2>(h, s, p);
     case 7: return launch_solve_T<7, 2>(h, s, p);
@@ -395,9 +428,16 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   mals_handle h = new (std::nothrow) mals_handle_s();
   if (!h) return MALS_OOM;
   h->cfg = *cfg;
+  h->cfg.flags &= 3;
+  if (const char* dbg = std::getenv("MALS_DEBUG_FLAGS")) h->cfg.flags |= (std::atoi(dbg) & 0xff) << 8;  // profiling ablations
   if (h->cfg.segment_nnz <= 0) h->cfg.segment_nnz = 4096;
   h->cfg.segment_nnz = (h->cfg.segment_nnz + 3) & ~3;
   h->T = (cfg->features + 15) / 16;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+      h->n_cu = prop.multiProcessorCount;
+  }
   std::memset(&h->stats, 0, sizeof(h->stats));
   h->stats.struct_size = (int32_t)sizeof(mals_stats);
   if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
@@ -405,6 +445,10 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
       hipMemset(h->d_bad, 0xff, 2 * sizeof(unsigned long long)) != hipSuccess) {
     delete h;
     return MALS_HIP_ERROR;
+  }
+  if (std::getenv("MALS_DEBUG_TRACE")) {
+    (void)hipMalloc(&h->d_trace, 64 * 64 * 5 * sizeof(unsigned long long));
+    (void)hipMemset(h->d_trace, 0, 64 * 64 * 5 * sizeof(unsigned long long));
   }
   *out = h;
   return MALS_OK;
@@ -414,6 +458,17 @@ int mals_destroy(mals_handle h) {
   if (!h) return MALS_INVALID_ARG;
   (void)hipSetDevice(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->d_trace) {  // dump the last launch's per-phase cycle stamps (profiling aid)
+    std::vector<unsigned long long> t(64 * 64 * 5);
+    (void)hipMemcpy(t.data(), h->d_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    for (int r = 0; r < 64; r += 9)
+      for (int w = 0; w < 64; w += 21) {
+        const unsigned long long* o = &t[(size_t)(r * 64 + w) * 5];
+        std::fprintf(stderr, "[trace] iter %2d wave %2d len %5llu gather %7llu chol %7llu solve+store %7llu gap_to_prev_end %lld\n", r, w, o[4],
+                     o[1] - o[0], o[2] - o[1], o[3] - o[2], r ? (long long)(o[0] - t[(size_t)((r - 1) * 64 + w) * 5 + 3]) : 0ll);
+      }
+    free_dev(h->d_trace);
+  }
   for (PendingEvent& pe : h->pending) {
     (void)hipEventDestroy(pe.a);
     (void)hipEventDestroy(pe.b);
@@ -712,12 +767,12 @@ int mals_solve_side(mals_handle h, int side) {
   p.M = o.F;
   p.Gf = o.Gf;
   p.out = s.F + s.row_offset * k;
-  p.order = s.orderA;
-  p.segs = s.segs;
+  p.items = nullptr;
   p.rowsC = s.rowsC;
   p.scratch = s.scratch;
   p.bad_row = h->d_bad + side;
   p.n_work = 0;
+  p.trace = h->d_trace;
   p.k = k;
   p.flags = h->cfg.flags;
   p.alpha = (float)h->cfg.alpha;
