@@ -462,7 +462,7 @@ int mals_destroy(mals_handle h) {
     std::vector<unsigned long long> t(64 * 64 * 5);
     (void)hipMemcpy(t.data(), h->d_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     for (int r = 0; r < 64; r += 9)
-      for (int w = 0; w < 64; w += 21) {
+      for (int w = 0; w < 8; w += 1) {
         const unsigned long long* o = &t[(size_t)(r * 64 + w) * 5];
         std::fprintf(stderr, "[trace] iter %2d wave %2d len %5llu gather %7llu chol %7llu solve+store %7llu gap_to_prev_end %lld\n", r, w, o[4],
                      o[1] - o[0], o[2] - o[1], o[3] - o[2], r ? (long long)(o[0] - t[(size_t)((r - 1) * 64 + w) * 5 + 3]) : 0ll);
@@ -773,6 +773,7 @@ int mals_solve_side(mals_handle h, int side) {
   p.bad_row = h->d_bad + side;
   p.n_work = 0;
   p.trace = h->d_trace;
+  if (const char* ts = std::getenv("MALS_DEBUG_TRACE_SIDE")) if (std::atoi(ts) != side) p.trace = nullptr;
   p.k = k;
   p.flags = h->cfg.flags;
   p.alpha = (float)h->cfg.alpha;
