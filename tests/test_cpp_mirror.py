@@ -1,0 +1,34 @@
+"""The C++ host mirror of the reference interface (include/myrrix/factorizer.hpp) drives the C-ABI
+directly: tests/cpp/test_als_known_answers.cpp re-states AlternatingLeastSquaresTest,
+NegativeInputTest and MatrixUtilsTest on it."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+BIN = os.path.join(CPP, "test_als_known_answers")
+
+
+def build():
+    subprocess.check_call(["make", "-C", CPP, "test_als_known_answers"], stdout=subprocess.DEVNULL)
+
+
+@pytest.mark.gpu
+def test_reference_unit_tests_through_the_cpp_mirror():
+    build()
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ALL PASSED" in r.stdout
+
+
+def test_cpp_mirror_builds_and_has_no_cpu_fallback():
+    import torch
+    build()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stdout

@@ -4,7 +4,7 @@ Tolerances: the reference computes in fp64 on fp32 storage and pins X*Y^T at 1e-
 inputs; the north-star tolerance for the native core is 1e-4 relative Frobenius on the factors.
 The HIP path computes the per-row Gramian, Cholesky and solves in fp32 (fp64 only for M^T M), so:
   * factors vs oracle: relative Frobenius <= 1e-4 (asserted; typically ~1e-6),
-  * golden X*Y^T:      absolute <= 2e-5 (the fp32 path; the fp64 oracle meets the reference's 1e-6).
+  * golden X*Y^T:      absolute <= 1e-6, the reference's own tolerance (measured 6e-7 on the fp32 path).
 """
 import json
 import os
@@ -65,7 +65,7 @@ def test_reference_known_answers(name):
     expected = np.array(case["expected_XYT"], dtype=np.float32)
     assert product.shape == expected.shape
     err = np.max(np.abs(product.astype(np.float32) - expected))
-    assert err <= 2e-5, (name, err, als.iterations)
+    assert err <= case["tol"], (name, err, als.iterations)   # the reference's own 1e-6 (MyrrixTest.java:34)
 
 
 def test_gramian_known_answer_and_vs_oracle():
