@@ -1,0 +1,73 @@
+"""ShardedALS with the real HIP core: two ranks (processes) sharing cuda:0 over gloo must reproduce
+the single-rank factors.  (RCCL refuses two ranks on one device, so the collective here is gloo;
+the slicing, row offsets, partial Gramians + all-reduce and in-place all-gather are the product
+code paths.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import myrrix_recommender_amd as pkg
+from myrrix_recommender_amd import sharded, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, shape, q):
+    n_users, n_items, nnz, k = shape
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, nnz, k, seed=31)
+        core = pkg.ALSCore(k, device=0)
+        core.set_stream(torch.cuda.current_stream().cuda_stream)
+        s = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device="cuda:0")
+        s.set_matrix_from_full(pkg.SIDE_X, *r_csr)
+        s.set_matrix_from_full(pkg.SIDE_Y, *c_csr)
+        s.set_factors(pkg.SIDE_Y, Y0)
+        s.iterate(2)
+        torch.cuda.synchronize()
+        q.put((rank, s.factors(pkg.SIDE_X).cpu().numpy(), s.factors(pkg.SIDE_Y).cpu().numpy()))
+        if world > 1:
+            dist.barrier()
+        core.close()
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_rank():
+    shape = (1001, 333, 30000, 24)          # odd sizes: the last slices are padded
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_run, args=(0, 1, 0, shape, q))
+    p.start()
+    _, X1, Y1 = q.get(timeout=300)
+    p.join(timeout=60)
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, shape, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, X, Y in res:
+        # partial-Gramian summation order differs from the single-rank Gramian only in fp64 rounding
+        assert np.allclose(X, X1, rtol=2e-5, atol=2e-6), rank
+        assert np.allclose(Y, Y1, rtol=2e-5, atol=2e-6), rank
