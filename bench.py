@@ -149,10 +149,20 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        # dominant kernel: the fused gather + Gramian + Cholesky kernel (als_rows_kernel)
+        # dominant kernel: the fused gather + Gramian + Cholesky kernel (als_persistent_kernel, MODE 0)
         avg_ms = st["rows_ms"] / max(st["rows_launches"], 1)
         bytes_per_launch = st["rows_bytes"] / max(st["rows_launches"], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch of the same kernel from the PMC passes committed under profiles/
+        # (rocprofv3 cannot run inside this process); null when no profile matches this workload
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pm.get("workload") == args.workload and pm.get("k") == k and world == 1:
+                traffic = pm["traffic_bytes_per_launch"]
+                traffic_src = "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "ALS rows solved/sec (full iteration) at k=%d" % k,
             "value": (n_users + n_items) / (elapsed / args.steps),
@@ -167,8 +177,9 @@ def main():
             "config": {"workload": desc, "users": n_users, "items": n_items, "nnz": int(prob["nnz"]), "features": k,
                        "alpha": 1.0, "lambda": 0.1, "sharding": "rows x%d, in-place all-gather + kxk all-reduce" % world,
                        "setup_s": round(t_gen, 2)},
-            "roofline": {"bound": "hbm", "kernel": "als_rows_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "mals::als_persistent_kernel<T,D,MODE=0> (fused gather + Gramian + Cholesky, rows)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches": st["rows_launches"]},
             "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian")},
