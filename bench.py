@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segment-nnz", type=int, default=0)
+    ap.add_argument("--exchange-chunks", type=int, default=4,
+                    help="N>1: solve each slice in this many row chunks and all-gather a finished chunk while the next is solved")
     args = ap.parse_args()
 
     import torch
@@ -106,7 +108,11 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
-    core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz)
+    chunk_rows = 0
+    if world > 1 and args.exchange_chunks > 1:
+        upr = sharded.rows_per_rank(n_users, world)
+        chunk_rows = (upr + args.exchange_chunks - 1) // args.exchange_chunks
+    core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, chunk_rows=chunk_rows)
     core.set_stream(torch.cuda.current_stream().cuda_stream)
     als = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device=device)
     als.set_matrix_from_full(pkg.SIDE_X, *prob["r_csr"])
@@ -175,7 +181,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "users": n_users, "items": n_items, "nnz": int(prob["nnz"]), "features": k,
-                       "alpha": 1.0, "lambda": 0.1, "sharding": "rows x%d, in-place all-gather + kxk all-reduce" % world,
+                       "alpha": 1.0, "lambda": 0.1, "sharding": "rows x%d, %s all-gather + kxk all-reduce" % (world, "in-place" if chunk_rows == 0 else "chunked (%d rows) pipelined" % chunk_rows),
                        "setup_s": round(t_gen, 2)},
             "roofline": {"bound": "hbm", "kernel": "mals::als_persistent_kernel<T,D,MODE=0> (fused gather + Gramian + Cholesky, rows)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,

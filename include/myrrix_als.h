@@ -68,7 +68,10 @@ typedef struct mals_config {
   int32_t flags;                /* MALS_FLAG_*                                                 */
   int32_t device;               /* HIP device ordinal                                          */
   int32_t segment_nnz;          /* rows longer than this are split across waves; 0 = default   */
-  int32_t reserved;
+  int32_t chunk_rows;           /* >0: the shard's rows are cut into contiguous ranges of this many
+                                   rows that can be solved one by one (mals_solve_chunk), so that
+                                   the caller can exchange a finished range while the next one is
+                                   being solved; 0 = one chunk                                  */
 } mals_config;
 
 typedef struct mals_stats {
@@ -159,6 +162,11 @@ int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind);
  * [row_offset, row_offset+n_rows_local) of `side`'s factor replica.  Asynchronous on the handle's
  * stream; errors (singular rows) are reported by the next mals_check. */
 int mals_solve_side(mals_handle h, int side);
+
+/* The same for one chunk: local rows [chunk*cfg.chunk_rows, (chunk+1)*cfg.chunk_rows) of the shard
+ * (all chunks, in any order, = mals_solve_side).  mals_num_chunks = ceil(n_rows_local/chunk_rows). */
+int mals_solve_chunk(mals_handle h, int side, int32_t chunk);
+int mals_num_chunks(mals_handle h, int side, int32_t* n_chunks);
 
 /* Synchronise the stream and report MALS_SINGULAR if any row solved since the last check had a
  * non-positive-definite system (the reference throws SingularMatrixSolverException, CMLSS:46-54). */

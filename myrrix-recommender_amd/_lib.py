@@ -22,7 +22,7 @@ class Config(ctypes.Structure):
                 ("alpha", ctypes.c_double), ("lam", ctypes.c_double),
                 ("singularity_threshold", ctypes.c_double), ("flags", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("segment_nnz", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("chunk_rows", ctypes.c_int32)]
 
 
 class Stats(ctypes.Structure):
@@ -62,6 +62,8 @@ SYMBOLS = {
     "mals_gramian_partial": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),
     "mals_set_gramian": (ctypes.c_int, [_H, ctypes.c_int, _P, ctypes.c_int]),
     "mals_solve_side": (ctypes.c_int, [_H, ctypes.c_int]),
+    "mals_solve_chunk": (ctypes.c_int, [_H, ctypes.c_int, _I32]),
+    "mals_num_chunks": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(_I32)]),
     "mals_check": (ctypes.c_int, [_H]),
     "mals_singular_info": (ctypes.c_int, [_H, ctypes.POINTER(_I32), ctypes.POINTER(_I64), ctypes.POINTER(_I32)]),
     "mals_half_iteration": (ctypes.c_int, [_H, ctypes.c_int]),

@@ -41,7 +41,7 @@ def _host(a, dtype):
 
 class ALSCore:
     def __init__(self, features, alpha=1.0, lam=0.1, flags=0, device=0, segment_nnz=0,
-                 singularity_threshold=1e-5):
+                 singularity_threshold=1e-5, chunk_rows=0):
         self._L = _lib.load()
         cfg = _lib.Config()
         self._L.mals_default_config(ctypes.byref(cfg))
@@ -51,6 +51,8 @@ class ALSCore:
         cfg.flags = int(flags)
         cfg.device = int(device)
         cfg.segment_nnz = int(segment_nnz)
+        cfg.chunk_rows = int(chunk_rows)
+        self.chunk_rows = max(0, int(chunk_rows))
         cfg.singularity_threshold = float(singularity_threshold)
         self.features = int(features)
         self._h = ctypes.c_void_p()
@@ -198,6 +200,14 @@ class ALSCore:
 
     def solve_side(self, side):
         self._chk(self._L.mals_solve_side(self._h, side))
+
+    def solve_chunk(self, side, chunk):
+        self._chk(self._L.mals_solve_chunk(self._h, side, int(chunk)))
+
+    def num_chunks(self, side):
+        n = ctypes.c_int32()
+        self._chk(self._L.mals_num_chunks(self._h, side, ctypes.byref(n)))
+        return n.value
 
     def check(self):
         self._chk(self._L.mals_check(self._h))

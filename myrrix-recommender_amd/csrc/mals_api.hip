@@ -50,6 +50,13 @@ struct SideState {
   RowC* rowsC = nullptr;
   int64_t nC = 0;
   float* scratch = nullptr;
+  // the lists are stored chunk-major (contiguous ranges of cfg.chunk_rows rows of the shard), each
+  // chunk sorted by length; a chunk can be solved on its own so that the caller can overlap the
+  // exchange of finished chunks with the solve of the next one
+  struct ChunkRange {
+    int64_t offA = 0, nA = 0, nnzA = 0, offB = 0, nB = 0, nnzB = 0, offC = 0, nC = 0;
+  };
+  std::vector<ChunkRange> chunks;
   // Gramian of THIS side's factors (consumed when solving the other side)
   double* G = nullptr;
   float* Gf = nullptr;
@@ -139,71 +146,87 @@ void free_matrix(SideState& s) {
   free_dev(s.scratch);
   s.nA = s.nB = s.nC = 0;
   s.nnzA = s.nnzB = 0;
+  s.chunks.clear();
   s.h_row_ptr.clear();
   s.h_row_ptr.shrink_to_fit();
 }
 
 int64_t slot_floats(int T) { return (int64_t)(tri(T) * 4 + T) * 64; }
 
-// Split the rows of a shard into the three work lists (DESIGN.md "work decomposition").
+// Split the rows of a shard into the three work lists (DESIGN.md "work decomposition"), chunk by chunk.
 int build_work_lists(mals_handle h, SideState& s) {
   const int64_t n = s.n_local;
   const int seg = h->cfg.segment_nnz;
+  const int64_t chunk_rows = h->cfg.chunk_rows > 0 ? h->cfg.chunk_rows : std::max<int64_t>(n, 1);
+  const int n_chunks = (int)std::max<int64_t>(1, (n + chunk_rows - 1) / chunk_rows);
   const std::vector<int64_t>& rp = s.h_row_ptr;
   std::vector<WorkItem> order;
   std::vector<WorkItem> segs;
   std::vector<RowC> rowsC;
-  // counting sort of the short rows by length, longest first
-  std::vector<int64_t> count((size_t)seg + 2, 0);
-  int64_t n_short = 0;
-  for (int64_t r = 0; r < n; ++r) {
-    const int64_t len = rp[r + 1] - rp[r];
-    if (len < 0) return fail(h, MALS_INVALID_ARG, "row_ptr must be non-decreasing");
-    if (len <= seg) {
-      ++count[(size_t)(seg - len)];
-      ++n_short;
-      s.nnzA += len;
-    } else {
-      s.nnzB += len;
-    }
-  }
-  int64_t acc = 0;
-  for (size_t b = 0; b < count.size(); ++b) {
-    const int64_t c = count[b];
-    count[b] = acc;
-    acc += c;
-  }
-  order.resize((size_t)n_short);
+  order.reserve((size_t)n);
   int64_t slot = 0;
-  for (int64_t r = 0; r < n; ++r) {
-    const int64_t len = rp[r + 1] - rp[r];
-    if (len <= seg) {
-      WorkItem& w = order[(size_t)count[(size_t)(seg - len)]++];
-      w.begin = rp[r];
-      w.len = (int32_t)len;
-      w.id = (int32_t)r;
-    } else {
-      const int64_t nseg = (len + seg - 1) / seg;
-      int64_t per = (len + nseg - 1) / nseg;
-      per = (per + 3) & ~(int64_t)3;  // whole 4-entry steps
-      RowC rc;
-      rc.first_slot = slot;
-      rc.row = (int32_t)r;
-      rc.nseg = 0;
-      for (int64_t b = 0; b < len; b += per) {
-        if (slot >= std::numeric_limits<int32_t>::max()) return fail(h, MALS_INVALID_ARG, "too many row segments");
-        WorkItem sg;
-        sg.begin = rp[r] + b;
-        sg.len = (int32_t)std::min(per, len - b);
-        sg.id = (int32_t)slot++;
-        segs.push_back(sg);
-        ++rc.nseg;
+  s.chunks.assign((size_t)n_chunks, SideState::ChunkRange());
+  std::vector<int64_t> count((size_t)seg + 2);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int64_t r0 = std::min(n, c * chunk_rows), r1 = std::min(n, (c + 1) * chunk_rows);
+    SideState::ChunkRange& cr = s.chunks[(size_t)c];
+    cr.offA = (int64_t)order.size();
+    cr.offB = (int64_t)segs.size();
+    cr.offC = (int64_t)rowsC.size();
+    // counting sort of the chunk's short rows by length, longest first
+    std::fill(count.begin(), count.end(), 0);
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t len = rp[r + 1] - rp[r];
+      if (len < 0) return fail(h, MALS_INVALID_ARG, "row_ptr must be non-decreasing");
+      if (len <= seg) {
+        ++count[(size_t)(seg - len)];
+        ++cr.nA;
+        cr.nnzA += len;
+      } else {
+        cr.nnzB += len;
       }
-      rowsC.push_back(rc);
     }
+    int64_t acc = cr.offA;
+    for (size_t b = 0; b < count.size(); ++b) {
+      const int64_t cnt = count[b];
+      count[b] = acc;
+      acc += cnt;
+    }
+    order.resize((size_t)(cr.offA + cr.nA));
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t len = rp[r + 1] - rp[r];
+      if (len <= seg) {
+        WorkItem& w = order[(size_t)count[(size_t)(seg - len)]++];
+        w.begin = rp[r];
+        w.len = (int32_t)len;
+        w.id = (int32_t)r;
+      } else {
+        const int64_t nseg = (len + seg - 1) / seg;
+        int64_t per = (len + nseg - 1) / nseg;
+        per = (per + 3) & ~(int64_t)3;  // whole 4-entry steps
+        RowC rc;
+        rc.first_slot = slot;
+        rc.row = (int32_t)r;
+        rc.nseg = 0;
+        for (int64_t b = 0; b < len; b += per) {
+          if (slot >= std::numeric_limits<int32_t>::max()) return fail(h, MALS_INVALID_ARG, "too many row segments");
+          WorkItem sg;
+          sg.begin = rp[r] + b;
+          sg.len = (int32_t)std::min(per, len - b);
+          sg.id = (int32_t)slot++;
+          segs.push_back(sg);
+          ++rc.nseg;
+        }
+        rowsC.push_back(rc);
+      }
+    }
+    cr.nB = (int64_t)segs.size() - cr.offB;
+    cr.nC = (int64_t)rowsC.size() - cr.offC;
+    // longest segments first
+    std::stable_sort(segs.begin() + cr.offB, segs.end(), [](const WorkItem& a, const WorkItem& b) { return a.len > b.len; });
+    s.nnzA += cr.nnzA;
+    s.nnzB += cr.nnzB;
   }
-  // longest segments first
-  std::stable_sort(segs.begin(), segs.end(), [](const WorkItem& a, const WorkItem& b) { return a.len > b.len; });
   s.nA = (int64_t)order.size();
   s.nB = (int64_t)segs.size();
   s.nC = (int64_t)rowsC.size();
@@ -322,30 +345,32 @@ int persistent_grid(mals_handle h, K kernel, int64_t n_work, unsigned* grid) {
 }
 
 template <int T, int D, bool FULL>
-int launch_solve_TF(mals_handle h, SideState& s, SolveParams p) {
+int launch_solve_TF(mals_handle h, SideState& s, SolveParams p, int chunk) {
   const double per = 4.0 * p.k + 8.0;  // gathered row + col idx + value; written row + row_ptr
+  const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
   PendingEvent pe;
   unsigned grid = 1;
-  if (s.nB) {
-    p.n_work = s.nB;
-    p.items = s.itemsB;
-    if (int rc = persistent_grid(h, als_persistent_kernel<T, D, 1, FULL>, s.nB, &grid)) return rc;
-    if (int rc = begin_timed(h, 1, (double)s.nnzB * per, pe)) return rc;
+  if (cr.nB) {
+    p.n_work = cr.nB;
+    p.items = s.itemsB + cr.offB;
+    if (int rc = persistent_grid(h, als_persistent_kernel<T, D, 1, FULL>, cr.nB, &grid)) return rc;
+    if (int rc = begin_timed(h, 1, (double)cr.nnzB * per, pe)) return rc;
     hipLaunchKernelGGL((als_persistent_kernel<T, D, 1, FULL>), dim3(grid), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
-  if (s.nA) {
-    p.n_work = s.nA;
-    p.items = s.itemsA;
-    if (int rc = persistent_grid(h, als_persistent_kernel<T, D, 0, FULL>, s.nA, &grid)) return rc;
-    if (int rc = begin_timed(h, 0, (double)s.nnzA * per + (double)s.nA * per, pe)) return rc;
+  if (cr.nA) {
+    p.n_work = cr.nA;
+    p.items = s.itemsA + cr.offA;
+    if (int rc = persistent_grid(h, als_persistent_kernel<T, D, 0, FULL>, cr.nA, &grid)) return rc;
+    if (int rc = begin_timed(h, 0, (double)cr.nnzA * per + (double)cr.nA * per, pe)) return rc;
     hipLaunchKernelGGL((als_persistent_kernel<T, D, 0, FULL>), dim3(grid), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
-  if (s.nC) {
-    p.n_work = s.nC;
-    if (int rc = begin_timed(h, 2, (double)s.nC * per, pe)) return rc;
-    hipLaunchKernelGGL((als_finish_kernel<T>), dim3((unsigned)((s.nC + 3) / 4)), dim3(256), 0, h->stream, p);
+  if (cr.nC) {
+    p.n_work = cr.nC;
+    p.rowsC = s.rowsC + cr.offC;
+    if (int rc = begin_timed(h, 2, (double)cr.nC * per, pe)) return rc;
+    hipLaunchKernelGGL((als_finish_kernel<T>), dim3((unsigned)((cr.nC + 3) / 4)), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
   HIPCHK(h, hipGetLastError());
@@ -353,20 +378,20 @@ int launch_solve_TF(mals_handle h, SideState& s, SolveParams p) {
 }
 
 template <int T, int D>
-int launch_solve_T(mals_handle h, SideState& s, const SolveParams& p) {
-  return p.k == 16 * T ? launch_solve_TF<T, D, true>(h, s, p) : launch_solve_TF<T, D, false>(h, s, p);
+int launch_solve_T(mals_handle h, SideState& s, const SolveParams& p, int chunk) {
+  return p.k == 16 * T ? launch_solve_TF<T, D, true>(h, s, p, chunk) : launch_solve_TF<T, D, false>(h, s, p, chunk);
 }
 
-int launch_solve(mals_handle h, SideState& s, const SolveParams& p) {
+int launch_solve(mals_handle h, SideState& s, const SolveParams& p, int chunk) {
   switch (h->T) {
-    case 1: return launch_solve_T<1, 4>(h, s, p);
-    case 2: return launch_solve_T<2, 4>(h, s, p);
-    case 3: return launch_solve_T<3, 4>(h, s, p);
-    case 4: return launch_solve_T<4, MALS_D4>(h, s, p);
-    case 5: return launch_solve_T<5, 2>(h, s, p);
-    case 6: return launch_solve_T<6, 2>(h, s, p);
-    case 7: return launch_solve_T<7, 2>(h, s, p);
-    case 8: return launch_solve_T<8, 2>(h, s, p);
+    case 1: return launch_solve_T<1, 4>(h, s, p, chunk);
+    case 2: return launch_solve_T<2, 4>(h, s, p, chunk);
+    case 3: return launch_solve_T<3, 4>(h, s, p, chunk);
+    case 4: return launch_solve_T<4, MALS_D4>(h, s, p, chunk);
+    case 5: return launch_solve_T<5, 2>(h, s, p, chunk);
+    case 6: return launch_solve_T<6, 2>(h, s, p, chunk);
+    case 7: return launch_solve_T<7, 2>(h, s, p, chunk);
+    case 8: return launch_solve_T<8, 2>(h, s, p, chunk);
   }
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
 }
@@ -418,6 +443,7 @@ int mals_default_config(mals_config* cfg) {
   cfg->flags = 0;
   cfg->device = 0;
   cfg->segment_nnz = 0;
+  cfg->chunk_rows = 0;
   return MALS_OK;
 }
 
@@ -435,6 +461,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   h->cfg.flags &= 3;
   if (const char* dbg = std::getenv("MALS_DEBUG_FLAGS")) h->cfg.flags |= (std::atoi(dbg) & 0xff) << 8;  // profiling ablations
   if (h->cfg.segment_nnz <= 0) h->cfg.segment_nnz = 4096;
+  if (h->cfg.chunk_rows < 0) h->cfg.chunk_rows = 0;
   h->cfg.segment_nnz = (h->cfg.segment_nnz + 3) & ~3;
   h->T = (cfg->features + 15) / 16;
   {
@@ -752,8 +779,7 @@ int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) {
   return MALS_OK;
 }
 
-int mals_solve_side(mals_handle h, int side) {
-  CHECK_SIDE(h, side);
+static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end) {
   SideState& s = h->side[side];
   SideState& o = h->side[1 - side];
   if (!s.has_matrix) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
@@ -761,6 +787,8 @@ int mals_solve_side(mals_handle h, int side) {
   if (s.row_offset + s.n_local > s.n_total) return fail(h, MALS_INVALID_ARG, "matrix rows exceed the factor replica");
   const bool use_g = !(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED);
   if (use_g && !o.G_valid) return fail(h, MALS_INVALID_ARG, "Gramian of the opposite side not computed");
+  if (chunk_begin < 0 || chunk_end > (int)s.chunks.size() || chunk_begin >= chunk_end)
+    return fail(h, MALS_INVALID_ARG, "chunk index out of range");
   if (int rc = use_device(h)) return rc;
   if (s.n_local == 0) return MALS_OK;
   const int k = h->cfg.features;
@@ -783,10 +811,32 @@ int mals_solve_side(mals_handle h, int side) {
   p.alpha = (float)h->cfg.alpha;
   p.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);  // ALS:435
   p.sing_threshold = (float)h->cfg.singularity_threshold;
-  if (int rc = launch_solve(h, s, p)) return rc;
-  s.G_valid = false;  // this side's factors changed
-  h->stats.rows_solved += s.n_local;
-  h->stats.nnz_gathered += s.nnz;
+  for (int c = chunk_begin; c < chunk_end; ++c) {
+    if (int rc = launch_solve(h, s, p, c)) return rc;
+    const SideState::ChunkRange& cr = s.chunks[(size_t)c];
+    h->stats.rows_solved += cr.nA + cr.nC;
+    h->stats.nnz_gathered += cr.nnzA + cr.nnzB;
+  }
+  // this side's factors changed: its Gramian is stale.  (The OPPOSITE side's Gramian stays valid
+  // for the remaining chunks of this half-iteration.)
+  s.G_valid = false;
+  return MALS_OK;
+}
+
+int mals_solve_side(mals_handle h, int side) {
+  CHECK_SIDE(h, side);
+  return solve_chunks(h, side, 0, (int)h->side[side].chunks.size());
+}
+
+int mals_solve_chunk(mals_handle h, int side, int32_t chunk) {
+  CHECK_SIDE(h, side);
+  return solve_chunks(h, side, chunk, chunk + 1);
+}
+
+int mals_num_chunks(mals_handle h, int side, int32_t* n_chunks) {
+  CHECK_SIDE(h, side);
+  if (!h->side[side].has_matrix) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
+  if (n_chunks) *n_chunks = (int32_t)h->side[side].chunks.size();
   return MALS_OK;
 }
 

@@ -89,8 +89,28 @@ class ShardedALS:
     def half_iteration(self, side):
         """iterateXFromY (ALS:340-362) for SIDE_X / iterateYFromX (ALS:367-389) for SIDE_Y."""
         self._gramian(1 - side)
-        self.core.solve_side(side)
-        self._all_gather(side)
+        cr = getattr(self.core, "chunk_rows", 0)
+        if self.world == 1 or cr <= 0 or cr >= self.per[side]:
+            self.core.solve_side(side)
+            self._all_gather(side)
+            return
+        # Pipelined exchange: the slice is solved in chunks of `chunk_rows` rows; as soon as a chunk
+        # is solved its rows are all-gathered asynchronously (RCCL on its own stream) while the
+        # next chunk is being solved.  Every rank contributes the same chunk of its (padded) slice,
+        # so each collective is a plain equal-sized all-gather; padding rows are zero and stay zero.
+        import torch.distributed as dist
+        full, per = self.F[side], self.per[side]
+        n_chunks = (per + cr - 1) // cr
+        mine = self.core.num_chunks(side)
+        works = []
+        for c in range(n_chunks):
+            if c < mine:
+                self.core.solve_chunk(side, c)
+            lo, hi = c * cr, min((c + 1) * cr, per)
+            outs = [full[r * per + lo:r * per + hi] for r in range(self.world)]
+            works.append(dist.all_gather(outs, outs[self.rank], async_op=True))
+        for w in works:
+            w.wait()
 
     def iterate(self, n=1, check=True):
         for _ in range(n):

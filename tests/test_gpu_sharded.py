@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, shape, q):
+def _run(rank, world, port, shape, q, chunk_rows=0):
     n_users, n_items, nnz, k = shape
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,7 +34,7 @@ def _run(rank, world, port, shape, q):
     try:
         torch.cuda.set_device(0)
         r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, nnz, k, seed=31)
-        core = pkg.ALSCore(k, device=0)
+        core = pkg.ALSCore(k, device=0, chunk_rows=chunk_rows)
         core.set_stream(torch.cuda.current_stream().cuda_stream)
         s = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device="cuda:0")
         s.set_matrix_from_full(pkg.SIDE_X, *r_csr)
@@ -51,7 +51,8 @@ def _run(rank, world, port, shape, q):
             dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_rank():
+@pytest.mark.parametrize("chunk_rows", [0, 130])       # 130: 501 users per rank -> 4 pipelined chunks
+def test_two_ranks_on_one_gpu_match_single_rank(chunk_rows):
     shape = (1001, 333, 30000, 24)          # odd sizes: the last slices are padded
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -60,7 +61,7 @@ def test_two_ranks_on_one_gpu_match_single_rank():
     _, X1, Y1 = q.get(timeout=300)
     p.join(timeout=60)
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, shape, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, shape, q, chunk_rows)) for r in range(2)]
     for pr in procs:
         pr.start()
     res = [q.get(timeout=300) for _ in range(2)]
@@ -71,3 +72,26 @@ def test_two_ranks_on_one_gpu_match_single_rank():
         # partial-Gramian summation order differs from the single-rank Gramian only in fp64 rounding
         assert np.allclose(X, X1, rtol=2e-5, atol=2e-6), rank
         assert np.allclose(Y, Y1, rtol=2e-5, atol=2e-6), rank
+
+
+def test_chunked_solve_is_bitwise_identical_to_whole_side():
+    k, n_users, n_items = 40, 1500, 600
+    r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 40000, k, seed=12)
+    outs = []
+    for chunk_rows in (0, 400):
+        with pkg.ALSCore(k, chunk_rows=chunk_rows, segment_nnz=64) as core:
+            core.set_factor_rows(pkg.SIDE_X, n_users)
+            core.set_factor_rows(pkg.SIDE_Y, n_items)
+            core.set_matrix(pkg.SIDE_X, *r_csr)
+            core.set_factors(pkg.SIDE_Y, Y0)
+            core.gramian(pkg.SIDE_Y)
+            if chunk_rows:
+                assert core.num_chunks(pkg.SIDE_X) == 4
+                for c in (2, 0, 3, 1):                      # any order
+                    core.solve_chunk(pkg.SIDE_X, c)
+            else:
+                assert core.num_chunks(pkg.SIDE_X) == 1
+                core.solve_side(pkg.SIDE_X)
+            core.check()
+            outs.append(core.get_factors(pkg.SIDE_X))
+    assert np.array_equal(outs[0], outs[1])

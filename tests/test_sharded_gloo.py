@@ -18,8 +18,9 @@ from oracle import oracle
 class OracleBackedCore:
     """Duck-types the ALSCore methods ShardedALS uses, on CPU tensors."""
 
-    def __init__(self, k, alpha=1.0, lam=0.1):
+    def __init__(self, k, alpha=1.0, lam=0.1, chunk_rows=0):
         self.k, self.alpha, self.lam = k, alpha, lam
+        self.chunk_rows = chunk_rows
         self.F, self.M, self.G = {}, {}, {}
 
     def bind_factors(self, side, t):
@@ -43,6 +44,18 @@ class OracleBackedCore:
                                 alpha=self.alpha, lam=self.lam)
         self.F[side][off:off + len(rp) - 1].copy_(torch.from_numpy(out))
 
+    def num_chunks(self, side):
+        n = len(self.M[side][0]) - 1
+        return max(1, -(-n // self.chunk_rows))
+
+    def solve_chunk(self, side, c):
+        rp, col, val, off = self.M[side]
+        n = len(rp) - 1
+        r0, r1 = min(n, c * self.chunk_rows), min(n, (c + 1) * self.chunk_rows)
+        out = oracle.solve_rows(rp, col, val, self.F[1 - side].numpy(), self.G[1 - side],
+                                alpha=self.alpha, lam=self.lam, row_begin=r0, row_end=r1)
+        self.F[side][off + r0:off + r1].copy_(torch.from_numpy(out[r0:r1]))
+
     def check(self):
         pass
 
@@ -61,8 +74,9 @@ def _worker(rank, world, port, n_users, n_items, k, nnz, mode, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, nnz, k, seed=9)
-        s = sharded.ShardedALS(OracleBackedCore(k), n_users, n_items, k, rank=rank, world=world,
-                               device="cpu", gramian_mode=mode)
+        chunk_rows = 13 if mode == "chunked" else 0        # 51 users per rank -> 4 chunks; 19 items -> 2
+        s = sharded.ShardedALS(OracleBackedCore(k, chunk_rows=chunk_rows), n_users, n_items, k, rank=rank, world=world,
+                               device="cpu", gramian_mode="allreduce" if mode == "chunked" else mode)
         s.set_matrix_from_full(pkg.SIDE_X, *r_csr)
         s.set_matrix_from_full(pkg.SIDE_Y, *c_csr)
         s.set_factors(pkg.SIDE_Y, Y0)
@@ -73,7 +87,7 @@ def _worker(rank, world, port, n_users, n_items, k, nnz, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "replicated"])
+@pytest.mark.parametrize("mode", ["allreduce", "replicated", "chunked"])
 def test_world2_gloo_matches_unsharded(mode):
     n_users, n_items, k, nnz, world = 101, 37, 6, 1500, 2     # odd sizes: last slice is padded
     ctx = mp.get_context("spawn")
