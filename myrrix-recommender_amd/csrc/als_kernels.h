@@ -298,8 +298,10 @@ __device__ __forceinline__ Chunk chunk_issue(const SolveParams& p, int64_t begin
   const int n = base + lane;
   const int nn = n < len ? n : len - 1;
   Chunk e;
-  e.col = p.col[begin + nn];
-  e.w = p.val[begin + nn];           // raw r_ui until chunk_weights
+  // the entry stream is read exactly once: non-temporal, so that it does not push factor rows
+  // out of L2 / Infinity Cache
+  e.col = __builtin_nontemporal_load(p.col + begin + nn);
+  e.w = __builtin_nontemporal_load(p.val + begin + nn);  // raw r_ui until chunk_weights
   e.cb = n < len ? 1.f : 0.f;        // validity
   return e;
 }
@@ -516,11 +518,15 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
     float bpart[T];
 #pragma unroll
     for (int v = 0; v < T; ++v) bpart[v] = 0.f;
+#ifdef MALS_PROFILING  // per-phase cycle stamps + ablation switches; not compiled into the product library
     const bool tr = MODE == 0 && p.trace && wave < 64 && it < 64 * n_waves;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (tr) t0 = __builtin_readcyclecounter();
     if (!(p.flags & 0x200)) gather_row<T, D, FULL>(p, cur.begin, cur.len, lane, pp, acc, bpart);
     if (tr) t1 = __builtin_readcyclecounter();
+#else
+    gather_row<T, D, FULL>(p, cur.begin, cur.len, lane, pp, acc, bpart);
+#endif
     float bcol[T];
 #pragma unroll
     for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);
@@ -532,16 +538,21 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
       add_ridge<T>(p, acc, cur.len, lane);
       float minpiv = 3.0e38f;
       float xcol[T];
-      if (p.flags & 0x100) {  // profiling ablation (MALS_DEBUG_FLAGS): skip K3
+#ifdef MALS_PROFILING
+      if (p.flags & 0x100) {  // ablation (MALS_DEBUG_FLAGS): skip K3
 #pragma unroll
         for (int v = 0; v < T; ++v) xcol[v] = 1e-3f + 1e-9f * (bcol[v] + acc[tidx(T, v, v)][0] + acc[tidx(T, 0, v)][1]);
         if (prime_next) {
           chunk_weights(p, pp.ch);
           prime_row<T, D, FULL>(p, lane, pp);
         }
-      } else {
+      } else
+#endif
+      {
         cholesky_tiles<T>(acc, lane, minpiv);
+#ifdef MALS_PROFILING
         if (tr) t2 = __builtin_readcyclecounter();
+#endif
         if (prime_next) {  // gathers land during the solves
           chunk_weights(p, pp.ch);
           prime_row<T, D, FULL>(p, lane, pp);
@@ -549,6 +560,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
         solve_tiles<T>(acc, bcol, xcol, lane);
       }
       store_row<T>(p, xcol, minpiv, cur.id, lane);
+#ifdef MALS_PROFILING
       if (tr) {
         t3 = __builtin_readcyclecounter();
         if (lane == 0) {
@@ -556,6 +568,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
           o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = (unsigned long long)cur.len;
         }
       }
+#endif
     } else {
       float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64) + lane;
 #pragma unroll

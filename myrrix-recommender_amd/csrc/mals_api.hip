@@ -459,7 +459,9 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   if (!h) return MALS_OOM;
   h->cfg = *cfg;
   h->cfg.flags &= 3;
-  if (const char* dbg = std::getenv("MALS_DEBUG_FLAGS")) h->cfg.flags |= (std::atoi(dbg) & 0xff) << 8;  // profiling ablations
+#ifdef MALS_PROFILING
+  if (const char* dbg = std::getenv("MALS_DEBUG_FLAGS")) h->cfg.flags |= (std::atoi(dbg) & 0xff) << 8;  // ablations
+#endif
   if (h->cfg.segment_nnz <= 0) h->cfg.segment_nnz = 4096;
   if (h->cfg.chunk_rows < 0) h->cfg.chunk_rows = 0;
   h->cfg.segment_nnz = (h->cfg.segment_nnz + 3) & ~3;
@@ -477,10 +479,12 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
     delete h;
     return MALS_HIP_ERROR;
   }
+#ifdef MALS_PROFILING
   if (std::getenv("MALS_DEBUG_TRACE")) {
     (void)hipMalloc(&h->d_trace, 64 * 64 * 5 * sizeof(unsigned long long));
     (void)hipMemset(h->d_trace, 0, 64 * 64 * 5 * sizeof(unsigned long long));
   }
+#endif
   *out = h;
   return MALS_OK;
 }
