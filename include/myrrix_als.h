@@ -47,7 +47,8 @@ enum {
   MALS_HIP_ERROR = 3,
   MALS_COMM_ERROR = 4,
   MALS_CANCELLED = 5,
-  MALS_OOM = 6
+  MALS_OOM = 6,
+  MALS_ILL_CONDITIONED = 7 /* IllConditionedSolverException (Generation.java:150-153) */
 };
 
 enum { MALS_SIDE_X = 0, MALS_SIDE_Y = 1 };
@@ -171,6 +172,12 @@ int mals_num_chunks(mals_handle h, int side, int32_t* n_chunks);
 /* Synchronise the stream and report MALS_SINGULAR if any row solved since the last check had a
  * non-positive-definite system (the reference throws SingularMatrixSolverException, CMLSS:46-54). */
 int mals_check(mals_handle h);
+/* Details of the last MALS_SINGULAR: the side, the (global) row -- -1 when it was a model Gramian
+ * (mals_recompute_solver) -- and the apparent rank the reference would report (CMLSS:47,
+ * RRQRDecomposition.getRank(0.01)), which DelegateGenerationManager.java:345-354 uses to lower
+ * model.features and retry.  For a row, the rank is recomputed on the host in fp64 from the row's
+ * entries and the CURRENT opposite factors / Gramian, i.e. it is exact when the check directly
+ * follows the solve (mals_half_iteration, mals_factorize); 0 = could not be determined. */
 int mals_singular_info(mals_handle h, int32_t* side, int64_t* row, int32_t* apparent_rank);
 
 /* iterateXFromY (ALS:340-362) for side X, iterateYFromX (ALS:367-389) for side Y:
@@ -189,6 +196,27 @@ int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iter
 /* Cooperative cancellation (InterruptedException path, MatrixFactorizer.java:43-44): checked
  * between half-iterations of mals_factorize. */
 int mals_cancel(mals_handle h);
+
+/* ---- the model-load consumer of K1 --------------------------------
+ * Generation.recomputeSolver (online/src/net/myrrix/online/generation/Generation.java:142-158):
+ * M^T M of `side`'s factors (K1 on the device), its max-abs-column-sum norm (getNorm(), :149), and
+ * MatrixUtils.getSolver(M^T M) (MU:137, CMLSS:37-55).  The k x k factorization is host fp64.
+ *   MALS_OK, *out = NULL        the side has no factor rows ("M == null || M.isEmpty()", :145)
+ *   MALS_ILL_CONDITIONED        norm < 1.0 (:150-153); *inf_norm_out holds the norm
+ *   MALS_SINGULAR               getSolver threw; rank via mals_singular_info (row = -1)
+ * The Gramian stays installed on the device like after mals_gramian. */
+typedef struct mals_solver_s* mals_solver;
+int mals_recompute_solver(mals_handle h, int side, mals_solver* out, double* inf_norm_out);
+
+/* MatrixUtils.getSolver(A) for a caller-supplied row-major n x n matrix (host only, no device
+ * needed).  MALS_SINGULAR: *apparent_rank_out = getRank(0.01) and *out = NULL. */
+int mals_solver_create(const double* A, int32_t n, double singularity_threshold, mals_solver* out,
+                       int32_t* apparent_rank_out);
+int mals_solver_dim(mals_solver s);
+/* Solver.solveDToF / solveFToD (Solver.java:35-41, CommonsMathSolver.java:37-59). */
+int mals_solver_solve_dtof(mals_solver s, const double* b, float* x);
+int mals_solver_solve_ftod(mals_solver s, const float* b, double* x);
+int mals_solver_destroy(mals_solver s);
 
 int mals_enable_timing(mals_handle h, int32_t on);
 int mals_reset_stats(mals_handle h);

@@ -5,6 +5,7 @@ MatrixFactorizer / AlternatingLeastSquares surface.
   csrc/                         hand-written gfx950 kernels + host library (libmyrrix_als.so)
   core.ALSCore                  one handle = one GPU (plumbing over the C-ABI)
   factorizer                    host mirror of the reference interface (same names / errors)
+  generation                    host mirror of Generation.recomputeSolver + Solver (8(f) row 1)
   sharded.ShardedALS            one process per GPU, torch.distributed (RCCL) all-gather between
                                 half-iterations
   synth                         seeded synthetic interaction matrices
@@ -13,13 +14,15 @@ Importing the package does not need a GPU; creating an ALSCore does, and fails l
 one.  There is no CPU fallback anywhere in this package.
 """
 from . import _lib
-from .core import ALSCore, Cancelled, MalsError, SingularSystem
+from .core import ALSCore, Cancelled, HostSolver, IllConditioned, MalsError, SingularSystem
 from .factorizer import (AlternatingLeastSquares, ExecutionException, InterruptedException,
                          MatrixFactorizer, MatrixUtils, SingularMatrixSolverException,
                          SolverException, System)
+from .generation import Generation, IllConditionedSolverException, Solver
 from ._lib import (FLAG_LOSS_IGNORES_UNSPECIFIED, FLAG_RECONSTRUCT_R, SIDE_X, SIDE_Y)
 
-__all__ = ["ALSCore", "MalsError", "SingularSystem", "Cancelled", "AlternatingLeastSquares",
+__all__ = ["ALSCore", "HostSolver", "IllConditioned", "Generation", "Solver",
+           "IllConditionedSolverException", "MalsError", "SingularSystem", "Cancelled", "AlternatingLeastSquares",
            "MatrixFactorizer", "MatrixUtils", "System", "ExecutionException",
            "InterruptedException", "SolverException", "SingularMatrixSolverException",
            "SIDE_X", "SIDE_Y", "FLAG_RECONSTRUCT_R", "FLAG_LOSS_IGNORES_UNSPECIFIED"]

@@ -8,13 +8,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MALS_LIB") or os.path.join(_HERE, "csrc", "libmyrrix_als.so")  # MALS_LIB: A/B builds
 
-OK, SINGULAR, INVALID_ARG, HIP_ERROR, COMM_ERROR, CANCELLED, OOM = range(7)
+OK, SINGULAR, INVALID_ARG, HIP_ERROR, COMM_ERROR, CANCELLED, OOM, ILL_CONDITIONED = range(8)
 SIDE_X, SIDE_Y = 0, 1
 FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
-                COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM"}
+                COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM",
+                ILL_CONDITIONED: "ILL_CONDITIONED"}
 
 
 class Config(ctypes.Structure):
@@ -70,6 +71,12 @@ SYMBOLS = {
     "mals_factorize": (ctypes.c_int, [_H, ctypes.c_double, _I32, _I32, _I32, _P, _I32, _P, _I32,
                                       ctypes.POINTER(_I32), ctypes.POINTER(ctypes.c_double)]),
     "mals_cancel": (ctypes.c_int, [_H]),
+    "mals_recompute_solver": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(_H), ctypes.POINTER(ctypes.c_double)]),
+    "mals_solver_create": (ctypes.c_int, [_P, _I32, ctypes.c_double, ctypes.POINTER(_H), ctypes.POINTER(_I32)]),
+    "mals_solver_dim": (ctypes.c_int, [_H]),
+    "mals_solver_solve_dtof": (ctypes.c_int, [_H, _P, _P]),
+    "mals_solver_solve_ftod": (ctypes.c_int, [_H, _P, _P]),
+    "mals_solver_destroy": (ctypes.c_int, [_H]),
     "mals_enable_timing": (ctypes.c_int, [_H, _I32]),
     "mals_reset_stats": (ctypes.c_int, [_H]),
     "mals_get_stats": (ctypes.c_int, [_H, ctypes.POINTER(Stats)]),

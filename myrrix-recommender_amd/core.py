@@ -31,6 +31,66 @@ class Cancelled(MalsError):
     pass
 
 
+class IllConditioned(MalsError):
+    """MALS_ILL_CONDITIONED: IllConditionedSolverException (Generation.java:150-153)."""
+
+    def __init__(self, status, message, inf_norm):
+        super().__init__(status, message)
+        self.inf_norm = inf_norm
+
+
+class HostSolver:
+    """One mals_solver: the fp64 pivoted-QR factorization of a k x k matrix (Solver.java:35-41)."""
+
+    def __init__(self, L, handle):
+        self._L, self._s = L, handle
+        self.n = L.mals_solver_dim(handle)
+
+    @classmethod
+    def create(cls, A, singularity_threshold=1e-5):
+        """MatrixUtils.getSolver(A) (MU:137, CMLSS:37-55); raises SingularSystem with the rank."""
+        L = _lib.load()
+        A = _host(A, np.float64)
+        assert A.ndim == 2 and A.shape[0] == A.shape[1]
+        s, rank = ctypes.c_void_p(), ctypes.c_int32(0)
+        rc = L.mals_solver_create(A.ctypes.data_as(ctypes.c_void_p), A.shape[0], float(singularity_threshold),
+                                  ctypes.byref(s), ctypes.byref(rank))
+        if rc == _lib.SINGULAR:
+            raise SingularSystem(rc, "Apparent rank: %d" % rank.value, -1, -1, rank.value)
+        if rc != _lib.OK:
+            raise MalsError(rc, "mals_solver_create failed")
+        return cls(L, s)
+
+    def solve_dtof(self, b):
+        b = _host(b, np.float64)
+        assert b.shape == (self.n,)
+        x = np.empty(self.n, dtype=np.float32)
+        rc = self._L.mals_solver_solve_dtof(self._s, b.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p))
+        if rc != _lib.OK:
+            raise MalsError(rc, "mals_solver_solve_dtof failed")
+        return x
+
+    def solve_ftod(self, b):
+        b = _host(b, np.float32)
+        assert b.shape == (self.n,)
+        x = np.empty(self.n, dtype=np.float64)
+        rc = self._L.mals_solver_solve_ftod(self._s, b.ctypes.data_as(ctypes.c_void_p), x.ctypes.data_as(ctypes.c_void_p))
+        if rc != _lib.OK:
+            raise MalsError(rc, "mals_solver_solve_ftod failed")
+        return x
+
+    def close(self):
+        if getattr(self, "_s", None) is not None and self._s.value:
+            self._L.mals_solver_destroy(self._s)
+            self._s = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _is_torch(a):
     return type(a).__module__.startswith("torch")
 
@@ -231,6 +291,17 @@ class ALSCore:
     def cancel(self):
         self._chk(self._L.mals_cancel(self._h))
 
+    def recompute_solver(self, side):
+        """Generation.recomputeSolver (Generation.java:142-158) for `side`'s factors.  Returns
+        (HostSolver or None for an empty side, norm)."""
+        s, norm = ctypes.c_void_p(), ctypes.c_double(0.0)
+        rc = self._L.mals_recompute_solver(self._h, side, ctypes.byref(s), ctypes.byref(norm))
+        if rc == _lib.ILL_CONDITIONED:
+            msg = (self._L.mals_last_error(self._h) or b"").decode("utf-8", "replace")
+            raise IllConditioned(rc, msg, norm.value)
+        self._chk(rc)
+        return (HostSolver(self._L, s) if s.value else None), norm.value
+
     # -- stats ------------------------------------------------------------------------------------
     def enable_timing(self, on=True):
         self._chk(self._L.mals_enable_timing(self._h, 1 if on else 0))
@@ -244,5 +315,5 @@ class ALSCore:
         return {name: getattr(st, name) for name, _ in _lib.Stats._fields_ if name not in ("struct_size", "reserved")}
 
 
-__all__ = ["ALSCore", "MalsError", "SingularSystem", "Cancelled", "SIDE_X", "SIDE_Y",
+__all__ = ["ALSCore", "HostSolver", "MalsError", "SingularSystem", "Cancelled", "IllConditioned", "SIDE_X", "SIDE_Y",
            "FLAG_RECONSTRUCT_R", "FLAG_LOSS_IGNORES_UNSPECIFIED"]

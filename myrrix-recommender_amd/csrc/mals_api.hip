@@ -5,6 +5,7 @@
 // MALS_HIP_ERROR otherwise.
 #include "../../include/myrrix_als.h"
 #include "als_kernels.h"
+#include "host_solver.h"
 
 #include <hip/hip_runtime.h>
 
@@ -844,6 +845,47 @@ int mals_num_chunks(mals_handle h, int side, int32_t* n_chunks) {
   return MALS_OK;
 }
 
+namespace {
+
+// The reference's SingularMatrixSolverException carries RRQR's getRank(0.01) of the failing row's
+// system (CMLSS:47).  Error path only: rebuild that one k x k system on the host in fp64 from the
+// row's entries, the current opposite factors and their Gramian (ALS:450-492).  0 = unknown.
+int apparent_rank_of_row(mals_handle h, int side, int64_t local_row) {
+  SideState& s = h->side[side];
+  SideState& o = h->side[1 - side];
+  const int k = h->cfg.features;
+  if (!s.has_matrix || local_row < 0 || local_row >= s.n_local || !o.F) return 0;
+  const int64_t e0 = s.h_row_ptr[local_row], n_u = s.h_row_ptr[local_row + 1] - e0;
+  std::vector<int32_t> col((size_t)n_u);
+  std::vector<float> val((size_t)n_u);
+  std::vector<int64_t> idx((size_t)n_u);
+  std::vector<float> rows((size_t)n_u * k);
+  std::vector<double> W((size_t)k * k, 0.0);
+  if (n_u > 0) {
+    if (n_u > (int64_t)INT32_MAX) return 0;
+    if (hipMemcpy(col.data(), s.col + e0, sizeof(int32_t) * (size_t)n_u, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (hipMemcpy(val.data(), s.val + e0, sizeof(float) * (size_t)n_u, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (int64_t e = 0; e < n_u; ++e) idx[e] = col[e];
+    if (mals_get_rows(h, 1 - side, idx.data(), (int32_t)n_u, rows.data()) != MALS_OK) return 0;
+  }
+  const bool reconstruct = h->cfg.flags & MALS_FLAG_RECONSTRUCT_R;
+  if (!(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED)) {
+    if (!o.G || hipMemcpy(W.data(), o.G, sizeof(double) * W.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  }
+  for (int64_t e = 0; e < n_u; ++e) {
+    const float* y = rows.data() + (size_t)e * k;
+    double w = 0.0;
+    if (h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) w += 1.0;             // ALS:524-539
+    if (!reconstruct) w += h->cfg.alpha * std::fabs((double)val[e]);             // ALS:471-477
+    for (int r = 0; r < k; ++r)
+      for (int c = 0; c < k; ++c) W[(size_t)r * k + c] += w * (double)y[r] * (double)y[c];
+  }
+  for (int d = 0; d < k; ++d) W[(size_t)d * k + d] += h->cfg.lambda * h->cfg.alpha * (double)n_u;  // ALS:488
+  return mals::PivotedQR(W.data(), k, h->cfg.singularity_threshold).rank(0.01);
+}
+
+}  // namespace
+
 int mals_check(mals_handle h) {
   if (!h) return MALS_INVALID_ARG;
   if (int rc = use_device(h)) return rc;
@@ -853,9 +895,7 @@ int mals_check(mals_handle h) {
     if (h->h_bad[sd] != ~0ull) {
       h->sing_side = sd;
       h->sing_row = h->side[sd].row_offset + (int64_t)h->h_bad[sd];
-      // The reference reports RRQR's getRank(0.01) (CMLSS:47); no test pins that value.  The
-      // native core reports 0 = "unknown"; the adapter recomputes it in Java if it needs it.
-      h->sing_rank = 0;
+      h->sing_rank = apparent_rank_of_row(h, sd, (int64_t)h->h_bad[sd]);
       HIPCHK(h, hipMemsetAsync(h->d_bad, 0xff, 2 * sizeof(unsigned long long), h->stream));
       char buf[160];
       std::snprintf(buf, sizeof(buf), "near-singular system (pivot <= %g) for row %lld of side %c", h->cfg.singularity_threshold,
@@ -872,6 +912,77 @@ int mals_singular_info(mals_handle h, int32_t* side, int64_t* row, int32_t* appa
   if (row) *row = h->sing_row;
   if (apparent_rank) *apparent_rank = h->sing_rank;
   return MALS_OK;
+}
+
+// ---- Generation.recomputeSolver ---------------------------------------
+struct mals_solver_s {
+  mals::PivotedQR qr;
+};
+
+int mals_solver_create(const double* A, int32_t n, double singularity_threshold, mals_solver* out, int32_t* apparent_rank_out) {
+  if (out) *out = nullptr;
+  if (!A || !out || n <= 0) return MALS_INVALID_ARG;
+  mals_solver s = new (std::nothrow) mals_solver_s{mals::PivotedQR(A, n, singularity_threshold)};
+  if (!s) return MALS_OOM;
+  if (!s->qr.non_singular()) {  // CMLSS:43-54
+    if (apparent_rank_out) *apparent_rank_out = s->qr.rank(0.01);
+    delete s;
+    return MALS_SINGULAR;
+  }
+  *out = s;
+  return MALS_OK;
+}
+
+int mals_solver_dim(mals_solver s) { return s ? s->qr.dim() : 0; }
+
+int mals_solver_solve_dtof(mals_solver s, const double* b, float* x) {
+  if (!s || !b || !x) return MALS_INVALID_ARG;
+  std::vector<double> t((size_t)s->qr.dim());
+  s->qr.solve(b, t.data());
+  for (int i = 0; i < s->qr.dim(); ++i) x[i] = (float)t[i];  // CommonsMathSolver.java:40-42
+  return MALS_OK;
+}
+
+int mals_solver_solve_ftod(mals_solver s, const float* b, double* x) {
+  if (!s || !b || !x) return MALS_INVALID_ARG;
+  std::vector<double> t(b, b + s->qr.dim());  // CommonsMathSolver.java:48-51
+  s->qr.solve(t.data(), x);
+  return MALS_OK;
+}
+
+int mals_solver_destroy(mals_solver s) {
+  delete s;
+  return MALS_OK;
+}
+
+int mals_recompute_solver(mals_handle h, int side, mals_solver* out, double* inf_norm_out) {
+  CHECK_SIDE(h, side);
+  if (!out) return fail(h, MALS_INVALID_ARG, "out must not be NULL");
+  *out = nullptr;
+  if (inf_norm_out) *inf_norm_out = 0.0;
+  SideState& s = h->side[side];
+  if (!s.F || s.n_total == 0) return MALS_OK;  // Generation.java:145-147: no solver for an empty matrix
+  const int k = h->cfg.features;
+  std::vector<double> G((size_t)k * k);
+  if (int rc = mals_gramian(h, side, G.data())) return rc;  // Generation.java:148
+  const double norm = mals::max_abs_column_sum(G.data(), k);  // :149
+  if (inf_norm_out) *inf_norm_out = norm;
+  if (!(norm >= 1.0)) {  // :150-153 (a NaN norm is ill-conditioned too)
+    char buf[96];
+    std::snprintf(buf, sizeof(buf), "infNorm: %g; try decreasing model.als.lambda", norm);
+    return fail(h, MALS_ILL_CONDITIONED, buf);
+  }
+  int32_t rank = 0;
+  const int rc = mals_solver_create(G.data(), k, h->cfg.singularity_threshold, out, &rank);
+  if (rc == MALS_SINGULAR) {
+    h->sing_side = side;
+    h->sing_row = -1;
+    h->sing_rank = rank;
+    char buf[96];
+    std::snprintf(buf, sizeof(buf), "Apparent rank: %d", rank);
+    return fail(h, rc, buf);
+  }
+  return rc == MALS_OK ? MALS_OK : fail(h, rc, "mals_solver_create failed");
 }
 
 int mals_half_iteration(mals_handle h, int side) {

@@ -3,6 +3,7 @@
 //   AlternatingLeastSquaresTest.testALS / testALSPredictingR  (ALST:38-78, data ALST:92-115)
 //   NegativeInputTest.testALS                                  (NIT:36-80)
 //   MatrixUtilsTest.testAddTo / testRemove                     (MatrixUtilsTest.java:33-60)
+// plus the solver state of Generation (include/myrrix/generation.hpp; Generation.java:132-158).
 // The expected matrices are the known-answer data of those tests.  Tolerance 1e-6, the reference's own (the GPU path is
 // fp32; the reference's fp64 path is pinned at 1e-6 by the oracle, tests/test_oracle_golden.py).
 // Exit code 0 = all passed.  Needs a GPU.
@@ -11,6 +12,7 @@
 #include <cstdlib>
 
 #include "../../include/myrrix/factorizer.hpp"
+#include "../../include/myrrix/generation.hpp"
 
 using namespace myrrix;
 
@@ -103,6 +105,48 @@ int main() {
       CHECK(als.iterations() >= 2);  // ALS:252-253
       for (auto& e : als.getX())
         for (float f : e.second) CHECK(std::isfinite(f));
+    }
+    {  // Generation.recomputeSolver + Solver (Generation.java:142-158): (Y^T Y) x = b round trip
+      const int k = 6;
+      FastByIDMap<FloatVector> X, Y;
+      std::mt19937_64 rng(7);
+      std::normal_distribution<float> nd;
+      for (int i = 0; i < 300; ++i) {
+        FloatVector v(k), w(k);
+        for (int f = 0; f < k; ++f) { v[f] = nd(rng); w[f] = nd(rng); }
+        X[10 + i] = v;
+        Y[500 + 3 * i] = w;
+      }
+      Generation gen(X, Y);
+      CHECK(gen.getNumUsers() == 300 && gen.getNumItems() == 300);
+      CHECK(gen.getXTXSolver() != nullptr && gen.getYTYSolver() != nullptr);
+      std::vector<double> G((size_t)k * k, 0.0);  // fp64 Y^T Y on the host for the residual
+      for (auto& e : Y)
+        for (int r = 0; r < k; ++r)
+          for (int c = 0; c < k; ++c) G[(size_t)r * k + c] += (double)e.second[r] * (double)e.second[c];
+      FloatVector b = {1.f, -2.f, 0.5f, 3.f, 0.f, -1.f};
+      std::vector<double> x = gen.getYTYSolver()->solveFToD(b);
+      double worst = 0.0;
+      for (int r = 0; r < k; ++r) {
+        double s = 0.0;
+        for (int c = 0; c < k; ++c) s += G[(size_t)r * k + c] * x[c];
+        worst = std::fmax(worst, std::fabs(s - b[r]));
+      }
+      std::printf("%-22s max |Y^T Y x - b| = %.3g\n", "Generation solver", worst);
+      CHECK(worst < 1e-4);
+      FloatVector xf = gen.getYTYSolver()->solveDToF(std::vector<double>(b.begin(), b.end()));
+      for (int r = 0; r < k; ++r) CHECK(std::fabs(xf[r] - (float)x[r]) <= 1e-6f * std::fmax(1.f, std::fabs(xf[r])));
+      // ill-conditioned (Generation.java:150-153) and rank-deficient (CMLSS:46-54) factors
+      FastByIDMap<FloatVector> tiny = {{1, {1e-3f, 0.f}}, {2, {0.f, 1e-3f}}}, none;
+      bool threw = false;
+      try { Generation bad(none, tiny); } catch (const IllConditionedSolverException&) { threw = true; }
+      CHECK(threw);
+      FastByIDMap<FloatVector> flat = {{1, {1.f, 2.f, 3.f}}, {2, {2.f, 4.f, 6.f}}, {3, {-1.f, -2.f, -3.f}}};
+      int rank = -1;
+      try { Generation bad(none, flat); } catch (const SingularMatrixSolverException& e) { rank = e.getApparentRank(); }
+      CHECK(rank == 1);
+      CHECK(Generation(none, none).getYTYSolver() == nullptr);
+      CHECK(isNonSingular({2.0, 0.0, 0.0, 3.0}, 2) && !isNonSingular({1.0, 1.0, 1.0, 1.0}, 2));
     }
     {  // constructor preconditions (ALS:139-141)
       FastByIDMap<FastByIDFloatMap> a, b;

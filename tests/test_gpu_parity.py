@@ -135,7 +135,7 @@ def test_loss_ignores_unspecified_empty_row_is_singular_like_the_reference():
     row_ptr = np.array([0, 2, 2], dtype=np.int64)      # row 1 is empty: W = 0
     col = np.array([0, 1], dtype=np.int32)
     val = np.array([1.0, 2.0], dtype=np.float32)
-    with pytest.raises(oracle.SingularMatrix):
+    with pytest.raises(oracle.SingularMatrix) as eo:
         oracle.half_iteration(row_ptr, col, val, Y0, flags=pkg.FLAG_LOSS_IGNORES_UNSPECIFIED)
     with pkg.ALSCore(k, flags=pkg.FLAG_LOSS_IGNORES_UNSPECIFIED) as core:
         core.set_factor_rows(pkg.SIDE_X, 2)
@@ -145,6 +145,7 @@ def test_loss_ignores_unspecified_empty_row_is_singular_like_the_reference():
         with pytest.raises(pkg.SingularSystem) as ei:
             core.half_iteration(pkg.SIDE_X)
         assert ei.value.row == 1
+        assert ei.value.apparent_rank == eo.value.apparent_rank == 1     # CMLSS:47 getRank(0.01)
 
 
 @pytest.mark.parametrize("alpha,lam", [(1.0, 0.1), (40.0, 0.1), (1.0, 0.9), (0.5, 0.01)])
@@ -262,8 +263,13 @@ def test_singular_system_is_reported():
         with pytest.raises(pkg.SingularSystem) as ei:
             core.half_iteration(pkg.SIDE_X)
         assert ei.value.side == pkg.SIDE_X and ei.value.row in (0, 1)
-    with pytest.raises(oracle.SingularMatrix):
-        oracle.half_iteration(row_ptr, col, val, Y0, lam=0.0)
+        got_row, got_rank = ei.value.row, ei.value.apparent_rank
+    # the apparent rank the exception carries (DelegateGenerationManager.java:345-354 lowers
+    # model.features to it) is the oracle's for that row
+    with pytest.raises(oracle.SingularMatrix) as eo:
+        oracle.solve_rows(row_ptr, col, val, Y0, oracle.gramian(Y0), lam=0.0, row_begin=got_row,
+                          row_end=got_row + 1)
+    assert got_rank == eo.value.apparent_rank == 1
 
 
 def test_determinism_bitwise():
