@@ -58,6 +58,8 @@ enum { MALS_FLAG_RECONSTRUCT_R = 1, MALS_FLAG_LOSS_IGNORES_UNSPECIFIED = 2 };
 
 enum { MALS_MEM_HOST = 0, MALS_MEM_DEVICE = 1 };
 
+enum { MALS_GRAMIAN_AUTO = 0, MALS_GRAMIAN_FP32 = 1, MALS_GRAMIAN_SPLIT_F16 = 2 };
+
 typedef struct mals_config {
   int32_t struct_size;          /* sizeof(mals_config), for ABI evolution                      */
   int32_t features;             /* k; ALS:134 "features must be positive"; 1..128 supported    */
@@ -73,6 +75,14 @@ typedef struct mals_config {
                                    rows that can be solved one by one (mals_solve_chunk), so that
                                    the caller can exchange a finished range while the next one is
                                    being solved; 0 = one chunk                                  */
+  int32_t gramian_mode;         /* arithmetic of the per-row Gramian sum (c-1) y y^T (ALS:471-477):
+                                   MALS_GRAMIAN_AUTO (default): FP32 for features <= 32, SPLIT_F16
+                                   for 33..64, FP32 above; MALS_GRAMIAN_FP32: fp32 products, fp32
+                                   accumulate; MALS_GRAMIAN_SPLIT_F16 (features <= 64): operands
+                                   split into two f16 halves (22 significand bits), exact products,
+                                   fp32 accumulate -- 2.5x less matrix-pipe time, ~4x the rounding
+                                   error of FP32, both far inside 1e-4                          */
+  int32_t reserved0;
 } mals_config;
 
 typedef struct mals_stats {

@@ -12,6 +12,7 @@ OK, SINGULAR, INVALID_ARG, HIP_ERROR, COMM_ERROR, CANCELLED, OOM, ILL_CONDITIONE
 SIDE_X, SIDE_Y = 0, 1
 FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
+GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
                 COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM",
@@ -23,7 +24,8 @@ class Config(ctypes.Structure):
                 ("alpha", ctypes.c_double), ("lam", ctypes.c_double),
                 ("singularity_threshold", ctypes.c_double), ("flags", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("segment_nnz", ctypes.c_int32),
-                ("chunk_rows", ctypes.c_int32)]
+                ("chunk_rows", ctypes.c_int32), ("gramian_mode", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32)]
 
 
 class Stats(ctypes.Structure):

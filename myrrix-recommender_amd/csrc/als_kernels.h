@@ -19,10 +19,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace mals {
 
 #ifndef MALS_WAVES
 #define MALS_WAVES(T, MODE) ((T) <= 4 ? 4 : ((T) == 5 ? 3 : 2))
+#endif
+#ifndef MALS_WAVES_H
+#define MALS_WAVES_H(T, MODE) ((MODE) == 0 ? 3 : 2)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -60,6 +65,7 @@ struct SolveParams {
   float alpha;
   float lambda_alpha;       // lambda*alpha
   float sing_threshold;
+  const float* zscale;      // split-precision gather only: {S, 1/S^2}, written by gather_scale_kernel
   unsigned long long* trace;  // profiling only (MALS_DEBUG_TRACE): per-phase s_memtime stamps
 };
 
@@ -404,6 +410,172 @@ __device__ __forceinline__ void gather_row(const SolveParams& p, int64_t begin, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2, split-precision variant (T = 3, 4).  Measured on gfx950 (tools/ubench/coexec2.hip): an
+// fp32-input MFMA occupies its SIMD for 33 cycles per 16x16x4 and nothing else issues meanwhile, so
+// at k = 64 the fp32 Gramian above costs 10 x 33 cycles per 4 entries and the gather is matrix-issue
+// bound, not HBM bound.  The f16 matrix pipe does a 16x16x32 product in 17 cycles, 16x the
+// contraction depth per cycle.  Here the per-row Gramian  sum_n w_n y_n y_n^T  is therefore computed
+// as  sum_n z_n z_n^T  with z_n = sqrt(w_n) S y_n  split into two f16 numbers z = zh + zl
+// (zh = the top 11 significand bits of z, zl = the next 11, round-toward-zero) and three f16 MFMAs
+// per tile:  zh zh^T + zh zl^T + zl zh^T  (fp32 accumulate; the dropped zl zl^T term is < 2^-22
+// relative).  Every f16 x f16 product is exact in fp32, so the only error is the 22-bit
+// representation of z: ~4x the rounding error of the fp32 path, still two orders of magnitude
+// inside the 1e-4 bar (tests/test_gpu_parity.py).  S is a power of two chosen per launch so that
+// max |z| <= 2^14 (gather_scale_kernel): f16 overflow cannot happen, and values down to 2^-18 of the
+// largest keep all 22 bits.  The right-hand side is still accumulated in fp32 from the raw rows.
+//
+// One "super-step" = 32 entries = the contraction depth of one MFMA.  Lane (g,c) holds, for entry
+// n = 4e+g (e = 0..7) of the super-step and every 16-block v, feature 16v+c: T*8 dword gathers per
+// lane, each instruction again reading 4 rows x 64 B.  Slot e of the lane is contraction index
+// k = 8g+e of both MFMA operands (the same bijection entry <-> k on both sides, so the sum is over
+// the 32 entries whatever the hardware's k order is).  Pipeline: convert super-step s (raw ->
+// zh, zl; RHS update), issue the gathers of s+1 into the same raw registers, then the 3*tri(T)
+// MFMAs of s while they fly; across rows the first super-step of the next row is in flight during
+// the factorization, like above.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma_h(const i32x4& a, const i32x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ int pk_rtz(float a, float b) {  // v_cvt_pkrtz_f16_f32
+  return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+
+// the Gramian weight of the chunk becomes sqrt(w) * S
+__device__ __forceinline__ void chunk_weights_h(const SolveParams& p, Chunk& e, float zscale) {
+  chunk_weights(p, e);
+  e.w = __builtin_amdgcn_sqrtf(e.w) * zscale;
+}
+
+template <int T>
+struct PipeH {
+  Chunk ch;         // current 64-entry chunk (two super-steps)
+  float raw[T][8];  // gathered rows of one super-step: raw[v][e] = M[col(4e+g)][16v+c]
+};
+
+// Gather the two entries 4e+g, e = 2*E2 and 2*E2+1, of one super-step: their columns sit in lanes
+// (off/4 + 4e + g) of col_src (off = 4g + 128*half of the chunk).  Entries past the end of the row
+// have a clamped column (chunk_issue) and zero weights, so they gather a valid, cached row that
+// contributes nothing: no per-entry predication.  As in load_rows, lanes past k in a partial last
+// block never load and stay zero.
+template <int T, bool FULL, int E2>
+__device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, int off, int lane, float (&raw)[T][8]) {
+  const int c = lane & 15;
+#pragma unroll
+  for (int e = 2 * E2; e < 2 * E2 + 2; ++e) {
+    const int col = bperm_i(off + 16 * e, col_src);
+    const float* ptr = p.M + ((uint64_t)(uint32_t)col * (uint32_t)p.k + (uint32_t)c);
+#pragma unroll
+    for (int v = 0; v < T - 1; ++v) raw[v][e] = ptr[16 * v];
+    if (FULL || 16 * (T - 1) + c < p.k) raw[T - 1][e] = ptr[16 * (T - 1)];
+  }
+}
+
+// raw rows of one entry pair -> scaled, split f16 operands; RHS partial sums (fp32, raw rows)
+template <int T, int HALF, int E2>
+__device__ __forceinline__ void convert_pair_h(const Chunk& ch, int lane, const float (&raw)[T][8], i32x4 (&zh)[T], i32x4 (&zl)[T],
+                                               float (&bpart)[T]) {
+  const int gb = (lane >> 4) << 2;
+  const int o0 = 128 * HALF + 32 * E2, o1 = o0 + 16;
+  const float s0 = bperm(gb + o0, ch.w), s1 = bperm(gb + o1, ch.w);
+  const float c0 = bperm(gb + o0, ch.cb), c1 = bperm(gb + o1, ch.cb);
+#pragma unroll
+  for (int v = 0; v < T; ++v) {
+    const float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
+    const float z0 = y0 * s0, z1 = y1 * s1;
+    const float h0 = __int_as_float(__float_as_int(z0) & 0xffffe000);  // top 11 significand bits: exact in f16
+    const float h1 = __int_as_float(__float_as_int(z1) & 0xffffe000);
+    zh[v][E2] = pk_rtz(h0, h1);
+    zl[v][E2] = pk_rtz(z0 - h0, z1 - h1);
+    bpart[v] = fmaf(c0, y0, bpart[v]);
+    bpart[v] = fmaf(c1, y1, bpart[v]);
+  }
+}
+
+// Convert super-step (ch, HALF) out of the raw registers and, pair by pair, refill them with the
+// gathers of whatever comes next (columns in next_col at next_off): the registers are in flight
+// again as soon as they have been read.  The fences keep that order: left alone, the scheduler
+// issues the refills first and copies the old rows aside, at twice the registers.
+template <int T, bool FULL, int HALF>
+__device__ __forceinline__ void convert_refill_h(const SolveParams& p, const Chunk& ch, int next_col, int next_off, int lane,
+                                                 float (&raw)[T][8], i32x4 (&zh)[T], i32x4 (&zl)[T], float (&bpart)[T]) {
+#define MALS_SB __builtin_amdgcn_sched_barrier(0)
+  convert_pair_h<T, HALF, 0>(ch, lane, raw, zh, zl, bpart);
+  MALS_SB;
+  issue_pair_h<T, FULL, 0>(p, next_col, next_off, lane, raw);
+  MALS_SB;
+  convert_pair_h<T, HALF, 1>(ch, lane, raw, zh, zl, bpart);
+  MALS_SB;
+  issue_pair_h<T, FULL, 1>(p, next_col, next_off, lane, raw);
+  MALS_SB;
+  convert_pair_h<T, HALF, 2>(ch, lane, raw, zh, zl, bpart);
+  MALS_SB;
+  issue_pair_h<T, FULL, 2>(p, next_col, next_off, lane, raw);
+  MALS_SB;
+  convert_pair_h<T, HALF, 3>(ch, lane, raw, zh, zl, bpart);
+  MALS_SB;
+  issue_pair_h<T, FULL, 3>(p, next_col, next_off, lane, raw);
+#undef MALS_SB
+}
+
+template <int T>
+__device__ __forceinline__ void gram_super_step(const i32x4 (&zh)[T], const i32x4 (&zl)[T], f32x4 (&acc)[tri(T)]) {
+  // three passes over the tiles, so that consecutive MFMAs never wait on each other's accumulator
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h(zh[i], zh[j], acc[tidx(T, i, j)]);
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h(zh[i], zl[j], acc[tidx(T, i, j)]);
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h(zl[i], zh[j], acc[tidx(T, i, j)]);
+}
+
+// The gathers of a whole super-step (start of a wave's first row only).
+template <int T, bool FULL>
+__device__ __forceinline__ void prime_row_h(const SolveParams& p, int col_src, int lane, float (&raw)[T][8]) {
+  const int gb = (lane >> 4) << 2;
+  issue_pair_h<T, FULL, 0>(p, col_src, gb, lane, raw);
+  issue_pair_h<T, FULL, 1>(p, col_src, gb, lane, raw);
+  issue_pair_h<T, FULL, 2>(p, col_src, gb, lane, raw);
+  issue_pair_h<T, FULL, 3>(p, col_src, gb, lane, raw);
+}
+
+// acc (zero on entry) += S^2 * sum_n w_n y_n y_n^T,  bpart += sum_n cb_n y_n  for a row with len > 0.
+// On entry ch = chunk 0 (weights done) and raw = super-step 0 in flight; on exit raw = super-step 0
+// of the NEXT row (columns in lanes 0..31 of next_col) in flight.
+template <int T, bool FULL>
+__device__ __forceinline__ void gather_row_h(const SolveParams& p, int64_t begin, int len, int lane, float zscale, Chunk& ch,
+                                             int next_col, float (&raw)[T][8], f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
+  const int gb = (lane >> 4) << 2;
+  const int n_ss = (len + 31) >> 5;
+  for (int q = 0; 2 * q < n_ss; ++q) {
+    // next chunk (clamped inside the row, so always safe to issue); lands during this chunk
+    Chunk chn = chunk_issue(p, begin, len, 64 * (q + 1), lane);
+    i32x4 zh[T], zl[T];
+    const bool last0 = 2 * q + 1 >= n_ss;
+    convert_refill_h<T, FULL, 0>(p, ch, last0 ? next_col : ch.col, last0 ? gb : gb + 128, lane, raw, zh, zl, bpart);
+    __builtin_amdgcn_sched_barrier(0);
+    gram_super_step<T>(zh, zl, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!last0) {
+      chunk_weights_h(p, chn, zscale);
+      const bool last1 = 2 * q + 2 >= n_ss;
+      convert_refill_h<T, FULL, 1>(p, ch, last1 ? next_col : chn.col, gb, lane, raw, zh, zl, bpart);
+      __builtin_amdgcn_sched_barrier(0);
+      gram_super_step<T>(zh, zl, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ch = chn;
+  }
+}
+
 // acc <- shared Gramian image (ALS:447-450: start from YTY unless lossIgnoresUnspecified).  Gf is
 // stored in acc layout, [tile][lane] float4, so this is tri(T) 16-byte loads and no VALU.
 template <int T>
@@ -589,6 +761,102 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
   }
 }
 
+// The same two lists with the split-precision gather (gather_row_h).  Pipeline per wave: the raw
+// registers always hold the NEXT super-step in flight -- of this row or, from the last convert of
+// a row on, super-step 0 of the next row, which therefore flies during the whole factorization.
+// That needs the next row's first chunk (col, value) on chip a row ahead (nch, requested two rows
+// ahead as nnch) and the work items three ahead.  Rows are sorted by length, so the empty rows
+// (nothing to gather: W = G, b = 0) form the tail of a wave's list and are handled after the loop.
+template <int T, int MODE, bool FULL>
+__global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_kernel_h(SolveParams p) {
+  __shared__ f32x4 sG[MODE == 0 ? tri(T) * 64 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  if (MODE == 0) {  // stage the acc-layout Gramian image once per workgroup
+    const f32x4* G4 = reinterpret_cast<const f32x4*>(p.Gf);
+    for (int e = threadIdx.x; e < tri(T) * 64; e += 256) sG[e] = (p.flags & 2) ? f32x4{0.f, 0.f, 0.f, 0.f} : G4[e];
+    __syncthreads();
+  }
+  int64_t it = wave;
+  if (it >= p.n_work) return;
+  const float zscale = __int_as_float(uniform(__float_as_int(p.zscale[0])));
+  const float inv_s2 = __int_as_float(uniform(__float_as_int(p.zscale[1])));
+  WorkItem cur = load_item(p, it);
+  WorkItem nxt = load_item(p, it + n_waves);
+  WorkItem nx2 = load_item(p, it + 2 * n_waves);
+  float raw[T][8];
+#pragma unroll
+  for (int v = 0; v < T; ++v)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) raw[v][e] = 0.f;
+  if (cur.len > 0) {
+    Chunk ch = chunk_issue(p, cur.begin, cur.len, 0, lane);
+    // first chunks of the next two rows; where there is no such row, any valid columns do
+    Chunk nch = nxt.len > 0 ? chunk_issue(p, nxt.begin, nxt.len, 0, lane) : ch;
+    chunk_weights_h(p, ch, zscale);
+    prime_row_h<T, FULL>(p, ch.col, lane, raw);
+    for (;;) {
+      const Chunk nnch = nx2.len > 0 ? chunk_issue(p, nx2.begin, nx2.len, 0, lane) : nch;
+      const WorkItem nx3 = load_item(p, it + 3 * n_waves);
+      f32x4 acc[tri(T)];
+#pragma unroll
+      for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float bpart[T];
+#pragma unroll
+      for (int v = 0; v < T; ++v) bpart[v] = 0.f;
+      gather_row_h<T, FULL>(p, cur.begin, cur.len, lane, zscale, ch, nch.col, raw, acc, bpart);
+      float bcol[T];
+#pragma unroll
+      for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);
+      ch = nch;
+      if (nxt.len > 0) chunk_weights_h(p, ch, zscale);
+      if (MODE == 0) {
+        // back to the unscaled system (S^2 is a power of two: exact), on top of the shared Gramian
+#pragma unroll
+        for (int t = 0; t < tri(T); ++t) {
+          const f32x4 g4 = sG[t * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(acc[t][r], inv_s2, g4[r]);
+        }
+        add_ridge<T>(p, acc, cur.len, lane);
+        float minpiv = 3.0e38f;
+        float xcol[T];
+        cholesky_tiles<T>(acc, lane, minpiv);
+        solve_tiles<T>(acc, bcol, xcol, lane);
+        store_row<T>(p, xcol, minpiv, cur.id, lane);
+      } else {
+        float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < tri(T); ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r] * inv_s2;
+#pragma unroll
+        for (int v = 0; v < T; ++v) s[(tri(T) * 4 + v) * 64] = bcol[v];
+      }
+      cur = nxt;
+      nxt = nx2;
+      nx2 = nx3;
+      nch = nnch;
+      it += n_waves;
+      if (cur.len <= 0) break;
+    }
+  }
+  if (MODE == 0) {
+    while (cur.len == 0) {  // empty rows: W = G (+ 0 ridge), b = 0
+      f32x4 acc[tri(T)];
+#pragma unroll
+      for (int t = 0; t < tri(T); ++t) acc[t] = sG[t * 64 + lane];
+      float bcol[T];
+#pragma unroll
+      for (int v = 0; v < T; ++v) bcol[v] = 0.f;
+      finish_row<T>(p, acc, bcol, 0, cur.id, lane);
+      it += n_waves;
+      cur = load_item(p, it);
+    }
+  }
+}
+
 // list C: one wave per long row: sum the segment partials in order, then K3
 template <int T>
 __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
@@ -704,6 +972,34 @@ __global__ void gramian_pack_kernel(const double* __restrict__ G, int k, int T, 
   const int j = i + rem;
   const int row = 16 * i + 4 * (lane >> 4) + reg, col = 16 * j + (lane & 15);
   Gf[e] = (row < k && col < k) ? (float)G[(int64_t)row * k + col] : 0.f;
+}
+
+// Split-precision gather: S = 2^p with  max|z| = sqrt(w_max) * S * max|y| <= 2^14.  max|y| is
+// bounded by sqrt(max_f G_ff) (G = M^T M of the gathered factor matrix, always at hand), w_max by
+// the largest |value| of the matrix side (max_abs_kernel at upload).  out = {S, 1/S^2}.
+__global__ void gather_scale_kernel(const double* __restrict__ G, int k, float sqrt_w_max, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double d = 0.0;
+  for (int f = 0; f < k; ++f) d = fmax(d, G[(int64_t)f * k + f]);
+  const double bound = sqrt(d) * (double)sqrt_w_max;
+  int e = 0;
+  if (bound > 0.0 && bound < 1.0e300) {
+    int eb;
+    (void)frexp(bound, &eb);  // bound < 2^eb
+    e = 14 - eb;
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+  }
+  out[0] = (float)ldexp(1.0, e);
+  out[1] = (float)ldexp(1.0, -2 * e);
+}
+
+// max |v| over a value array, as the bit pattern of a non-negative float (atomicMax on uint)
+__global__ void max_abs_kernel(const float* __restrict__ v, int64_t n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(v[i]));
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ F, const int64_t* __restrict__ idx, int n, int k,

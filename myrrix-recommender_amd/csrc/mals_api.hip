@@ -51,6 +51,7 @@ struct SideState {
   RowC* rowsC = nullptr;
   int64_t nC = 0;
   float* scratch = nullptr;
+  float max_abs_val = 0.f;  // largest |value| of the shard (bounds the Gramian weights)
   // the lists are stored chunk-major (contiguous ranges of cfg.chunk_rows rows of the shard), each
   // chunk sorted by length; a chunk can be solved on its own so that the caller can overlap the
   // exchange of finished chunks with the solve of the next one
@@ -77,6 +78,9 @@ struct PendingEvent {
 struct mals_handle_s {
   mals_config cfg;
   int T = 0;
+  bool split_f16 = false;  // cfg.gramian_mode resolved
+  float* d_zscale = nullptr;  // {S, 1/S^2} of the split-precision gather (gather_scale_kernel)
+  unsigned* d_maxabs = nullptr;
   int n_cu = 256;
   SideState side[2];
   hipStream_t stream = nullptr;
@@ -156,6 +160,15 @@ int64_t slot_floats(int T) { return (int64_t)(tri(T) * 4 + T) * 64; }
 
 // Split the rows of a shard into the three work lists (DESIGN.md "work decomposition"), chunk by chunk.
 int build_work_lists(mals_handle h, SideState& s) {
+  s.max_abs_val = 0.f;
+  if (s.nnz > 0) {  // one pass over the values: bounds the Gramian weights (gather_scale_kernel)
+    HIPCHK(h, hipMemsetAsync(h->d_maxabs, 0, sizeof(unsigned), h->stream));
+    const unsigned blocks = (unsigned)std::min<int64_t>(4096, (s.nnz + 255) / 256);
+    hipLaunchKernelGGL(max_abs_kernel, dim3(blocks), dim3(256), 0, h->stream, s.val, s.nnz, h->d_maxabs);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(&s.max_abs_val, h->d_maxabs, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   const int64_t n = s.n_local;
   const int seg = h->cfg.segment_nnz;
   const int64_t chunk_rows = h->cfg.chunk_rows > 0 ? h->cfg.chunk_rows : std::max<int64_t>(n, 1);
@@ -345,8 +358,8 @@ int persistent_grid(mals_handle h, K kernel, int64_t n_work, unsigned* grid) {
   return MALS_OK;
 }
 
-template <int T, int D, bool FULL>
-int launch_solve_TF(mals_handle h, SideState& s, SolveParams p, int chunk) {
+template <typename KA, typename KB, typename KC>
+int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, KA rows_kernel, KB segments_kernel, KC finish_kernel) {
   const double per = 4.0 * p.k + 8.0;  // gathered row + col idx + value; written row + row_ptr
   const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
   PendingEvent pe;
@@ -354,28 +367,37 @@ int launch_solve_TF(mals_handle h, SideState& s, SolveParams p, int chunk) {
   if (cr.nB) {
     p.n_work = cr.nB;
     p.items = s.itemsB + cr.offB;
-    if (int rc = persistent_grid(h, als_persistent_kernel<T, D, 1, FULL>, cr.nB, &grid)) return rc;
+    if (int rc = persistent_grid(h, segments_kernel, cr.nB, &grid)) return rc;
     if (int rc = begin_timed(h, 1, (double)cr.nnzB * per, pe)) return rc;
-    hipLaunchKernelGGL((als_persistent_kernel<T, D, 1, FULL>), dim3(grid), dim3(256), 0, h->stream, p);
+    hipLaunchKernelGGL(segments_kernel, dim3(grid), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
   if (cr.nA) {
     p.n_work = cr.nA;
     p.items = s.itemsA + cr.offA;
-    if (int rc = persistent_grid(h, als_persistent_kernel<T, D, 0, FULL>, cr.nA, &grid)) return rc;
+    if (int rc = persistent_grid(h, rows_kernel, cr.nA, &grid)) return rc;
     if (int rc = begin_timed(h, 0, (double)cr.nnzA * per + (double)cr.nA * per, pe)) return rc;
-    hipLaunchKernelGGL((als_persistent_kernel<T, D, 0, FULL>), dim3(grid), dim3(256), 0, h->stream, p);
+    hipLaunchKernelGGL(rows_kernel, dim3(grid), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
   if (cr.nC) {
     p.n_work = cr.nC;
     p.rowsC = s.rowsC + cr.offC;
     if (int rc = begin_timed(h, 2, (double)cr.nC * per, pe)) return rc;
-    hipLaunchKernelGGL((als_finish_kernel<T>), dim3((unsigned)((cr.nC + 3) / 4)), dim3(256), 0, h->stream, p);
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((cr.nC + 3) / 4)), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
+}
+
+template <int T, int D, bool FULL>
+int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk) {
+  if constexpr (T <= 4) {
+    if (h->split_f16)
+      return launch_lists(h, s, p, chunk, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>, als_finish_kernel<T>);
+  }
+  return launch_lists(h, s, p, chunk, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
 }
 
 template <int T, int D>
@@ -445,6 +467,7 @@ int mals_default_config(mals_config* cfg) {
   cfg->device = 0;
   cfg->segment_nnz = 0;
   cfg->chunk_rows = 0;
+  cfg->gramian_mode = MALS_GRAMIAN_AUTO;
   return MALS_OK;
 }
 
@@ -467,6 +490,18 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   if (h->cfg.chunk_rows < 0) h->cfg.chunk_rows = 0;
   h->cfg.segment_nnz = (h->cfg.segment_nnz + 3) & ~3;
   h->T = (cfg->features + 15) / 16;
+  switch (cfg->gramian_mode) {
+    case MALS_GRAMIAN_AUTO: h->split_f16 = h->T == 3 || h->T == 4; break;
+    case MALS_GRAMIAN_FP32: h->split_f16 = false; break;
+    case MALS_GRAMIAN_SPLIT_F16:
+      if (h->T > 4) {
+        delete h;
+        return MALS_INVALID_ARG;
+      }
+      h->split_f16 = true;
+      break;
+    default: delete h; return MALS_INVALID_ARG;
+  }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -476,6 +511,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   h->stats.struct_size = (int32_t)sizeof(mals_stats);
   if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(&h->h_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&h->d_zscale, 2 * sizeof(float)) != hipSuccess || hipMalloc(&h->d_maxabs, sizeof(unsigned)) != hipSuccess ||
       hipMemset(h->d_bad, 0xff, 2 * sizeof(unsigned long long)) != hipSuccess) {
     delete h;
     return MALS_HIP_ERROR;
@@ -518,6 +554,8 @@ int mals_destroy(mals_handle h) {
     free_dev(s.partials);
   }
   free_dev(h->d_bad);
+  free_dev(h->d_zscale);
+  free_dev(h->d_maxabs);
   if (h->h_bad) (void)hipHostFree(h->h_bad);
   free_dev(h->d_idx);
   free_dev(h->d_rows);
@@ -790,7 +828,8 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   if (!s.has_matrix) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
   if (!s.F || !o.F) return fail(h, MALS_INVALID_ARG, "factor replicas not allocated");
   if (s.row_offset + s.n_local > s.n_total) return fail(h, MALS_INVALID_ARG, "matrix rows exceed the factor replica");
-  const bool use_g = !(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED);
+  // the split-precision gather takes its scale from the Gramian's diagonal even when W does not start from G
+  const bool use_g = !(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) || h->split_f16;
   if (use_g && !o.G_valid) return fail(h, MALS_INVALID_ARG, "Gramian of the opposite side not computed");
   if (chunk_begin < 0 || chunk_end > (int)s.chunks.size() || chunk_begin >= chunk_end)
     return fail(h, MALS_INVALID_ARG, "chunk index out of range");
@@ -816,6 +855,13 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.alpha = (float)h->cfg.alpha;
   p.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);  // ALS:435
   p.sing_threshold = (float)h->cfg.singularity_threshold;
+  p.zscale = h->d_zscale;
+  if (h->split_f16) {
+    const double base_w = (h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) ? 1.0 : 0.0;
+    const double w_max = base_w + ((h->cfg.flags & MALS_FLAG_RECONSTRUCT_R) ? 0.0 : std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
+    hipLaunchKernelGGL(gather_scale_kernel, dim3(1), dim3(64), 0, h->stream, o.G, k, (float)std::sqrt(w_max), h->d_zscale);
+    HIPCHK(h, hipGetLastError());
+  }
   for (int c = chunk_begin; c < chunk_end; ++c) {
     if (int rc = launch_solve(h, s, p, c)) return rc;
     const SideState::ChunkRange& cr = s.chunks[(size_t)c];
@@ -987,7 +1033,7 @@ int mals_recompute_solver(mals_handle h, int side, mals_solver* out, double* inf
 
 int mals_half_iteration(mals_handle h, int side) {
   CHECK_SIDE(h, side);
-  if (!(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) || !h->side[1 - side].G_valid) {
+  if (!(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) || h->split_f16 || !h->side[1 - side].G_valid) {
     if (int rc = mals_gramian(h, 1 - side, nullptr)) return rc;  // ALS:342 / ALS:369
   }
   if (int rc = mals_solve_side(h, side)) return rc;                // ALS:344 / ALS:371

@@ -31,12 +31,12 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # mals_config: 2 x int32, 3 x double, 4 x int32 ; mals_stats: 2 x int32, 4 x double, 4 x int64, 4 x double, 2 x int64
-    assert ctypes.sizeof(_lib.Config) == 48
+    # mals_config: 2 x int32, 3 x double, 6 x int32 ; mals_stats: 2 x int32, 4 x double, 4 x int64, 4 x double, 2 x int64
+    assert ctypes.sizeof(_lib.Config) == 56
     assert ctypes.sizeof(_lib.Stats) == 120
     cfg = _lib.Config()
     assert _lib.load().mals_default_config(ctypes.byref(cfg)) == _lib.OK
-    assert cfg.struct_size == 48 and cfg.features == 30            # MatrixFactorizer.java:34
+    assert cfg.struct_size == 56 and cfg.features == 30            # MatrixFactorizer.java:34
     assert cfg.alpha == 1.0 and abs(cfg.lam - 0.1) < 1e-15         # ALS:71-73
     assert cfg.singularity_threshold == 1e-5                       # LinearSystemSolver.java:33-34
 
