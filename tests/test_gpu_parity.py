@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import myrrix_recommender_amd as pkg
-from myrrix_recommender_amd import synth
+from myrrix_recommender_amd import _lib, synth
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -299,3 +299,60 @@ def test_mid_size_problem_k64_several_iterations():
         Xo = oracle.half_iteration(*r_csr, Yo, threads=8)
         Yo = oracle.half_iteration(*c_csr, Xo, threads=8)
     assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL, (rel(X, Xo), rel(Y, Yo))
+
+
+# ---- cfg.gramian_mode: fp32 products vs two-f16 split operands (gather_row / gather_row_h) --------
+@pytest.mark.parametrize("mode", [_lib.GRAMIAN_FP32, _lib.GRAMIAN_SPLIT_F16])
+@pytest.mark.parametrize("k,flags,alpha,vscale", [
+    (64, 0, 1.0, 1.0), (50, 0, 40.0, 1.0), (33, 0, 1.0, 1000.0), (48, 0, 1.0, 1e-3), (16, 0, 1.0, 1.0),
+    (10, 0, 40.0, 30.0), (64, pkg.FLAG_RECONSTRUCT_R, 1.0, 1.0),
+    (40, pkg.FLAG_LOSS_IGNORES_UNSPECIFIED, 1.0, 1.0),
+    (64, pkg.FLAG_RECONSTRUCT_R | pkg.FLAG_LOSS_IGNORES_UNSPECIFIED, 1.0, 1.0)])
+def test_gramian_modes_match_oracle(mode, k, flags, alpha, vscale):
+    n_users, n_items = 700, 300
+    r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 60000, k, seed=100 + k)
+    r_csr = (r_csr[0], r_csr[1], (r_csr[2] * vscale).astype(np.float32))
+    keep = np.flatnonzero(np.diff(r_csr[0]) >= (k if flags & 2 else 0))   # lossIgnores: n_u >= k or W is singular
+    rp = np.concatenate([[0], np.cumsum(np.diff(r_csr[0])[keep])]).astype(np.int64)
+    ent = np.concatenate([np.arange(r_csr[0][i], r_csr[0][i + 1]) for i in keep]) if len(keep) else np.zeros(0, np.int64)
+    r_csr = (rp, r_csr[1][ent], r_csr[2][ent])
+    assert len(keep) > 50
+    with pkg.ALSCore(k, alpha=alpha, flags=flags, gramian_mode=mode) as core:
+        core.set_factor_rows(pkg.SIDE_X, len(keep))
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_matrix(pkg.SIDE_X, *r_csr)
+        core.set_factors(pkg.SIDE_Y, Y0)
+        core.half_iteration(pkg.SIDE_X)
+        X = core.get_factors(pkg.SIDE_X)
+    Xo = oracle.half_iteration(*r_csr, Y0, alpha=alpha, flags=flags)
+    assert rel(X, Xo) < REL_TOL, (mode, k, flags, rel(X, Xo))
+    worst = max(rel(X[i], Xo[i]) for i in range(len(keep)))
+    assert worst < 10 * REL_TOL, (mode, k, flags, worst)
+
+
+def test_split_f16_mode_limits_and_degenerate_scales():
+    # the split path exists for features <= 64 only
+    with pytest.raises(pkg.MalsError):
+        pkg.ALSCore(65, gramian_mode=_lib.GRAMIAN_SPLIT_F16)
+    with pytest.raises(pkg.MalsError):
+        pkg.ALSCore(64, gramian_mode=7)
+    # all-zero opposite factors (G = 0: scale falls back to 1); huge / tiny factors and values
+    # (scale far from 1), combined so that W stays well conditioned in fp32
+    k = 64
+    r_csr, c_csr, Y0 = synth.numpy_problem(300, 200, 20000, k, seed=5)
+    for Y, vs in ((np.zeros_like(Y0), 1.0), (Y0 * 1e4, 1e-4), (Y0 * 1e-6, 1e6), (Y0 * 300, 100.0)):
+        rc = (r_csr[0], r_csr[1], (r_csr[2] * vs).astype(np.float32))
+        with pkg.ALSCore(k, gramian_mode=_lib.GRAMIAN_SPLIT_F16) as core:
+            core.set_factor_rows(pkg.SIDE_X, 300)
+            core.set_factor_rows(pkg.SIDE_Y, 200)
+            core.set_matrix(pkg.SIDE_X, *rc)
+            core.set_factors(pkg.SIDE_Y, Y)
+            try:
+                core.half_iteration(pkg.SIDE_X)
+                X = core.get_factors(pkg.SIDE_X)
+                assert np.all(np.isfinite(X))
+                Xo = oracle.half_iteration(*rc, Y)
+                assert rel(X, Xo) < REL_TOL or np.linalg.norm(Xo) == 0
+            except pkg.SingularSystem:
+                with pytest.raises(oracle.SingularMatrix):      # singular in the reference too
+                    oracle.half_iteration(*rc, Y)

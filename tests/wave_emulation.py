@@ -1,7 +1,7 @@
 """Lane-level numpy emulation of the K2/K3 wave algorithm (one 64-lane wave per row).
 
 This is a design check, not product code and not the oracle: it executes the exact register/lane
-choreography the HIP kernel uses (myrrix-recommender_amd/csrc/als_kernels.hip) with numpy arrays
+choreography the HIP kernel uses (myrrix-recommender_amd/csrc/als_kernels.h) with numpy arrays
 of shape [64] standing in for VGPRs, so the MFMA fragment layouts, the blocked Cholesky and the
 triangular solves can be validated on a CPU-only box (tests/test_wave_emulation.py).
 
@@ -88,6 +88,79 @@ def wave_gram_rhs(Yg, w, cb, k):
                 acc[(i, j)] = mfma_16x16x4(a[i], yv[j], acc[(i, j)])
         for v in range(T):
             bpart[v] = (bpart[v] + cbn * yv[v]).astype(np.float32)
+    bcol = [reduce_groups(bpart[v]) for v in range(T)]
+    return acc, bcol
+
+
+def f16_rtz(x):
+    """v_cvt_pkrtz_f16_f32 on each element: round toward zero to f16 (returned as fp32 values)."""
+    x = np.asarray(x, np.float32)
+    h = x.astype(np.float16)
+    over = np.abs(h.astype(np.float32)) > np.abs(x)
+    h = np.where(over, np.nextafter(h, np.float16(0)), h)
+    return h.astype(np.float32)
+
+
+def gather_scale(Gd, k, w_max):
+    """gather_scale_kernel: S = 2^e with sqrt(w_max) * S * sqrt(max_f G_ff) < 2^14."""
+    bound = np.sqrt(max(float(np.max(np.diag(Gd)[:k])), 0.0)) * np.sqrt(float(w_max))
+    e = 0
+    if 0.0 < bound < 1e300:
+        e = int(np.clip(14 - np.frexp(bound)[1], -60, 60))
+    return np.float32(np.ldexp(1.0, e)), np.float32(np.ldexp(1.0, -2 * e))
+
+
+def mfma_16x16x32_f16(a, b, acc):
+    """acc: [4][64] fp32 acc layout; a, b: [8][64] f16-representable values, slot e of lane (g,c) =
+    contraction index 8g+e.  Products of f16 numbers are exact in fp32; the hardware's internal
+    summation order is not documented, so the 32-term dot is taken exactly (fp64) and rounded once."""
+    A = np.zeros((16, 32), np.float64)
+    B = np.zeros((32, 16), np.float64)
+    for e in range(8):
+        for g in range(4):
+            A[:, 8 * g + e] = a[e][16 * g:16 * g + 16]
+            B[8 * g + e, :] = b[e][16 * g:16 * g + 16]
+    D = A @ B
+    out = np.zeros((4, 64), dtype=np.float32)
+    for row in range(16):
+        sl = slice(16 * (row >> 2), 16 * (row >> 2) + 16)
+        out[row & 3][sl] = (acc[row & 3][sl].astype(np.float64) + D[row]).astype(np.float32)
+    return out
+
+
+def wave_gram_rhs_split(Yg, w, cb, k, zscale, inv_s2):
+    """Split-precision gather (gather_row_h): super-steps of 32 entries, lane (g,c) slot e = entry
+    4e+g; z = sqrt(w)*S*y split as zh (top 11 significand bits) + zl (next 11, toward zero);
+    acc += zh zh^T + zh zl^T + zl zh^T on the f16 matrix pipe; RHS from the raw rows in fp32.
+    Returns the UNSCALED tiles (acc / S^2) and bcol."""
+    T = (k + 15) // 16
+    n_u = Yg.shape[0]
+    acc = {(i, j): np.zeros((4, 64), np.float32) for i in range(T) for j in range(i, T)}
+    bpart = [np.zeros(64, np.float32) for _ in range(T)]
+    sw = (np.sqrt(np.asarray(w, np.float32)) * np.float32(zscale)).astype(np.float32)
+    for ss in range((n_u + 31) // 32):
+        zh = [[None] * 8 for _ in range(T)]
+        zl = [[None] * 8 for _ in range(T)]
+        for e in range(8):
+            n = 32 * ss + 4 * e + G_
+            valid_n = n < n_u
+            nn = np.where(valid_n, n, n_u - 1)                    # clamped column, zero weights
+            swn = np.where(valid_n, sw[nn], 0.0).astype(np.float32)
+            cbn = np.where(valid_n, cb[nn], 0.0).astype(np.float32)
+            for v in range(T):
+                f = 16 * v + C_
+                y = np.where(f < k, Yg[nn, np.minimum(f, k - 1)], 0.0).astype(np.float32)
+                z = (y * swn).astype(np.float32)
+                h = (z.view(np.uint32) & np.uint32(0xffffe000)).view(np.float32)
+                zh[v][e] = f16_rtz(h)
+                zl[v][e] = f16_rtz((z - h).astype(np.float32))
+                bpart[v] = (bpart[v] + cbn * y).astype(np.float32)
+        for a_, b_ in ((zh, zh), (zh, zl), (zl, zh)):
+            for i in range(T):
+                for j in range(i, T):
+                    acc[(i, j)] = mfma_16x16x32_f16(a_[i], b_[j], acc[(i, j)])
+    for key in acc:
+        acc[key] = (acc[key] * np.float32(inv_s2)).astype(np.float32)
     bcol = [reduce_groups(bpart[v]) for v in range(T)]
     return acc, bcol
 
@@ -211,8 +284,10 @@ def wave_solve(acc, bcol, T):
     return xcol
 
 
-def wave_solve_row(Yg, vals, Gd, k, alpha=1.0, lam=0.1, reconstruct=False, loss_ignores=False):
-    """Full per-row pipeline; returns x[k] (fp32) and the smallest Cholesky pivot."""
+def wave_solve_row(Yg, vals, Gd, k, alpha=1.0, lam=0.1, reconstruct=False, loss_ignores=False, split_f16=False,
+                   max_abs_val=None):
+    """Full per-row pipeline; returns x[k] (fp32) and the smallest Cholesky pivot.  split_f16: the
+    MALS_GRAMIAN_SPLIT_F16 gather (max_abs_val = largest |value| of the whole matrix side)."""
     vals = np.asarray(vals, np.float32)
     n_u = len(vals)
     base_w = 1.0 if loss_ignores else 0.0
@@ -223,7 +298,12 @@ def wave_solve_row(Yg, vals, Gd, k, alpha=1.0, lam=0.1, reconstruct=False, loss_
         w = (base_w + alpha * np.abs(vals)).astype(np.float32)
         cb = np.where(vals > 0, 1.0 + alpha * np.abs(vals), 0.0).astype(np.float32)
     T = (k + 15) // 16
-    acc, bcol = wave_gram_rhs(np.asarray(Yg, np.float32).reshape(n_u, k), w, cb, k)
+    if split_f16 and n_u:
+        mx = float(np.max(np.abs(vals))) if max_abs_val is None else float(max_abs_val)
+        zscale, inv_s2 = gather_scale(Gd, k, base_w + (0.0 if reconstruct else abs(alpha) * mx))
+        acc, bcol = wave_gram_rhs_split(np.asarray(Yg, np.float32).reshape(n_u, k), w, cb, k, zscale, inv_s2)
+    else:
+        acc, bcol = wave_gram_rhs(np.asarray(Yg, np.float32).reshape(n_u, k), w, cb, k)
     acc = wave_add_base(acc, Gd, lam * alpha * n_u, k, use_g=not loss_ignores)
     acc, minpiv = wave_cholesky(acc, T)
     xcol = wave_solve(acc, bcol, T)
