@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segment-nnz", type=int, default=0)
+    ap.add_argument("--gramian-mode", default="auto", choices=["auto", "fp32", "split_f16"],
+                    help="mals_config.gramian_mode (A/B only; the headline number uses the library default)")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N>1: solve each slice in this many row chunks and all-gather a finished chunk while the next is solved")
     args = ap.parse_args()
@@ -112,7 +114,8 @@ def main():
     if world > 1 and args.exchange_chunks > 1:
         upr = sharded.rows_per_rank(n_users, world)
         chunk_rows = (upr + args.exchange_chunks - 1) // args.exchange_chunks
-    core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, chunk_rows=chunk_rows)
+    core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, chunk_rows=chunk_rows,
+                       gramian_mode={"auto": 0, "fp32": 1, "split_f16": 2}[args.gramian_mode])
     core.set_stream(torch.cuda.current_stream().cuda_stream)
     als = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device=device)
     als.set_matrix_from_full(pkg.SIDE_X, *prob["r_csr"])

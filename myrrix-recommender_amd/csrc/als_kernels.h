@@ -27,7 +27,7 @@ namespace mals {
 #define MALS_WAVES(T, MODE) ((T) <= 4 ? 4 : ((T) == 5 ? 3 : 2))
 #endif
 #ifndef MALS_WAVES_H
-#define MALS_WAVES_H(T, MODE) ((MODE) == 0 ? 3 : 2)
+#define MALS_WAVES_H(T, MODE) ((T) <= 4 && (MODE) == 0 ? 3 : ((T) == 8 && (MODE) == 0 ? 1 : 2))
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -434,14 +434,29 @@ __device__ __forceinline__ void gather_row(const SolveParams& p, int64_t begin, 
 // MFMAs of s while they fly; across rows the first super-step of the next row is in flight during
 // the factorization, like above.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ f32x4 mfma_h(const i32x4& a, const i32x4& b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+// E = entry slots per lane and super-step: 8 -> 32 entries, v_mfma_f32_16x16x32_f16 (T <= 6);
+// 4 -> 16 entries, v_mfma_f32_16x16x16_f16 (T = 7, 8, where 8 slots would not fit the registers).
+// Both MFMAs take 16 cycles, so E = 8 does twice the work per matrix-pipe cycle.
+template <int E>
+struct ZOp {  // one f16 MFMA operand: E halves = E/2 dwords
+  int r[E / 2];
+};
+template <int E>
+__device__ __forceinline__ f32x4 mfma_h(const ZOp<E>& a, const ZOp<E>& b, f32x4 c) {
+  if constexpr (E == 8) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+  }
 }
 __device__ __forceinline__ int pk_rtz(float a, float b) {  // v_cvt_pkrtz_f16_f32
   return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
+__host__ __device__ constexpr int split_slots(int T) { return T <= 5 ? 8 : 4; }
 
 // the Gramian weight of the chunk becomes sqrt(w) * S
 __device__ __forceinline__ void chunk_weights_h(const SolveParams& p, Chunk& e, float zscale) {
@@ -449,19 +464,13 @@ __device__ __forceinline__ void chunk_weights_h(const SolveParams& p, Chunk& e, 
   e.w = __builtin_amdgcn_sqrtf(e.w) * zscale;
 }
 
-template <int T>
-struct PipeH {
-  Chunk ch;         // current 64-entry chunk (two super-steps)
-  float raw[T][8];  // gathered rows of one super-step: raw[v][e] = M[col(4e+g)][16v+c]
-};
-
 // Gather the two entries 4e+g, e = 2*E2 and 2*E2+1, of one super-step: their columns sit in lanes
-// (off/4 + 4e + g) of col_src (off = 4g + 128*half of the chunk).  Entries past the end of the row
+// (off/4 + 4e + g) of col_src (off = 4g + 16*E*part of the chunk).  Entries past the end of the row
 // have a clamped column (chunk_issue) and zero weights, so they gather a valid, cached row that
 // contributes nothing: no per-entry predication.  As in load_rows, lanes past k in a partial last
 // block never load and stay zero.
-template <int T, bool FULL, int E2>
-__device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, int off, int lane, float (&raw)[T][8]) {
+template <int T, int E, bool FULL, int E2>
+__device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, int off, int lane, float (&raw)[T][E]) {
   const int c = lane & 15;
 #pragma unroll
   for (int e = 2 * E2; e < 2 * E2 + 2; ++e) {
@@ -474,11 +483,11 @@ __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, 
 }
 
 // raw rows of one entry pair -> scaled, split f16 operands; RHS partial sums (fp32, raw rows)
-template <int T, int HALF, int E2>
-__device__ __forceinline__ void convert_pair_h(const Chunk& ch, int lane, const float (&raw)[T][8], i32x4 (&zh)[T], i32x4 (&zl)[T],
+template <int T, int E, int PART, int E2>
+__device__ __forceinline__ void convert_pair_h(const Chunk& ch, int lane, const float (&raw)[T][E], ZOp<E> (&zh)[T], ZOp<E> (&zl)[T],
                                                float (&bpart)[T]) {
   const int gb = (lane >> 4) << 2;
-  const int o0 = 128 * HALF + 32 * E2, o1 = o0 + 16;
+  const int o0 = 16 * E * PART + 32 * E2, o1 = o0 + 16;
   const float s0 = bperm(gb + o0, ch.w), s1 = bperm(gb + o1, ch.w);
   const float c0 = bperm(gb + o0, ch.cb), c1 = bperm(gb + o1, ch.cb);
 #pragma unroll
@@ -487,90 +496,110 @@ __device__ __forceinline__ void convert_pair_h(const Chunk& ch, int lane, const 
     const float z0 = y0 * s0, z1 = y1 * s1;
     const float h0 = __int_as_float(__float_as_int(z0) & 0xffffe000);  // top 11 significand bits: exact in f16
     const float h1 = __int_as_float(__float_as_int(z1) & 0xffffe000);
-    zh[v][E2] = pk_rtz(h0, h1);
-    zl[v][E2] = pk_rtz(z0 - h0, z1 - h1);
+    zh[v].r[E2] = pk_rtz(h0, h1);
+    zl[v].r[E2] = pk_rtz(z0 - h0, z1 - h1);
     bpart[v] = fmaf(c0, y0, bpart[v]);
     bpart[v] = fmaf(c1, y1, bpart[v]);
   }
 }
 
-// Convert super-step (ch, HALF) out of the raw registers and, pair by pair, refill them with the
+// Convert super-step (ch, PART) out of the raw registers and, pair by pair, refill them with the
 // gathers of whatever comes next (columns in next_col at next_off): the registers are in flight
 // again as soon as they have been read.  The fences keep that order: left alone, the scheduler
 // issues the refills first and copies the old rows aside, at twice the registers.
-template <int T, bool FULL, int HALF>
+template <int T, int E, bool FULL, int PART>
 __device__ __forceinline__ void convert_refill_h(const SolveParams& p, const Chunk& ch, int next_col, int next_off, int lane,
-                                                 float (&raw)[T][8], i32x4 (&zh)[T], i32x4 (&zl)[T], float (&bpart)[T]) {
+                                                 float (&raw)[T][E], ZOp<E> (&zh)[T], ZOp<E> (&zl)[T], float (&bpart)[T]) {
 #define MALS_SB __builtin_amdgcn_sched_barrier(0)
-  convert_pair_h<T, HALF, 0>(ch, lane, raw, zh, zl, bpart);
+  convert_pair_h<T, E, PART, 0>(ch, lane, raw, zh, zl, bpart);
   MALS_SB;
-  issue_pair_h<T, FULL, 0>(p, next_col, next_off, lane, raw);
+  issue_pair_h<T, E, FULL, 0>(p, next_col, next_off, lane, raw);
   MALS_SB;
-  convert_pair_h<T, HALF, 1>(ch, lane, raw, zh, zl, bpart);
+  convert_pair_h<T, E, PART, 1>(ch, lane, raw, zh, zl, bpart);
   MALS_SB;
-  issue_pair_h<T, FULL, 1>(p, next_col, next_off, lane, raw);
-  MALS_SB;
-  convert_pair_h<T, HALF, 2>(ch, lane, raw, zh, zl, bpart);
-  MALS_SB;
-  issue_pair_h<T, FULL, 2>(p, next_col, next_off, lane, raw);
-  MALS_SB;
-  convert_pair_h<T, HALF, 3>(ch, lane, raw, zh, zl, bpart);
-  MALS_SB;
-  issue_pair_h<T, FULL, 3>(p, next_col, next_off, lane, raw);
+  issue_pair_h<T, E, FULL, 1>(p, next_col, next_off, lane, raw);
+  if constexpr (E == 8) {
+    MALS_SB;
+    convert_pair_h<T, E, PART, 2>(ch, lane, raw, zh, zl, bpart);
+    MALS_SB;
+    issue_pair_h<T, E, FULL, 2>(p, next_col, next_off, lane, raw);
+    MALS_SB;
+    convert_pair_h<T, E, PART, 3>(ch, lane, raw, zh, zl, bpart);
+    MALS_SB;
+    issue_pair_h<T, E, FULL, 3>(p, next_col, next_off, lane, raw);
+  }
 #undef MALS_SB
 }
 
-template <int T>
-__device__ __forceinline__ void gram_super_step(const i32x4 (&zh)[T], const i32x4 (&zl)[T], f32x4 (&acc)[tri(T)]) {
+template <int T, int E>
+__device__ __forceinline__ void gram_super_step(const ZOp<E> (&zh)[T], const ZOp<E> (&zl)[T], f32x4 (&acc)[tri(T)]) {
   // three passes over the tiles, so that consecutive MFMAs never wait on each other's accumulator
 #pragma unroll
   for (int i = 0; i < T; ++i)
 #pragma unroll
-    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h(zh[i], zh[j], acc[tidx(T, i, j)]);
+    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<E>(zh[i], zh[j], acc[tidx(T, i, j)]);
 #pragma unroll
   for (int i = 0; i < T; ++i)
 #pragma unroll
-    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h(zh[i], zl[j], acc[tidx(T, i, j)]);
+    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<E>(zh[i], zl[j], acc[tidx(T, i, j)]);
 #pragma unroll
   for (int i = 0; i < T; ++i)
 #pragma unroll
-    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h(zl[i], zh[j], acc[tidx(T, i, j)]);
+    for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<E>(zl[i], zh[j], acc[tidx(T, i, j)]);
 }
 
 // The gathers of a whole super-step (start of a wave's first row only).
-template <int T, bool FULL>
-__device__ __forceinline__ void prime_row_h(const SolveParams& p, int col_src, int lane, float (&raw)[T][8]) {
+template <int T, int E, bool FULL>
+__device__ __forceinline__ void prime_row_h(const SolveParams& p, int col_src, int lane, float (&raw)[T][E]) {
   const int gb = (lane >> 4) << 2;
-  issue_pair_h<T, FULL, 0>(p, col_src, gb, lane, raw);
-  issue_pair_h<T, FULL, 1>(p, col_src, gb, lane, raw);
-  issue_pair_h<T, FULL, 2>(p, col_src, gb, lane, raw);
-  issue_pair_h<T, FULL, 3>(p, col_src, gb, lane, raw);
+  issue_pair_h<T, E, FULL, 0>(p, col_src, gb, lane, raw);
+  issue_pair_h<T, E, FULL, 1>(p, col_src, gb, lane, raw);
+  if constexpr (E == 8) {
+    issue_pair_h<T, E, FULL, 2>(p, col_src, gb, lane, raw);
+    issue_pair_h<T, E, FULL, 3>(p, col_src, gb, lane, raw);
+  }
+}
+
+// One super-step of the row pipeline: PART-th group of 4E entries of chunk ch.
+template <int T, int E, bool FULL, int PART>
+__device__ __forceinline__ void super_step_h(const SolveParams& p, const Chunk& ch, const Chunk& chn, int next_col, bool last, int lane,
+                                             float (&raw)[T][E], f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
+  constexpr int NP = 16 / E;  // super-steps per 64-entry chunk
+  const int gb = (lane >> 4) << 2;
+  ZOp<E> zh[T], zl[T];
+  // what the raw registers are refilled with: the next part of this chunk, part 0 of the next chunk,
+  // or (after the row's last super-step) the first super-step of the next row
+  const int same_row_col = PART == NP - 1 ? chn.col : ch.col;
+  const int same_row_off = PART == NP - 1 ? gb : gb + 16 * E * (PART + 1);
+  convert_refill_h<T, E, FULL, PART>(p, ch, last ? next_col : same_row_col, last ? gb : same_row_off, lane, raw, zh, zl, bpart);
+  __builtin_amdgcn_sched_barrier(0);
+  gram_super_step<T, E>(zh, zl, acc);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc (zero on entry) += S^2 * sum_n w_n y_n y_n^T,  bpart += sum_n cb_n y_n  for a row with len > 0.
 // On entry ch = chunk 0 (weights done) and raw = super-step 0 in flight; on exit raw = super-step 0
-// of the NEXT row (columns in lanes 0..31 of next_col) in flight.
-template <int T, bool FULL>
+// of the NEXT row (columns in the first lanes of next_col) in flight.
+template <int T, int E, bool FULL>
 __device__ __forceinline__ void gather_row_h(const SolveParams& p, int64_t begin, int len, int lane, float zscale, Chunk& ch,
-                                             int next_col, float (&raw)[T][8], f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
-  const int gb = (lane >> 4) << 2;
-  const int n_ss = (len + 31) >> 5;
-  for (int q = 0; 2 * q < n_ss; ++q) {
+                                             int next_col, float (&raw)[T][E], f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
+  constexpr int NS = 4 * E, NP = 16 / E;
+  const int n_ss = (len + NS - 1) / NS;
+  for (int q = 0; NP * q < n_ss; ++q) {
     // next chunk (clamped inside the row, so always safe to issue); lands during this chunk
     Chunk chn = chunk_issue(p, begin, len, 64 * (q + 1), lane);
-    i32x4 zh[T], zl[T];
-    const bool last0 = 2 * q + 1 >= n_ss;
-    convert_refill_h<T, FULL, 0>(p, ch, last0 ? next_col : ch.col, last0 ? gb : gb + 128, lane, raw, zh, zl, bpart);
-    __builtin_amdgcn_sched_barrier(0);
-    gram_super_step<T>(zh, zl, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!last0) {
-      chunk_weights_h(p, chn, zscale);
-      const bool last1 = 2 * q + 2 >= n_ss;
-      convert_refill_h<T, FULL, 1>(p, ch, last1 ? next_col : chn.col, gb, lane, raw, zh, zl, bpart);
-      __builtin_amdgcn_sched_barrier(0);
-      gram_super_step<T>(zh, zl, acc);
-      __builtin_amdgcn_sched_barrier(0);
+    const int ss = NP * q;
+    super_step_h<T, E, FULL, 0>(p, ch, chn, next_col, ss + 1 >= n_ss, lane, raw, acc, bpart);
+    if (ss + 1 < n_ss) {
+      if (NP == 2) chunk_weights_h(p, chn, zscale);
+      super_step_h<T, E, FULL, 1>(p, ch, chn, next_col, ss + 2 >= n_ss, lane, raw, acc, bpart);
+    }
+    if constexpr (NP == 4) {
+      if (ss + 2 < n_ss) super_step_h<T, E, FULL, 2>(p, ch, chn, next_col, ss + 3 >= n_ss, lane, raw, acc, bpart);
+      if (ss + 3 < n_ss) {
+        chunk_weights_h(p, chn, zscale);
+        super_step_h<T, E, FULL, 3>(p, ch, chn, next_col, ss + 4 >= n_ss, lane, raw, acc, bpart);
+      }
     }
     ch = chn;
   }
@@ -785,17 +814,18 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
   WorkItem cur = load_item(p, it);
   WorkItem nxt = load_item(p, it + n_waves);
   WorkItem nx2 = load_item(p, it + 2 * n_waves);
-  float raw[T][8];
+  constexpr int E = split_slots(T);
+  float raw[T][E];
 #pragma unroll
   for (int v = 0; v < T; ++v)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) raw[v][e] = 0.f;
+    for (int e = 0; e < E; ++e) raw[v][e] = 0.f;
   if (cur.len > 0) {
     Chunk ch = chunk_issue(p, cur.begin, cur.len, 0, lane);
     // first chunks of the next two rows; where there is no such row, any valid columns do
     Chunk nch = nxt.len > 0 ? chunk_issue(p, nxt.begin, nxt.len, 0, lane) : ch;
     chunk_weights_h(p, ch, zscale);
-    prime_row_h<T, FULL>(p, ch.col, lane, raw);
+    prime_row_h<T, E, FULL>(p, ch.col, lane, raw);
     for (;;) {
       const Chunk nnch = nx2.len > 0 ? chunk_issue(p, nx2.begin, nx2.len, 0, lane) : nch;
       const WorkItem nx3 = load_item(p, it + 3 * n_waves);
@@ -805,7 +835,7 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
       float bpart[T];
 #pragma unroll
       for (int v = 0; v < T; ++v) bpart[v] = 0.f;
-      gather_row_h<T, FULL>(p, cur.begin, cur.len, lane, zscale, ch, nch.col, raw, acc, bpart);
+      gather_row_h<T, E, FULL>(p, cur.begin, cur.len, lane, zscale, ch, nch.col, raw, acc, bpart);
       float bcol[T];
 #pragma unroll
       for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);

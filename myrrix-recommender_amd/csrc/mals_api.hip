@@ -393,10 +393,8 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, KA rows_
 
 template <int T, int D, bool FULL>
 int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk) {
-  if constexpr (T <= 4) {
-    if (h->split_f16)
-      return launch_lists(h, s, p, chunk, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>, als_finish_kernel<T>);
-  }
+  if (h->split_f16)
+    return launch_lists(h, s, p, chunk, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>, als_finish_kernel<T>);
   return launch_lists(h, s, p, chunk, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
 }
 
@@ -491,15 +489,9 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   h->cfg.segment_nnz = (h->cfg.segment_nnz + 3) & ~3;
   h->T = (cfg->features + 15) / 16;
   switch (cfg->gramian_mode) {
-    case MALS_GRAMIAN_AUTO: h->split_f16 = h->T == 3 || h->T == 4; break;
+    case MALS_GRAMIAN_AUTO: h->split_f16 = h->T >= 3; break;  // k <= 32: the fp32 products are not the bottleneck
     case MALS_GRAMIAN_FP32: h->split_f16 = false; break;
-    case MALS_GRAMIAN_SPLIT_F16:
-      if (h->T > 4) {
-        delete h;
-        return MALS_INVALID_ARG;
-      }
-      h->split_f16 = true;
-      break;
+    case MALS_GRAMIAN_SPLIT_F16: h->split_f16 = true; break;
     default: delete h; return MALS_INVALID_ARG;
   }
   {

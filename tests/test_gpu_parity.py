@@ -305,6 +305,7 @@ def test_mid_size_problem_k64_several_iterations():
 @pytest.mark.parametrize("mode", [_lib.GRAMIAN_FP32, _lib.GRAMIAN_SPLIT_F16])
 @pytest.mark.parametrize("k,flags,alpha,vscale", [
     (64, 0, 1.0, 1.0), (50, 0, 40.0, 1.0), (33, 0, 1.0, 1000.0), (48, 0, 1.0, 1e-3), (16, 0, 1.0, 1.0),
+    (80, 0, 1.0, 1.0), (96, 0, 40.0, 1.0), (100, 0, 1.0, 1.0), (128, 0, 1.0, 10.0), (2, 0, 1.0, 1.0),
     (10, 0, 40.0, 30.0), (64, pkg.FLAG_RECONSTRUCT_R, 1.0, 1.0),
     (40, pkg.FLAG_LOSS_IGNORES_UNSPECIFIED, 1.0, 1.0),
     (64, pkg.FLAG_RECONSTRUCT_R | pkg.FLAG_LOSS_IGNORES_UNSPECIFIED, 1.0, 1.0)])
@@ -331,9 +332,6 @@ def test_gramian_modes_match_oracle(mode, k, flags, alpha, vscale):
 
 
 def test_split_f16_mode_limits_and_degenerate_scales():
-    # the split path exists for features <= 64 only
-    with pytest.raises(pkg.MalsError):
-        pkg.ALSCore(65, gramian_mode=_lib.GRAMIAN_SPLIT_F16)
     with pytest.raises(pkg.MalsError):
         pkg.ALSCore(64, gramian_mode=7)
     # all-zero opposite factors (G = 0: scale falls back to 1); huge / tiny factors and values

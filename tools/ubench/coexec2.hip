@@ -28,6 +28,13 @@ __device__ float work(int iters, float x, float y) {
         a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, a1, 0, 0, 0);
         a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, a2, 0, 0, 0);
         a3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, a3, 0, 0, 0);
+      } else if (KIND == 4) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 qa = {ha[0], ha[1], ha[2], ha[3]}, qb = {hb[0], hb[1], hb[2], hb[3]};
+        a0 = __builtin_amdgcn_mfma_f32_16x16x16f16(qa, qb, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x16f16(qa, qb, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x16f16(qa, qb, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_16x16x16f16(qa, qb, a3, 0, 0, 0);
       } else if (KIND == 3) {
         v0 = fmaf(v0, y, x); v1 = fmaf(v1, y, x); v2 = fmaf(v2, y, x); v3 = fmaf(v3, y, x);
         v4 = fmaf(v4, y, x); v5 = fmaf(v5, y, x); v6 = fmaf(v6, y, x); v7 = fmaf(v7, y, x);
@@ -62,6 +69,7 @@ void run(const char* name, float* d, int iters) {
 int main() {
   float* d; hipMalloc(&d, 256 * 512 * 4);
   const int it = 200000;
+  run<4, 0>("f16 MFMA 16x16x16 | idle", d, it);
   run<1, 0>("f32 MFMA | idle", d, it);
   run<2, 0>("f16 MFMA | idle", d, it);
   run<3, 0>("VALU | idle", d, it);
