@@ -152,6 +152,13 @@ int mals_append_rows(mals_handle h, int side, int64_t n_rows, const int64_t* row
                      const int32_t* col_idx, const float* val);
 int mals_end_matrix(mals_handle h, int side);
 
+/* Largest |value| of the local matrix rows of `side` (computed at upload), and an override for it.
+ * The split-precision Gramian takes its operand scale from this bound; a multi-GPU caller installs
+ * the maximum over all shards so that every rank uses the same scale and the factors do not depend
+ * on how the rows are sharded.  The override must be >= the local maximum. */
+int mals_get_value_bound(mals_handle h, int side, float* max_abs_value);
+int mals_set_value_bound(mals_handle h, int side, float max_abs_value);
+
 /* Host <-> device factor rows.  setPreviousY (ALS:172-174) = mals_set_factors(MALS_SIDE_Y, ...);
  * getX()/getY() (ALS:149-157) = mals_get_factors. */
 int mals_set_factors(mals_handle h, int side, int64_t row_begin, int64_t n_rows, const float* host_rows);

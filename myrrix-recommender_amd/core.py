@@ -214,6 +214,14 @@ class ALSCore:
                 c.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)))
         self._chk(self._L.mals_end_matrix(self._h, side))
 
+    def value_bound(self, side):
+        v = ctypes.c_float(0.0)
+        self._chk(self._L.mals_get_value_bound(self._h, side, ctypes.byref(v)))
+        return v.value
+
+    def set_value_bound(self, side, max_abs_value):
+        self._chk(self._L.mals_set_value_bound(self._h, side, float(max_abs_value)))
+
     # -- factors ----------------------------------------------------------------------------------
     def set_factors(self, side, rows, row_begin=0):
         rows = _host(rows, np.float32)

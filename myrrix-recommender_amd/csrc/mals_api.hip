@@ -51,7 +51,8 @@ struct SideState {
   RowC* rowsC = nullptr;
   int64_t nC = 0;
   float* scratch = nullptr;
-  float max_abs_val = 0.f;  // largest |value| of the shard (bounds the Gramian weights)
+  float max_abs_val = 0.f;  // bound on |value| used for the operand scale (>= local_max_abs_val)
+  float local_max_abs_val = 0.f;  // largest |value| of the shard
   // the lists are stored chunk-major (contiguous ranges of cfg.chunk_rows rows of the shard), each
   // chunk sorted by length; a chunk can be solved on its own so that the caller can overlap the
   // exchange of finished chunks with the solve of the next one
@@ -169,6 +170,7 @@ int build_work_lists(mals_handle h, SideState& s) {
     HIPCHK(h, hipMemcpyAsync(&s.max_abs_val, h->d_maxabs, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
+  s.local_max_abs_val = s.max_abs_val;
   const int64_t n = s.n_local;
   const int seg = h->cfg.segment_nnz;
   const int64_t chunk_rows = h->cfg.chunk_rows > 0 ? h->cfg.chunk_rows : std::max<int64_t>(n, 1);
@@ -708,6 +710,22 @@ int mals_end_matrix(mals_handle h, int side) {
     return rc;
   }
   s.has_matrix = true;
+  return MALS_OK;
+}
+
+int mals_get_value_bound(mals_handle h, int side, float* max_abs_value) {
+  CHECK_SIDE(h, side);
+  if (!h->side[side].has_matrix || !max_abs_value) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
+  *max_abs_value = h->side[side].max_abs_val;
+  return MALS_OK;
+}
+
+int mals_set_value_bound(mals_handle h, int side, float max_abs_value) {
+  CHECK_SIDE(h, side);
+  SideState& s = h->side[side];
+  if (!s.has_matrix) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
+  if (!(max_abs_value >= s.local_max_abs_val)) return fail(h, MALS_INVALID_ARG, "bound below the largest local |value|");
+  s.max_abs_val = max_abs_value;
   return MALS_OK;
 }
 

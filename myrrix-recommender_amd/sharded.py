@@ -53,6 +53,18 @@ class ShardedALS:
         e0, e1 = int(row_ptr[r0]), int(row_ptr[r1])
         rp = row_ptr[r0:r1 + 1] - row_ptr[r0]
         self.core.set_matrix(side, rp, col_idx[e0:e1], val[e0:e1], row_offset=r0)
+        self.sync_value_bound(side)
+
+    def sync_value_bound(self, side):
+        """Every rank uses the largest |value| over ALL shards for the split-precision operand
+        scale, so the factors do not depend on how the rows are sharded (one scalar MAX all-reduce
+        per matrix upload)."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        t = self.torch.tensor([self.core.value_bound(side)], dtype=self.torch.float32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.core.set_value_bound(side, float(t.item()))
 
     def set_factors(self, side, rows):
         """Install (replicated) factor rows [0, len(rows)) -- e.g. the initial Y."""

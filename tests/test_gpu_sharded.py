@@ -51,9 +51,11 @@ def _run(rank, world, port, shape, q, chunk_rows=0):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chunk_rows", [0, 130])       # 130: 501 users per rank -> 4 pipelined chunks
-def test_two_ranks_on_one_gpu_match_single_rank(chunk_rows):
-    shape = (1001, 333, 30000, 24)          # odd sizes: the last slices are padded
+# chunk_rows 130: 501 users per rank -> 4 pipelined chunks; k = 48: the split-precision gather, whose
+# operand scale every rank takes from the largest |value| of the whole matrix (sync_value_bound)
+@pytest.mark.parametrize("chunk_rows,k", [(0, 24), (130, 24), (0, 48), (130, 48)])
+def test_two_ranks_on_one_gpu_match_single_rank(chunk_rows, k):
+    shape = (1001, 333, 30000, k)           # odd sizes: the last slices are padded
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_run, args=(0, 1, 0, shape, q))

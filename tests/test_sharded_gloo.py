@@ -21,13 +21,20 @@ class OracleBackedCore:
     def __init__(self, k, alpha=1.0, lam=0.1, chunk_rows=0):
         self.k, self.alpha, self.lam = k, alpha, lam
         self.chunk_rows = chunk_rows
-        self.F, self.M, self.G = {}, {}, {}
+        self.F, self.M, self.G, self.bound = {}, {}, {}, {}
 
     def bind_factors(self, side, t):
         self.F[side] = t
 
     def set_matrix(self, side, row_ptr, col, val, row_offset=0):
         self.M[side] = (np.asarray(row_ptr), np.asarray(col), np.asarray(val), row_offset)
+
+    def value_bound(self, side):
+        return self.bound.get(side, float(np.max(np.abs(self.M[side][2]), initial=0.0)))
+
+    def set_value_bound(self, side, v):
+        assert v >= float(np.max(np.abs(self.M[side][2]), initial=0.0))
+        self.bound[side] = v
 
     def gramian(self, side):
         self.G[side] = oracle.gramian(self.F[side].numpy())
@@ -81,6 +88,8 @@ def _worker(rank, world, port, n_users, n_items, k, nnz, mode, q):
         s.set_matrix_from_full(pkg.SIDE_Y, *c_csr)
         s.set_factors(pkg.SIDE_Y, Y0)
         s.iterate(2)
+        # one operand-scale bound for all ranks: the largest |value| of the WHOLE matrix
+        assert s.core.bound[pkg.SIDE_X] == s.core.bound[pkg.SIDE_Y] == float(np.max(np.abs(r_csr[2])))
         q.put((rank, s.factors(pkg.SIDE_X).numpy().copy(), s.factors(pkg.SIDE_Y).numpy().copy()))
         dist.barrier()
     finally:
