@@ -956,16 +956,23 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
     for (int r = 0; r < 4; ++r) o[(t * 4 + r) * 64] = acc[t][r];
 }
 
-// one thread per (tile, reg, lane) element: sums the wave partials in order; optionally adds into
-// an existing G (accumulate = 1) so that several row ranges can be combined.
+// 64 (tile, reg, lane) elements per workgroup: each of the 4 waves sums a contiguous quarter of the
+// wave partials in order (coalesced 512-byte reads), the quarters are then added in order -- a fixed
+// summation tree, so the result is deterministic.
 template <int T>
-__global__ void gramian_finalize_kernel(const double* __restrict__ partial, int64_t n_waves, int k, double* __restrict__ G,
-                                        float* __restrict__ Gf) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= tri(T) * 256) return;
+__global__ __launch_bounds__(256) void gramian_finalize_kernel(const double* __restrict__ partial, int64_t n_waves, int k,
+                                                               double* __restrict__ G, float* __restrict__ Gf) {
+  __shared__ double part[4][64];
+  const int q = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int e = blockIdx.x * 64 + ln;  // tri(T)*256 elements, a multiple of 64
+  const int64_t per = n_waves >> 2;    // n_waves is a multiple of 4
+  double acc = 0.0;
+  for (int64_t w = q * per; w < (q + 1) * per; ++w) acc += partial[w * (int64_t)(tri(T) * 256) + e];
+  part[q][ln] = acc;
+  __syncthreads();
+  if (q != 0) return;
+  const double s = ((part[0][ln] + part[1][ln]) + part[2][ln]) + part[3][ln];
   const int t = e >> 8, reg = (e >> 6) & 3, lane = e & 63;
-  double s = 0.0;
-  for (int64_t w = 0; w < n_waves; ++w) s += partial[w * (int64_t)(tri(T) * 256) + e];
   // decode tile (i,j) from t
   int i = 0, rem = t;
   while (rem >= T - i) {

@@ -322,7 +322,7 @@ int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows
   hipLaunchKernelGGL((gramian_partial_kernel<T>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, h->stream, M, n_rows, k,
                      rows_per_wave, s.partials);
   const int elems = tri(T) * 256;
-  hipLaunchKernelGGL((gramian_finalize_kernel<T>), dim3((elems + 255) / 256), dim3(256), 0, h->stream, s.partials, n_waves,
+  hipLaunchKernelGGL((gramian_finalize_kernel<T>), dim3(elems / 64), dim3(256), 0, h->stream, s.partials, n_waves,
                      k, G_out, Gf_out);
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
