@@ -16,8 +16,8 @@ def main():
     con = sqlite3.connect(db)
     cur = con.cursor()
     rows = list(cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-    print("# rocprofv3 --kernel-trace --stats summary (durations in microseconds)")
-    print("%-112s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    print("# rocprofv3 --kernel-trace --stats summary (top_kernels view; durations in milliseconds)")
+    print("%-112s %8s %14s %12s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "pct"))
     for n, c, t, a, p in rows[:top]:
         print("%-112s %8d %14.1f %12.1f %6.2f%%" % (short(n), c, t / 1e3, a / 1e3, p))
     print("\n# per-dispatch detail of the mals:: kernels (grid = workgroups x 256 threads)")
