@@ -158,7 +158,12 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        # dominant kernel: the fused gather + Gramian + Cholesky kernel (als_persistent_kernel, MODE 0)
+        # dominant kernel: the fused gather + Gramian + Cholesky kernel over list A (MODE 0); the
+        # split-precision variant (als_persistent_kernel_h) is what AUTO selects above k = 32
+        split = args.gramian_mode == "split_f16" or (args.gramian_mode == "auto" and k > 32)
+        kernel_name = ("mals::als_persistent_kernel_h<T=%d,MODE=0> (fused gather + split-f16 Gramian + Cholesky, rows)"
+                       if split else
+                       "mals::als_persistent_kernel<T=%d,D,MODE=0> (fused gather + fp32 Gramian + Cholesky, rows)") % ((k + 15) // 16)
         avg_ms = st["rows_ms"] / max(st["rows_launches"], 1)
         bytes_per_launch = st["rows_bytes"] / max(st["rows_launches"], 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -186,7 +191,7 @@ def main():
             "config": {"workload": desc, "users": n_users, "items": n_items, "nnz": int(prob["nnz"]), "features": k,
                        "alpha": 1.0, "lambda": 0.1, "sharding": "rows x%d, %s all-gather + kxk all-reduce" % (world, "in-place" if chunk_rows == 0 else "chunked (%d rows) pipelined" % chunk_rows),
                        "setup_s": round(t_gen, 2)},
-            "roofline": {"bound": "hbm", "kernel": "mals::als_persistent_kernel<T,D,MODE=0> (fused gather + Gramian + Cholesky, rows)",
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
