@@ -26,6 +26,7 @@ WORKLOADS = {
     "c4": (10_000_000, 1_000_000, 1_000_000_000, 64, "C4 synthetic 10M x 1M, 1e9 interactions requested, k=64"),
     "c2": (162_541, 59_047, 25_000_095, 50, "C2 MovieLens-25M shape 162541 x 59047, 25M interactions requested, k=50"),
     "c3": (480_189, 17_770, 100_480_507, 100, "C3 Netflix shape 480189 x 17770, 100M interactions requested, k=100"),
+    "c4shard8": (1_250_000, 1_000_000, 125_000_000, 64, "one rank's user rows of C4 at 8 GPUs (1.25M x 1M, 125M interactions requested), k=64"),
     "small": (200_000, 50_000, 10_000_000, 64, "small smoke workload 200K x 50K, 10M interactions requested, k=64"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
