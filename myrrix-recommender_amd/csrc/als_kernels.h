@@ -28,7 +28,7 @@ namespace mals {
 #define MALS_WAVES(T, MODE) ((T) <= 4 ? 4 : ((T) == 5 ? 3 : 2))
 #endif
 #ifndef MALS_WAVES_H
-#define MALS_WAVES_H(T, MODE) ((T) <= 4 && (MODE) == 0 ? 3 : ((T) == 8 && (MODE) == 0 ? 1 : 2))
+#define MALS_WAVES_H(T, MODE) ((T) <= 4 ? 3 : ((T) == 8 && (MODE) == 0 ? 1 : 2))
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -298,6 +298,31 @@ struct Chunk {
 
 __device__ __forceinline__ int bperm_i(int byte_idx, int v) { return __builtin_amdgcn_ds_bpermute(byte_idx, v); }
 
+// ds_bpermute with the constant part of the lane address in the instruction's offset field.  hipcc
+// never folds an add into that field, so every distinct (base + constant) costs a live VGPR -- 16 of
+// them in the split-precision gather loop.  Written as asm the constants are free; the block ends
+// with its own lgkmcnt(0) because the compiler's waitcnt pass does not see inside it.
+template <int O0, int O1>
+__device__ __forceinline__ void bperm2x2(int addr, float a, float b, float& a0, float& a1, float& b0, float& b1) {
+  asm volatile(
+      "ds_bpermute_b32 %0, %4, %5 offset:%7\n\t"
+      "ds_bpermute_b32 %1, %4, %5 offset:%8\n\t"
+      "ds_bpermute_b32 %2, %4, %6 offset:%7\n\t"
+      "ds_bpermute_b32 %3, %4, %6 offset:%8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+      : "v"(addr), "v"(a), "v"(b), "n"(O0), "n"(O1));
+}
+template <int O0, int O1>
+__device__ __forceinline__ void bperm2_i(int addr, int v, int& r0, int& r1) {
+  asm volatile(
+      "ds_bpermute_b32 %0, %2, %3 offset:%4\n\t"
+      "ds_bpermute_b32 %1, %2, %3 offset:%5\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(r0), "=&v"(r1)
+      : "v"(addr), "v"(v), "n"(O0), "n"(O1));
+}
+
 // Entry base+lane of a row with len > 0.  Issued in two halves so that no arithmetic waits on the
 // loads right after they are issued: chunk_issue only loads (col, raw value), chunk_weights turns
 // the raw value into the two weights when the chunk is about to be used.
@@ -473,10 +498,12 @@ __device__ __forceinline__ void chunk_weights_h(const SolveParams& p, Chunk& e, 
 template <int T, int E, bool FULL, int E2>
 __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, int off, int lane, float (&raw)[T][E]) {
   const int c = lane & 15;
+  int col[2];
+  bperm2_i<32 * E2, 32 * E2 + 16>(off, col_src, col[0], col[1]);
 #pragma unroll
-  for (int e = 2 * E2; e < 2 * E2 + 2; ++e) {
-    const int col = bperm_i(off + 16 * e, col_src);
-    const float* ptr = p.M + ((uint64_t)(uint32_t)col * (uint32_t)p.k + (uint32_t)c);
+  for (int i = 0; i < 2; ++i) {
+    const int e = 2 * E2 + i;
+    const float* ptr = p.M + ((uint64_t)(uint32_t)col[i] * (uint32_t)p.k + (uint32_t)c);
 #pragma unroll
     for (int v = 0; v < T - 1; ++v) raw[v][e] = ptr[16 * v];
     if (FULL || 16 * (T - 1) + c < p.k) raw[T - 1][e] = ptr[16 * (T - 1)];
@@ -488,9 +515,9 @@ template <int T, int E, int PART, int E2>
 __device__ __forceinline__ void convert_pair_h(const Chunk& ch, int lane, const float (&raw)[T][E], ZOp<E> (&zh)[T], ZOp<E> (&zl)[T],
                                                float (&bpart)[T]) {
   const int gb = (lane >> 4) << 2;
-  const int o0 = 16 * E * PART + 32 * E2, o1 = o0 + 16;
-  const float s0 = bperm(gb + o0, ch.w), s1 = bperm(gb + o1, ch.w);
-  const float c0 = bperm(gb + o0, ch.cb), c1 = bperm(gb + o1, ch.cb);
+  constexpr int o0 = 16 * E * PART + 32 * E2, o1 = o0 + 16;
+  float s0, s1, c0, c1;
+  bperm2x2<o0, o1>(gb, ch.w, ch.cb, s0, s1, c0, c1);
 #pragma unroll
   for (int v = 0; v < T; ++v) {
     const float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
