@@ -101,8 +101,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # MALS_FORCE_COLLECTIVES=1 (diagnostic): run the multi-GPU code path -- chunked solves, partial
+    # Gramian + all-reduce, all-gathers -- with a single rank, to price everything but the wire
+    force = os.environ.get("MALS_FORCE_COLLECTIVES", "0") == "1"
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     n_users, n_items, nnz_req, k, desc = WORKLOADS[args.workload]
@@ -112,13 +116,13 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     chunk_rows = 0
-    if world > 1 and args.exchange_chunks > 1:
+    if (world > 1 or force) and args.exchange_chunks > 1:
         upr = sharded.rows_per_rank(n_users, world)
         chunk_rows = (upr + args.exchange_chunks - 1) // args.exchange_chunks
     core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, chunk_rows=chunk_rows,
                        gramian_mode={"auto": 0, "fp32": 1, "split_f16": 2}[args.gramian_mode])
     core.set_stream(torch.cuda.current_stream().cuda_stream)
-    als = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device=device)
+    als = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device=device, force_collectives=force)
     als.set_matrix_from_full(pkg.SIDE_X, *prob["r_csr"])
     als.set_matrix_from_full(pkg.SIDE_Y, *prob["c_csr"])
     als.set_factors(pkg.SIDE_Y, prob["Y0"])
@@ -205,7 +209,7 @@ def main():
             Y = als.factors(pkg.SIDE_Y)
             out["cpu_baseline"] = cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 

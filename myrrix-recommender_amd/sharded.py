@@ -24,7 +24,7 @@ def rows_per_rank(n, world):
 
 class ShardedALS:
     def __init__(self, core, n_users, n_items, features, rank=0, world=1, device="cuda",
-                 gramian_mode="allreduce"):
+                 gramian_mode="allreduce", force_collectives=False):
         import torch
         self.torch = torch
         self.core = core
@@ -34,6 +34,9 @@ class ShardedALS:
         self.per = {SIDE_X: rows_per_rank(n_users, world), SIDE_Y: rows_per_rank(n_items, world)}
         self.device = device
         self.gramian_mode = gramian_mode
+        # run the collectives even with a single rank (they are no-ops then): lets one GPU exercise
+        # the exact RCCL call sequence of the multi-GPU path (tests/test_gpu_sharded.py)
+        self.single = world == 1 and not force_collectives
         self.F = {}
         for side in (SIDE_X, SIDE_Y):
             self.F[side] = torch.zeros(self.per[side] * world, features, dtype=torch.float32, device=device)
@@ -59,7 +62,7 @@ class ShardedALS:
         """Every rank uses the largest |value| over ALL shards for the split-precision operand
         scale, so the factors do not depend on how the rows are sharded (one scalar MAX all-reduce
         per matrix upload)."""
-        if self.world == 1:
+        if self.single:
             return
         import torch.distributed as dist
         t = self.torch.tensor([self.core.value_bound(side)], dtype=self.torch.float32, device=self.device)
@@ -77,7 +80,7 @@ class ShardedALS:
     # -- one half-iteration -----------------------------------------------------------------------
     def _gramian(self, side):
         """Install G = M^T M of `side`'s factors for the next solve of the other side."""
-        if self.world == 1 or self.gramian_mode == "replicated":
+        if self.single or self.gramian_mode == "replicated":
             self.core.gramian(side)
             return
         import torch.distributed as dist
@@ -87,7 +90,7 @@ class ShardedALS:
         self.core.set_gramian(side, self._gp)
 
     def _all_gather(self, side):
-        if self.world == 1:
+        if self.single:
             return
         import torch.distributed as dist
         full = self.F[side]
@@ -102,7 +105,7 @@ class ShardedALS:
         """iterateXFromY (ALS:340-362) for SIDE_X / iterateYFromX (ALS:367-389) for SIDE_Y."""
         self._gramian(1 - side)
         cr = getattr(self.core, "chunk_rows", 0)
-        if self.world == 1 or cr <= 0 or cr >= self.per[side]:
+        if self.single or cr <= 0 or cr >= self.per[side]:
             self.core.solve_side(side)
             self._all_gather(side)
             return

@@ -97,3 +97,46 @@ def test_chunked_solve_is_bitwise_identical_to_whole_side():
             core.check()
             outs.append(core.get_factors(pkg.SIDE_X))
     assert np.array_equal(outs[0], outs[1])
+
+
+def _run_rccl_single(port, q, chunk_rows):
+    """One rank, backend nccl (= RCCL): world size 1 makes every collective a no-op on the wire, but
+    the whole call sequence of the multi-GPU path -- communicator creation on the device, the fp64
+    k x k all-reduce, the scalar MAX all-reduce, the in-place all-gather and the chunked async
+    all-gathers into strided views, stream ordering against the solve kernels -- runs for real."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n_users, n_items, nnz, k = 1001, 333, 30000, 48
+        r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, nnz, k, seed=31)
+        out = []
+        for force in (False, True):
+            core = pkg.ALSCore(k, device=0, chunk_rows=chunk_rows)
+            core.set_stream(torch.cuda.current_stream().cuda_stream)
+            s = sharded.ShardedALS(core, n_users, n_items, k, rank=0, world=1, device="cuda:0", force_collectives=force)
+            s.set_matrix_from_full(pkg.SIDE_X, *r_csr)
+            s.set_matrix_from_full(pkg.SIDE_Y, *c_csr)
+            s.set_factors(pkg.SIDE_Y, Y0)
+            s.iterate(2)
+            torch.cuda.synchronize()
+            out.append((s.factors(pkg.SIDE_X).cpu().numpy(), s.factors(pkg.SIDE_Y).cpu().numpy()))
+            core.close()
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunk_rows", [0, 260])
+def test_rccl_call_sequence_on_one_gpu(chunk_rows):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_run_rccl_single, args=(_free_port(), q, chunk_rows))
+    p.start()
+    (X0, Y0), (X1, Y1) = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    # partial-Gramian + all-reduce vs the fused Gramian: fp64 summation order only
+    assert np.allclose(X1, X0, rtol=2e-5, atol=2e-6) and np.allclose(Y1, Y0, rtol=2e-5, atol=2e-6)
+    assert np.all(np.isfinite(X1)) and np.linalg.norm(X1) > 0
