@@ -208,7 +208,14 @@ def main():
             X = als.factors(pkg.SIDE_X)
             Y = als.factors(pkg.SIDE_Y)
             out["cpu_baseline"] = cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k)
-        print(json.dumps(out))
+        # the JSON line must be the last thing on stdout: RCCL's banner sits in the C stdio buffer of
+        # this process until exit, so flush that first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()

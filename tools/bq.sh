@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick bench: prints ms/step + kernel split; args passed to bench.py
-python bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" 2>&1 | tail -1 | python -c "
+python bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" 2>&1 | grep '^{' | tail -1 | python -c "
 import sys,json
 t=sys.stdin.read()
 try:
