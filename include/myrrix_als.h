@@ -236,6 +236,39 @@ int mals_solver_solve_dtof(mals_solver s, const double* b, float* x);
 int mals_solver_solve_ftod(mals_solver s, const float* b, double* x);
 int mals_solver_destroy(mals_solver s);
 
+/* ---- ingest -> CSR ------------------------------------------------------
+ * What InputFilesReader.readInputFiles (online-local/src/net/myrrix/online/generation/
+ * InputFilesReader.java:64-211) does to the parsed records of the input files, on the device: the
+ * caller appends (user id, item id, value) records IN FILE ORDER -- value NaN = the line had an empty
+ * value token = "remove this entry" (IFR:137,165-167) -- and mals_ingest_finish leaves in HBM exactly
+ * the matrices the reference ends up with in RbyRow / RbyColumn:
+ *   per (user,item) pair the records are replayed in order: NaN removes the entry (MU:102-125), a
+ *   value starts it or is added to it with one fp32 add per record (MU:64-92, FastByIDFloatMap.java:
+ *   129-138); a user / item exists iff it still owns an entry at the end of the stream (MU:117-125);
+ *   then entries with |value| < zero_threshold (model.decay.zeroThreshold, IFR:58-59) are dropped,
+ *   which may leave existing rows empty (IFR:200-211 removes entries, not rows).
+ * Dense indices are assigned in ascending id order; CSR columns ascend within a row.  Side X = R by
+ * user, side Y = R^T by item.  Text parsing, tag hashing and file ordering stay with the caller.
+ * At most 2^31 records per ingest. */
+typedef struct mals_ingest_s* mals_ingest;
+int mals_ingest_create(int32_t device, float zero_threshold, mals_ingest* out);
+int mals_ingest_destroy(mals_ingest g);
+const char* mals_ingest_last_error(mals_ingest g);
+int mals_ingest_append(mals_ingest g, int64_t n, const int64_t* user_ids, const int64_t* item_ids,
+                       const float* values, int mem_kind);
+int mals_ingest_finish(mals_ingest g);
+int mals_ingest_counts(mals_ingest g, int64_t* n_records, int64_t* n_users, int64_t* n_items, int64_t* nnz);
+/* dense index -> 64-bit id (n_users / n_items entries) */
+int mals_ingest_get_ids(mals_ingest g, int side, int64_t* host_ids_out);
+/* host copies of one CSR (any pointer may be NULL) / the device arrays themselves */
+int mals_ingest_get_csr(mals_ingest g, int side, int64_t* host_row_ptr, int32_t* host_col_idx, float* host_val);
+int mals_ingest_device_csr(mals_ingest g, int side, const int64_t** row_ptr, const int32_t** col_idx, const float** val);
+/* mals_set_matrix(MALS_MEM_DEVICE) of both sides into a factorizer handle on the same device; the
+ * handle borrows the arrays, so the ingest object must outlive their use. */
+int mals_ingest_install(mals_ingest g, mals_handle h);
+/* last finish: HIP-event milliseconds, algorithmic bytes read+written by all passes, radix passes run */
+int mals_ingest_stats(mals_ingest g, double* finish_ms, double* bytes_moved, int32_t* radix_passes);
+
 int mals_enable_timing(mals_handle h, int32_t on);
 int mals_reset_stats(mals_handle h);
 int mals_get_stats(mals_handle h, mals_stats* out);

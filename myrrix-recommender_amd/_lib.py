@@ -81,6 +81,17 @@ SYMBOLS = {
     "mals_solver_solve_dtof": (ctypes.c_int, [_H, _P, _P]),
     "mals_solver_solve_ftod": (ctypes.c_int, [_H, _P, _P]),
     "mals_solver_destroy": (ctypes.c_int, [_H]),
+    "mals_ingest_create": (ctypes.c_int, [_I32, ctypes.c_float, ctypes.POINTER(_H)]),
+    "mals_ingest_destroy": (ctypes.c_int, [_H]),
+    "mals_ingest_last_error": (ctypes.c_char_p, [_H]),
+    "mals_ingest_append": (ctypes.c_int, [_H, _I64, _P, _P, _P, ctypes.c_int]),
+    "mals_ingest_finish": (ctypes.c_int, [_H]),
+    "mals_ingest_counts": (ctypes.c_int, [_H, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "mals_ingest_get_ids": (ctypes.c_int, [_H, ctypes.c_int, _P]),
+    "mals_ingest_get_csr": (ctypes.c_int, [_H, ctypes.c_int, _P, _P, _P]),
+    "mals_ingest_device_csr": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P)]),
+    "mals_ingest_install": (ctypes.c_int, [_H, _H]),
+    "mals_ingest_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I32)]),
     "mals_enable_timing": (ctypes.c_int, [_H, _I32]),
     "mals_reset_stats": (ctypes.c_int, [_H]),
     "mals_get_stats": (ctypes.c_int, [_H, ctypes.POINTER(Stats)]),

@@ -1,0 +1,447 @@
+// ingest_api.hip -- host side of the ingest -> CSR path (mals_ingest_*, include/myrrix_als.h).
+// Everything between "records appended" and "two CSR matrices + id tables in HBM" runs on the device
+// (ingest_kernels.h); the host only sequences kernels and reads back three counters.
+#include "../../include/myrrix_als.h"
+#include "ingest_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mals;
+
+struct mals_ingest_s {
+  int device = 0;
+  float zero_threshold = 1.0e-4f;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // appended records (device), capacity-doubling
+  int64_t n = 0, cap = 0;
+  int64_t* d_user = nullptr;
+  int64_t* d_item = nullptr;
+  float* d_value = nullptr;
+  // results
+  bool finished = false;
+  int64_t n_users = 0, n_items = 0, nnz = 0;
+  int64_t* ids[2] = {nullptr, nullptr};      // dense index -> id, ascending
+  int64_t* ptr[2] = {nullptr, nullptr};      // CSR row pointers (side X: by user, side Y: by item)
+  int32_t* col[2] = {nullptr, nullptr};
+  float* val[2] = {nullptr, nullptr};
+  double last_finish_ms = 0.0;
+  double bytes_moved = 0.0;  // algorithmic bytes of the last finish (reads + writes of every pass)
+  int radix_passes = 0;
+};
+
+namespace {
+
+int fail(mals_ingest g, int code, const std::string& msg) {
+  if (g) g->err = msg;
+  return code;
+}
+
+#define ICHK(g, call)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (call);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      const int _code = (_e == hipErrorOutOfMemory) ? MALS_OOM : MALS_HIP_ERROR;       \
+      return fail(g, _code, std::string(#call) + ": " + hipGetErrorString(_e));        \
+    }                                                                                  \
+  } while (0)
+
+template <typename P>
+void dfree(P*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+unsigned blocks_for(int64_t n, int per_block = 256, int64_t cap = 1 << 20) {
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + per_block - 1) / per_block, cap));
+}
+
+// scratch shared by the sorts and scans of one finish
+struct Scratch {
+  uint64_t* keys[2] = {nullptr, nullptr};
+  unsigned* pay[2] = {nullptr, nullptr};
+  unsigned* counts = nullptr;     // 256 * n_waves
+  unsigned* tile_sums = nullptr;  // scan tiles
+  unsigned long long* digit_tot = nullptr;  // [8][256]
+  unsigned* total = nullptr;      // grand total of a scan
+  int64_t n_alloc = 0, n_waves_alloc = 0, tiles_alloc = 0;
+  ~Scratch() {
+    dfree(keys[0]); dfree(keys[1]); dfree(pay[0]); dfree(pay[1]);
+    dfree(counts); dfree(tile_sums); dfree(digit_tot); dfree(total);
+  }
+};
+
+// exclusive scan of `n` uint32 (in != out allowed to alias); optional grand total copied to *host_total
+int scan_u32(mals_ingest g, Scratch& s, const unsigned* in, unsigned* out, int64_t n, unsigned* host_total) {
+  if (n <= 0) {
+    if (host_total) *host_total = 0;
+    return MALS_OK;
+  }
+  const int64_t tiles = (n + SC_TILE - 1) / SC_TILE;
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)tiles), dim3(256), 0, g->stream, in, n, out, s.tile_sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, g->stream, s.tile_sums, tiles, s.total);
+  hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)tiles), dim3(256), 0, g->stream, out, n, s.tile_sums);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += 12.0 * (double)n;
+  if (host_total) {
+    ICHK(g, hipMemcpyAsync(host_total, s.total, sizeof(unsigned), hipMemcpyDeviceToHost, g->stream));
+    ICHK(g, hipStreamSynchronize(g->stream));
+  }
+  return MALS_OK;
+}
+
+// Stable LSD radix sort of (keys[0], pay[0]) by key; *result = index of the buffer pair holding the
+// sorted data.  Digits on which all keys agree are skipped.
+int radix_sort(mals_ingest g, Scratch& s, int64_t n, int* result) {
+  *result = 0;
+  if (n <= 1) return MALS_OK;
+  ICHK(g, hipMemsetAsync(s.digit_tot, 0, 8 * 256 * sizeof(unsigned long long), g->stream));
+  hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(blocks_for(n, 256 * 16, 4096)), dim3(256), 0, g->stream, s.keys[0], n, s.digit_tot);
+  ICHK(g, hipGetLastError());
+  std::vector<unsigned long long> tot(8 * 256);
+  ICHK(g, hipMemcpyAsync(tot.data(), s.digit_tot, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream));
+  ICHK(g, hipStreamSynchronize(g->stream));
+  g->bytes_moved += 8.0 * (double)n;
+  const int64_t n_waves = (n + RS_WAVE_TILE - 1) / RS_WAVE_TILE;
+  const unsigned grid = (unsigned)((n_waves + 3) / 4);
+  int cur = 0;
+  for (int d = 0; d < 8; ++d) {
+    bool trivial = false;
+    for (int b = 0; b < 256; ++b)
+      if (tot[(size_t)d * 256 + b] == (unsigned long long)n) trivial = true;
+    if (trivial) continue;
+    hipLaunchKernelGGL(rs_histogram_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], n, 8 * d, n_waves, s.counts);
+    ICHK(g, hipGetLastError());
+    if (int rc = scan_u32(g, s, s.counts, s.counts, 256 * n_waves, nullptr)) return rc;
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], s.pay[cur], n, 8 * d, n_waves,
+                       s.counts, s.keys[1 - cur], s.pay[1 - cur]);
+    ICHK(g, hipGetLastError());
+    g->bytes_moved += (8.0 + 12.0 + 12.0) * (double)n;  // histogram read; scatter read + write
+    ++g->radix_passes;
+    cur = 1 - cur;
+  }
+  *result = cur;
+  return MALS_OK;
+}
+
+void free_results(mals_ingest g) {
+  for (int sd = 0; sd < 2; ++sd) {
+    dfree(g->ids[sd]);
+    dfree(g->ptr[sd]);
+    dfree(g->col[sd]);
+    dfree(g->val[sd]);
+  }
+  g->finished = false;
+  g->n_users = g->n_items = g->nnz = 0;
+}
+
+// dense rank (among all ids seen) of every record's id in stream order + the ascending id table
+int rank_ids(mals_ingest g, Scratch& s, const int64_t* d_ids, int64_t n, unsigned* head, unsigned* head_scan,
+             unsigned* rank_of_record, int64_t* id_table, unsigned* n_ids) {
+  hipLaunchKernelGGL(id_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, d_ids, n, s.keys[0], s.pay[0]);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += 20.0 * (double)n;
+  int r = 0;
+  if (int rc = radix_sort(g, s, n, &r)) return rc;
+  hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], n, head);
+  ICHK(g, hipGetLastError());
+  if (int rc = scan_u32(g, s, head, head_scan, n, n_ids)) return rc;
+  hipLaunchKernelGGL(scatter_ranks_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], s.pay[r], head, head_scan, n,
+                     rank_of_record, id_table);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += (12.0 + 4.0 + 20.0 + 4.0) * (double)n;
+  return MALS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mals_ingest_create(int32_t device, float zero_threshold, mals_ingest* out) {
+  if (!out) return MALS_INVALID_ARG;
+  *out = nullptr;
+  if (!(zero_threshold >= 0.f)) return MALS_INVALID_ARG;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return MALS_HIP_ERROR;
+  mals_ingest g = new (std::nothrow) mals_ingest_s();
+  if (!g) return MALS_OOM;
+  g->device = device;
+  g->zero_threshold = zero_threshold;
+  *out = g;
+  return MALS_OK;
+}
+
+int mals_ingest_destroy(mals_ingest g) {
+  if (!g) return MALS_INVALID_ARG;
+  (void)hipSetDevice(g->device);
+  (void)hipStreamSynchronize(g->stream);
+  free_results(g);
+  dfree(g->d_user);
+  dfree(g->d_item);
+  dfree(g->d_value);
+  delete g;
+  return MALS_OK;
+}
+
+const char* mals_ingest_last_error(mals_ingest g) { return g ? g->err.c_str() : "null ingest handle"; }
+
+int mals_ingest_append(mals_ingest g, int64_t n, const int64_t* user_ids, const int64_t* item_ids, const float* values,
+                       int mem_kind) {
+  if (!g) return MALS_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!user_ids || !item_ids || !values))) return fail(g, MALS_INVALID_ARG, "bad record arrays");
+  if (mem_kind != MALS_MEM_HOST && mem_kind != MALS_MEM_DEVICE) return fail(g, MALS_INVALID_ARG, "mem_kind must be MALS_MEM_HOST or MALS_MEM_DEVICE");
+  if (g->n + n >= (int64_t)0x7fffff00) return fail(g, MALS_INVALID_ARG, "at most 2^31 records per ingest");
+  if (n == 0) return MALS_OK;
+  ICHK(g, hipSetDevice(g->device));
+  if (g->finished) free_results(g);
+  if (g->n + n > g->cap) {
+    const int64_t cap = std::max<int64_t>(g->n + n, g->cap * 2);
+    int64_t *u = nullptr, *it = nullptr;
+    float* v = nullptr;
+    ICHK(g, hipMalloc(&u, sizeof(int64_t) * (size_t)cap));
+    ICHK(g, hipMalloc(&it, sizeof(int64_t) * (size_t)cap));
+    ICHK(g, hipMalloc(&v, sizeof(float) * (size_t)cap));
+    if (g->n) {
+      ICHK(g, hipMemcpyAsync(u, g->d_user, sizeof(int64_t) * (size_t)g->n, hipMemcpyDeviceToDevice, g->stream));
+      ICHK(g, hipMemcpyAsync(it, g->d_item, sizeof(int64_t) * (size_t)g->n, hipMemcpyDeviceToDevice, g->stream));
+      ICHK(g, hipMemcpyAsync(v, g->d_value, sizeof(float) * (size_t)g->n, hipMemcpyDeviceToDevice, g->stream));
+      ICHK(g, hipStreamSynchronize(g->stream));
+    }
+    dfree(g->d_user);
+    dfree(g->d_item);
+    dfree(g->d_value);
+    g->d_user = u;
+    g->d_item = it;
+    g->d_value = v;
+    g->cap = cap;
+  }
+  const hipMemcpyKind kind = mem_kind == MALS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  ICHK(g, hipMemcpyAsync(g->d_user + g->n, user_ids, sizeof(int64_t) * (size_t)n, kind, g->stream));
+  ICHK(g, hipMemcpyAsync(g->d_item + g->n, item_ids, sizeof(int64_t) * (size_t)n, kind, g->stream));
+  ICHK(g, hipMemcpyAsync(g->d_value + g->n, values, sizeof(float) * (size_t)n, kind, g->stream));
+  ICHK(g, hipStreamSynchronize(g->stream));
+  g->n += n;
+  return MALS_OK;
+}
+
+}  // extern "C"
+
+static int alloc_results(mals_ingest g, unsigned n_users, unsigned n_items, unsigned nnz) {
+  g->n_users = n_users;
+  g->n_items = n_items;
+  g->nnz = nnz;
+  const size_t nnz1 = std::max<size_t>(nnz, 1);
+  ICHK(g, hipMalloc(&g->ids[0], sizeof(int64_t) * std::max<size_t>(n_users, 1)));
+  ICHK(g, hipMalloc(&g->ids[1], sizeof(int64_t) * std::max<size_t>(n_items, 1)));
+  ICHK(g, hipMalloc(&g->ptr[0], sizeof(int64_t) * ((size_t)n_users + 1)));
+  ICHK(g, hipMalloc(&g->ptr[1], sizeof(int64_t) * ((size_t)n_items + 1)));
+  for (int sd = 0; sd < 2; ++sd) {
+    ICHK(g, hipMalloc(&g->col[sd], sizeof(int32_t) * nnz1));
+    ICHK(g, hipMalloc(&g->val[sd], sizeof(float) * nnz1));
+  }
+  return MALS_OK;
+}
+
+static int finish_impl(mals_ingest g) {
+  const int64_t n = g->n;
+  if (n == 0) {
+    if (int rc = alloc_results(g, 0, 0, 0)) return rc;
+    ICHK(g, hipMemsetAsync(g->ptr[0], 0, sizeof(int64_t), g->stream));
+    ICHK(g, hipMemsetAsync(g->ptr[1], 0, sizeof(int64_t), g->stream));
+    return MALS_OK;
+  }
+  struct Tmp {  // per-finish device temporaries
+    unsigned *head = nullptr, *scan = nullptr, *ru = nullptr, *ri = nullptr, *keep = nullptr;
+    unsigned *alive_u = nullptr, *alive_i = nullptr, *new_u = nullptr, *new_i = nullptr, *cnt_u = nullptr, *cnt_i = nullptr;
+    int64_t *uid_all = nullptr, *iid_all = nullptr;
+    float* pair_val = nullptr;
+    int32_t* coo_row = nullptr;
+    ~Tmp() {
+      dfree(head); dfree(scan); dfree(ru); dfree(ri); dfree(keep); dfree(alive_u); dfree(alive_i); dfree(new_u); dfree(new_i);
+      dfree(cnt_u); dfree(cnt_i); dfree(uid_all); dfree(iid_all); dfree(pair_val); dfree(coo_row);
+    }
+  } t;
+  Scratch s;
+  unsigned n_u_all = 0, n_i_all = 0, n_users = 0, n_items = 0, nnz = 0;
+  const int64_t n_waves = (n + RS_WAVE_TILE - 1) / RS_WAVE_TILE;
+  const int64_t scan_len = std::max<int64_t>(n, 256 * n_waves);
+  const int64_t tiles = (scan_len + SC_TILE - 1) / SC_TILE;
+  for (int b = 0; b < 2; ++b) {
+    ICHK(g, hipMalloc(&s.keys[b], sizeof(uint64_t) * (size_t)n));
+    ICHK(g, hipMalloc(&s.pay[b], sizeof(unsigned) * (size_t)n));
+  }
+  ICHK(g, hipMalloc(&s.counts, sizeof(unsigned) * (size_t)(256 * n_waves)));
+  ICHK(g, hipMalloc(&s.tile_sums, sizeof(unsigned) * (size_t)tiles));
+  ICHK(g, hipMalloc(&s.digit_tot, sizeof(unsigned long long) * 8 * 256));
+  ICHK(g, hipMalloc(&s.total, sizeof(unsigned)));
+  ICHK(g, hipMalloc(&t.head, sizeof(unsigned) * (size_t)n));
+  ICHK(g, hipMalloc(&t.scan, sizeof(unsigned) * (size_t)n));
+  ICHK(g, hipMalloc(&t.ru, sizeof(unsigned) * (size_t)n));
+  ICHK(g, hipMalloc(&t.ri, sizeof(unsigned) * (size_t)n));
+  ICHK(g, hipMalloc(&t.uid_all, sizeof(int64_t) * (size_t)n));
+  ICHK(g, hipMalloc(&t.iid_all, sizeof(int64_t) * (size_t)n));
+  // 1-2. dense ranks of the user and item ids (among all ids seen), back in stream order
+  if (int rc = rank_ids(g, s, g->d_user, n, t.head, t.scan, t.ru, t.uid_all, &n_u_all)) return rc;
+  if (int rc = rank_ids(g, s, g->d_item, n, t.head, t.scan, t.ri, t.iid_all, &n_i_all)) return rc;
+  // 3. records grouped by (user, item); the sort is stable, so stream order survives inside a group
+  hipLaunchKernelGGL(pair_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, t.ru, t.ri, n, s.keys[0], s.pay[0]);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += 20.0 * (double)n;
+  int r = 0;
+  if (int rc = radix_sort(g, s, n, &r)) return rc;
+  // 4. replay every pair's records in order
+  ICHK(g, hipMalloc(&t.keep, sizeof(unsigned) * (size_t)n));
+  ICHK(g, hipMalloc(&t.pair_val, sizeof(float) * (size_t)n));
+  ICHK(g, hipMalloc(&t.alive_u, sizeof(unsigned) * (size_t)n_u_all));
+  ICHK(g, hipMalloc(&t.alive_i, sizeof(unsigned) * (size_t)n_i_all));
+  ICHK(g, hipMalloc(&t.new_u, sizeof(unsigned) * (size_t)n_u_all));
+  ICHK(g, hipMalloc(&t.new_i, sizeof(unsigned) * (size_t)n_i_all));
+  ICHK(g, hipMemsetAsync(t.alive_u, 0, sizeof(unsigned) * (size_t)n_u_all, g->stream));
+  ICHK(g, hipMemsetAsync(t.alive_i, 0, sizeof(unsigned) * (size_t)n_i_all, g->stream));
+  hipLaunchKernelGGL(replay_pairs_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], s.pay[r], g->d_value, n,
+                     g->zero_threshold, t.keep, t.pair_val, t.alive_u, t.alive_i);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += (8.0 + 4.0 + 4.0 + 8.0) * (double)n;
+  // 5. ids that still own an entry, renumbered densely (ascending id)
+  if (int rc = scan_u32(g, s, t.alive_u, t.new_u, n_u_all, &n_users)) return rc;
+  if (int rc = scan_u32(g, s, t.alive_i, t.new_i, n_i_all, &n_items)) return rc;
+  // 6. surviving entries (|value| >= threshold): already sorted by (user, item)
+  if (int rc = scan_u32(g, s, t.keep, t.scan, n, &nnz)) return rc;
+  if (int rc = alloc_results(g, n_users, n_items, nnz)) return rc;
+  ICHK(g, hipMalloc(&t.cnt_u, sizeof(unsigned) * ((size_t)n_users + 1)));
+  ICHK(g, hipMalloc(&t.cnt_i, sizeof(unsigned) * ((size_t)n_items + 1)));
+  ICHK(g, hipMalloc(&t.coo_row, sizeof(int32_t) * std::max<size_t>(nnz, 1)));
+  ICHK(g, hipMemsetAsync(t.cnt_u, 0, sizeof(unsigned) * ((size_t)n_users + 1), g->stream));
+  ICHK(g, hipMemsetAsync(t.cnt_i, 0, sizeof(unsigned) * ((size_t)n_items + 1), g->stream));
+  hipLaunchKernelGGL(compact_ids_kernel, dim3(blocks_for(n_u_all)), dim3(256), 0, g->stream, t.uid_all, t.alive_u, t.new_u,
+                     (int64_t)n_u_all, g->ids[0]);
+  hipLaunchKernelGGL(compact_ids_kernel, dim3(blocks_for(n_i_all)), dim3(256), 0, g->stream, t.iid_all, t.alive_i, t.new_i,
+                     (int64_t)n_i_all, g->ids[1]);
+  hipLaunchKernelGGL(compact_pairs_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], t.keep, t.scan, t.pair_val, n,
+                     t.new_u, t.new_i, t.coo_row, g->col[0], g->val[0], t.cnt_u, t.cnt_i);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += 16.0 * (double)n + 12.0 * (double)nnz;
+  // row pointers = exclusive scan of the per-row counts
+  if (int rc = scan_u32(g, s, t.cnt_u, t.cnt_u, (int64_t)n_users + 1, nullptr)) return rc;
+  if (int rc = scan_u32(g, s, t.cnt_i, t.cnt_i, (int64_t)n_items + 1, nullptr)) return rc;
+  hipLaunchKernelGGL(widen_ptr_kernel, dim3(blocks_for((int64_t)n_users + 1)), dim3(256), 0, g->stream, t.cnt_u, (int64_t)n_users,
+                     (int64_t)nnz, g->ptr[0]);
+  hipLaunchKernelGGL(widen_ptr_kernel, dim3(blocks_for((int64_t)n_items + 1)), dim3(256), 0, g->stream, t.cnt_i, (int64_t)n_items,
+                     (int64_t)nnz, g->ptr[1]);
+  ICHK(g, hipGetLastError());
+  // 7. the transposed matrix: sort the surviving entries by (item, user)
+  if (nnz > 0) {
+    hipLaunchKernelGGL(transpose_keys_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, t.coo_row, g->col[0], (int64_t)nnz,
+                       s.keys[0], s.pay[0]);
+    ICHK(g, hipGetLastError());
+    g->bytes_moved += 20.0 * (double)nnz;
+    int r2 = 0;
+    if (int rc = radix_sort(g, s, (int64_t)nnz, &r2)) return rc;
+    hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], g->val[0],
+                       (int64_t)nnz, g->col[1], g->val[1]);
+    ICHK(g, hipGetLastError());
+    g->bytes_moved += 24.0 * (double)nnz;
+  }
+  ICHK(g, hipStreamSynchronize(g->stream));
+  return MALS_OK;
+}
+
+extern "C" {
+
+int mals_ingest_finish(mals_ingest g) {
+  if (!g) return MALS_INVALID_ARG;
+  ICHK(g, hipSetDevice(g->device));
+  free_results(g);
+  g->bytes_moved = 0.0;
+  g->radix_passes = 0;
+  hipEvent_t e0, e1;
+  ICHK(g, hipEventCreate(&e0));
+  ICHK(g, hipEventCreate(&e1));
+  ICHK(g, hipEventRecord(e0, g->stream));
+  const int rc = finish_impl(g);
+  if (rc != MALS_OK) {
+    free_results(g);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+  }
+  ICHK(g, hipEventRecord(e1, g->stream));
+  ICHK(g, hipEventSynchronize(e1));
+  float ms = 0.f;
+  ICHK(g, hipEventElapsedTime(&ms, e0, e1));
+  g->last_finish_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  g->finished = true;
+  return MALS_OK;
+}
+
+int mals_ingest_counts(mals_ingest g, int64_t* n_records, int64_t* n_users, int64_t* n_items, int64_t* nnz) {
+  if (!g) return MALS_INVALID_ARG;
+  if (n_records) *n_records = g->n;
+  if (!g->finished && (n_users || n_items || nnz)) return fail(g, MALS_INVALID_ARG, "mals_ingest_finish has not run");
+  if (n_users) *n_users = g->n_users;
+  if (n_items) *n_items = g->n_items;
+  if (nnz) *nnz = g->nnz;
+  return MALS_OK;
+}
+
+int mals_ingest_get_ids(mals_ingest g, int side, int64_t* host_ids_out) {
+  if (!g || !host_ids_out) return MALS_INVALID_ARG;
+  if (side != MALS_SIDE_X && side != MALS_SIDE_Y) return fail(g, MALS_INVALID_ARG, "side must be MALS_SIDE_X or _Y");
+  if (!g->finished) return fail(g, MALS_INVALID_ARG, "mals_ingest_finish has not run");
+  ICHK(g, hipSetDevice(g->device));
+  const int64_t cnt = side == MALS_SIDE_X ? g->n_users : g->n_items;
+  if (cnt) ICHK(g, hipMemcpy(host_ids_out, g->ids[side], sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+  return MALS_OK;
+}
+
+int mals_ingest_get_csr(mals_ingest g, int side, int64_t* host_row_ptr, int32_t* host_col_idx, float* host_val) {
+  if (!g) return MALS_INVALID_ARG;
+  if (side != MALS_SIDE_X && side != MALS_SIDE_Y) return fail(g, MALS_INVALID_ARG, "side must be MALS_SIDE_X or _Y");
+  if (!g->finished) return fail(g, MALS_INVALID_ARG, "mals_ingest_finish has not run");
+  ICHK(g, hipSetDevice(g->device));
+  const int64_t rows = side == MALS_SIDE_X ? g->n_users : g->n_items;
+  if (host_row_ptr) ICHK(g, hipMemcpy(host_row_ptr, g->ptr[side], sizeof(int64_t) * (size_t)(rows + 1), hipMemcpyDeviceToHost));
+  if (host_col_idx && g->nnz) ICHK(g, hipMemcpy(host_col_idx, g->col[side], sizeof(int32_t) * (size_t)g->nnz, hipMemcpyDeviceToHost));
+  if (host_val && g->nnz) ICHK(g, hipMemcpy(host_val, g->val[side], sizeof(float) * (size_t)g->nnz, hipMemcpyDeviceToHost));
+  return MALS_OK;
+}
+
+int mals_ingest_device_csr(mals_ingest g, int side, const int64_t** row_ptr, const int32_t** col_idx, const float** val) {
+  if (!g) return MALS_INVALID_ARG;
+  if (side != MALS_SIDE_X && side != MALS_SIDE_Y) return fail(g, MALS_INVALID_ARG, "side must be MALS_SIDE_X or _Y");
+  if (!g->finished) return fail(g, MALS_INVALID_ARG, "mals_ingest_finish has not run");
+  if (row_ptr) *row_ptr = g->ptr[side];
+  if (col_idx) *col_idx = g->col[side];
+  if (val) *val = g->val[side];
+  return MALS_OK;
+}
+
+int mals_ingest_install(mals_ingest g, mals_handle h) {
+  if (!g || !h) return MALS_INVALID_ARG;
+  if (!g->finished) return fail(g, MALS_INVALID_ARG, "mals_ingest_finish has not run");
+  if (int rc = mals_set_matrix(h, MALS_SIDE_X, 0, g->n_users, g->nnz, g->ptr[0], g->col[0], g->val[0], MALS_MEM_DEVICE))
+    return fail(g, rc, mals_last_error(h));
+  if (int rc = mals_set_matrix(h, MALS_SIDE_Y, 0, g->n_items, g->nnz, g->ptr[1], g->col[1], g->val[1], MALS_MEM_DEVICE))
+    return fail(g, rc, mals_last_error(h));
+  return MALS_OK;
+}
+
+int mals_ingest_stats(mals_ingest g, double* finish_ms, double* bytes_moved, int32_t* radix_passes) {
+  if (!g) return MALS_INVALID_ARG;
+  if (finish_ms) *finish_ms = g->last_finish_ms;
+  if (bytes_moved) *bytes_moved = g->bytes_moved;
+  if (radix_passes) *radix_passes = g->radix_passes;
+  return MALS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,274 @@
+// ingest_kernels.h -- hand-written gfx950 kernels of the ingest -> CSR path (SURVEY.md section 8(f)
+// row 2): what InputFilesReader.readInputFiles (online-local/.../generation/InputFilesReader.java:
+// 64-211) + MatrixUtils.addTo / remove (common/.../math/MatrixUtils.java:64-125) +
+// FastByIDFloatMap.increment (common/.../collection/FastByIDFloatMap.java:129-138) do to a stream of
+// (user, item, value | NaN) records, restated as sorts, scans and one sequential pass per pair.
+//
+// All of it is HBM-bound integer work: an LSD radix sort (8-bit digits, stable) of 64-bit keys with a
+// 32-bit payload, prefix sums, and elementwise passes.  Nothing here is shaped into a GEMM.
+//   radix pass = histogram kernel (one read of the keys) + scan of the per-wave digit counts +
+//   scatter kernel (one read of keys+payload, one scattered write).  Each wave owns a contiguous
+//   sub-tile and walks it 64 keys at a time in order; the rank of a key among the equal digits of
+//   its round comes from 8 ballots ("multi-split"), the running per-digit offsets live in a
+//   wave-private LDS array, so the scatter is stable without any atomics.
+//   Digits on which all keys agree are skipped (one preliminary histogram of all 8 digits), which
+//   is most of them for ids below 2^32 and for (row,col) keys of realistic shapes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mals {
+
+constexpr int RS_WAVE_TILE = 4096;  // keys per wave and pass (64 rounds of 64)
+constexpr int RS_BLOCK_TILE = 4 * RS_WAVE_TILE;
+
+// ---- digit statistics of all 8 digits in one read: tot[8][256] (global atomics on block sums) -------
+__global__ __launch_bounds__(256) void rs_digit_totals_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                              unsigned long long* __restrict__ tot) {
+  __shared__ unsigned h[8 * 256];
+  for (int i = threadIdx.x; i < 8 * 256; i += 256) h[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const uint64_t k = keys[i];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) atomicAdd(&h[d * 256 + (int)((k >> (8 * d)) & 255)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 256; i += 256)
+    if (h[i]) atomicAdd(&tot[i], (unsigned long long)h[i]);
+}
+
+// ---- per-wave digit histogram: counts[digit * n_waves + wave] ------------------------------------
+__global__ __launch_bounds__(256) void rs_histogram_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                           int64_t n_waves, unsigned* __restrict__ counts) {
+  __shared__ unsigned h[4][256];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w;
+  for (int i = lane; i < 256; i += 64) h[w][i] = 0;
+  // wave-private LDS rows: no barrier needed, a wave executes in lock step
+  const int64_t b = wave * RS_WAVE_TILE;
+  for (int r = 0; r < RS_WAVE_TILE / 64; ++r) {
+    const int64_t i = b + 64 * r + lane;
+    if (i < n) atomicAdd(&h[w][(int)((keys[i] >> shift) & 255)], 1u);
+  }
+  if (wave < n_waves)
+    for (int d = lane; d < 256; d += 64) counts[(int64_t)d * n_waves + wave] = h[w][d];
+}
+
+// ---- stable scatter ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
+                                                         int64_t n, int shift, int64_t n_waves,
+                                                         const unsigned* __restrict__ offsets,  // scanned counts
+                                                         uint64_t* __restrict__ keys_out, unsigned* __restrict__ pay_out) {
+  __shared__ unsigned base[4][256];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w;
+  if (wave >= n_waves) return;
+  for (int d = lane; d < 256; d += 64) base[w][d] = offsets[(int64_t)d * n_waves + wave];
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int64_t b = wave * RS_WAVE_TILE;
+  for (int r = 0; r < RS_WAVE_TILE / 64; ++r) {
+    const int64_t i = b + 64 * r + lane;
+    const bool ok = i < n;
+    const uint64_t k = ok ? keys[i] : 0;
+    const unsigned p = ok ? pay[i] : 0;
+    const int digit = (int)((k >> shift) & 255);
+    // lanes of this round with the same digit (inactive lanes match nobody)
+    uint64_t peers = __ballot(ok);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (digit >> bit) & 1;
+      const uint64_t m = __ballot(one);
+      peers &= one ? m : ~m;
+    }
+    if (ok) {
+      const unsigned rank = (unsigned)__popcll(peers & lt);
+      const unsigned pos = base[w][digit] + rank;
+      keys_out[pos] = k;
+      pay_out[pos] = p;
+      // the highest peer advances the digit's running offset; every peer has read it already
+      // (LDS operations of one wave complete in program order)
+      if ((peers >> lane) == 1ull) base[w][digit] = pos + 1;
+    }
+  }
+}
+
+// ---- exclusive scan of uint32 (three kernels; block = 256 threads x 8 items) -----------------------
+constexpr int SC_TILE = 2048;
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* total) {  // v: per-thread value
+  __shared__ unsigned ws[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned y = __shfl_up(x, off);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) ws[w] = x;
+  __syncthreads();
+  unsigned pre = 0;
+  for (int i = 0; i < w; ++i) pre += ws[i];
+  if (total) *total = ws[0] + ws[1] + ws[2] + ws[3];
+  __syncthreads();
+  return pre + x - v;
+}
+__global__ __launch_bounds__(256) void scan_tiles_kernel(const unsigned* __restrict__ in, int64_t n, unsigned* __restrict__ out,
+                                                         unsigned* __restrict__ tile_sums) {
+  const int64_t b = (int64_t)blockIdx.x * SC_TILE + threadIdx.x * 8;
+  unsigned v[8], s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = b + i < n ? in[b + i] : 0;
+    s += v[i];
+  }
+  unsigned total;
+  unsigned pre = block_exclusive_scan(s, &total);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (b + i < n) out[b + i] = pre;
+    pre += v[i];
+  }
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+// one block scans the tile sums in place (exclusive), carrying across chunks of 2048
+__global__ __launch_bounds__(256) void scan_sums_kernel(unsigned* __restrict__ sums, int64_t n_tiles, unsigned* __restrict__ grand_total) {
+  unsigned carry = 0;
+  for (int64_t b0 = 0; b0 < n_tiles; b0 += SC_TILE) {
+    const int64_t b = b0 + threadIdx.x * 8;
+    unsigned v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = b + i < n_tiles ? sums[b + i] : 0;
+      s += v[i];
+    }
+    unsigned total;
+    unsigned pre = carry + block_exclusive_scan(s, &total);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (b + i < n_tiles) sums[b + i] = pre;
+      pre += v[i];
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0 && grand_total) *grand_total = carry;
+}
+__global__ __launch_bounds__(256) void scan_add_kernel(unsigned* __restrict__ out, int64_t n, const unsigned* __restrict__ tile_offsets) {
+  const int64_t b = (int64_t)blockIdx.x * SC_TILE + threadIdx.x * 8;
+  const unsigned o = tile_offsets[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (b + i < n) out[b + i] += o;
+}
+
+// ---- elementwise passes ------------------------------------------------------------------------------
+#define MALS_GRID_STRIDE(i, n) \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// signed 64-bit id -> radix key with the same order
+__device__ __host__ __forceinline__ uint64_t id_to_key(int64_t id) { return (uint64_t)id ^ 0x8000000000000000ull; }
+__device__ __host__ __forceinline__ int64_t key_to_id(uint64_t k) { return (int64_t)(k ^ 0x8000000000000000ull); }
+
+__global__ void id_keys_kernel(const int64_t* __restrict__ ids, int64_t n, uint64_t* __restrict__ keys, unsigned* __restrict__ pay) {
+  MALS_GRID_STRIDE(i, n) {
+    keys[i] = id_to_key(ids[i]);
+    pay[i] = (unsigned)i;
+  }
+}
+// head[i] = 1 where a new key starts in a sorted key array
+__global__ void heads_kernel(const uint64_t* __restrict__ keys, int64_t n, unsigned* __restrict__ head) {
+  MALS_GRID_STRIDE(i, n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// rank of every record's id (dense index among all ids seen) back in stream order + the id table
+__global__ void scatter_ranks_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
+                                     const unsigned* __restrict__ head, const unsigned* __restrict__ head_scan, int64_t n,
+                                     unsigned* __restrict__ rank_of_record, int64_t* __restrict__ id_table) {
+  MALS_GRID_STRIDE(i, n) {
+    const unsigned r = head_scan[i] + head[i] - 1;  // inclusive scan - 1
+    rank_of_record[pay[i]] = r;
+    if (head[i]) id_table[r] = key_to_id(keys[i]);
+  }
+}
+__global__ void pair_keys_kernel(const unsigned* __restrict__ ru, const unsigned* __restrict__ ri, int64_t n,
+                                 uint64_t* __restrict__ keys, unsigned* __restrict__ pay) {
+  MALS_GRID_STRIDE(i, n) {
+    keys[i] = ((uint64_t)ru[i] << 32) | ri[i];
+    pay[i] = (unsigned)i;
+  }
+}
+// One thread per (user,item) pair = per run of equal keys in the stably sorted record array: replays
+// the pair's records in stream order exactly as the reference does (IFR:165-171): NaN removes the
+// entry (MU:102-125), a value starts it or is added to it in fp32 (FBIFM:129-138).  Marks the ids
+// that own a live entry (MU:81-92: a row exists while it has entries).
+__global__ void replay_pairs_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
+                                    const float* __restrict__ values, int64_t n, float zero_threshold,
+                                    unsigned* __restrict__ keep, float* __restrict__ pair_val,
+                                    unsigned* __restrict__ user_alive, unsigned* __restrict__ item_alive) {
+  MALS_GRID_STRIDE(i, n) {
+    keep[i] = 0;
+    const uint64_t k = keys[i];
+    if (i != 0 && keys[i - 1] == k) continue;  // not the head of its run
+    bool present = false;
+    float v = 0.f;
+    for (int64_t t = i; t < n && keys[t] == k; ++t) {
+      const float x = values[pay[t]];
+      if (x != x) {
+        present = false;
+      } else if (!present) {
+        present = true;
+        v = x;
+      } else {
+        v = v + x;
+      }
+    }
+    if (present) {
+      user_alive[(unsigned)(k >> 32)] = 1u;
+      item_alive[(unsigned)(k & 0xffffffffu)] = 1u;
+      pair_val[i] = v;
+      keep[i] = (fabsf(v) < zero_threshold) ? 0u : 1u;  // removeSmall, IFR:200-211 (NaN sums are kept, like there)
+    }
+  }
+}
+// compact the existing ids: new dense index = exclusive scan of alive
+__global__ void compact_ids_kernel(const int64_t* __restrict__ id_table, const unsigned* __restrict__ alive,
+                                   const unsigned* __restrict__ alive_scan, int64_t n_ids, int64_t* __restrict__ ids_out) {
+  MALS_GRID_STRIDE(i, n_ids)
+    if (alive[i]) ids_out[alive_scan[i]] = id_table[i];
+}
+// compact the kept pairs into COO sorted by (row, col); count entries per row
+__global__ void compact_pairs_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ keep,
+                                     const unsigned* __restrict__ keep_scan, const float* __restrict__ pair_val, int64_t n,
+                                     const unsigned* __restrict__ new_u, const unsigned* __restrict__ new_i,
+                                     int32_t* __restrict__ row, int32_t* __restrict__ col, float* __restrict__ val,
+                                     unsigned* __restrict__ row_count, unsigned* __restrict__ col_count) {
+  MALS_GRID_STRIDE(i, n) {
+    if (!keep[i]) continue;
+    const unsigned p = keep_scan[i];
+    const unsigned r = new_u[(unsigned)(keys[i] >> 32)], c = new_i[(unsigned)(keys[i] & 0xffffffffu)];
+    row[p] = (int32_t)r;
+    col[p] = (int32_t)c;
+    val[p] = pair_val[i];
+    atomicAdd(&row_count[r], 1u);
+    atomicAdd(&col_count[c], 1u);
+  }
+}
+__global__ void transpose_keys_kernel(const int32_t* __restrict__ row, const int32_t* __restrict__ col, int64_t nnz,
+                                      uint64_t* __restrict__ keys, unsigned* __restrict__ pay) {
+  MALS_GRID_STRIDE(i, nnz) {
+    keys[i] = ((uint64_t)(uint32_t)col[i] << 32) | (uint32_t)row[i];
+    pay[i] = (unsigned)i;
+  }
+}
+__global__ void transpose_gather_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
+                                        const float* __restrict__ val, int64_t nnz, int32_t* __restrict__ t_col,
+                                        float* __restrict__ t_val) {
+  MALS_GRID_STRIDE(i, nnz) {
+    t_col[i] = (int32_t)(keys[i] & 0xffffffffu);  // the user index
+    t_val[i] = val[pay[i]];
+  }
+}
+__global__ void widen_ptr_kernel(const unsigned* __restrict__ scan, int64_t n_rows, int64_t nnz, int64_t* __restrict__ ptr) {
+  MALS_GRID_STRIDE(i, n_rows + 1) ptr[i] = i < n_rows ? (int64_t)scan[i] : nnz;
+}
+
+}  // namespace mals
