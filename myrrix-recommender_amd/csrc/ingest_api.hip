@@ -260,13 +260,13 @@ static int finish_impl(mals_ingest g) {
   }
   struct Tmp {  // per-finish device temporaries
     unsigned *head = nullptr, *scan = nullptr, *ru = nullptr, *ri = nullptr, *keep = nullptr;
-    unsigned *alive_u = nullptr, *alive_i = nullptr, *new_u = nullptr, *new_i = nullptr, *cnt_u = nullptr, *cnt_i = nullptr;
+    unsigned *alive_u = nullptr, *alive_i = nullptr, *new_u = nullptr, *new_i = nullptr;
     int64_t *uid_all = nullptr, *iid_all = nullptr;
     float* pair_val = nullptr;
     int32_t* coo_row = nullptr;
     ~Tmp() {
       dfree(head); dfree(scan); dfree(ru); dfree(ri); dfree(keep); dfree(alive_u); dfree(alive_i); dfree(new_u); dfree(new_i);
-      dfree(cnt_u); dfree(cnt_i); dfree(uid_all); dfree(iid_all); dfree(pair_val); dfree(coo_row);
+      dfree(uid_all); dfree(iid_all); dfree(pair_val); dfree(coo_row);
     }
   } t;
   Scratch s;
@@ -316,27 +316,17 @@ static int finish_impl(mals_ingest g) {
   // 6. surviving entries (|value| >= threshold): already sorted by (user, item)
   if (int rc = scan_u32(g, s, t.keep, t.scan, n, &nnz)) return rc;
   if (int rc = alloc_results(g, n_users, n_items, nnz)) return rc;
-  ICHK(g, hipMalloc(&t.cnt_u, sizeof(unsigned) * ((size_t)n_users + 1)));
-  ICHK(g, hipMalloc(&t.cnt_i, sizeof(unsigned) * ((size_t)n_items + 1)));
   ICHK(g, hipMalloc(&t.coo_row, sizeof(int32_t) * std::max<size_t>(nnz, 1)));
-  ICHK(g, hipMemsetAsync(t.cnt_u, 0, sizeof(unsigned) * ((size_t)n_users + 1), g->stream));
-  ICHK(g, hipMemsetAsync(t.cnt_i, 0, sizeof(unsigned) * ((size_t)n_items + 1), g->stream));
   hipLaunchKernelGGL(compact_ids_kernel, dim3(blocks_for(n_u_all)), dim3(256), 0, g->stream, t.uid_all, t.alive_u, t.new_u,
                      (int64_t)n_u_all, g->ids[0]);
   hipLaunchKernelGGL(compact_ids_kernel, dim3(blocks_for(n_i_all)), dim3(256), 0, g->stream, t.iid_all, t.alive_i, t.new_i,
                      (int64_t)n_i_all, g->ids[1]);
   hipLaunchKernelGGL(compact_pairs_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], t.keep, t.scan, t.pair_val, n,
-                     t.new_u, t.new_i, t.coo_row, g->col[0], g->val[0], t.cnt_u, t.cnt_i);
+                     t.new_u, t.new_i, t.coo_row, g->col[0], g->val[0]);
+  hipLaunchKernelGGL(row_ptr_from_sorted_kernel, dim3(blocks_for((int64_t)nnz + 1)), dim3(256), 0, g->stream, t.coo_row, (int64_t)nnz,
+                     (int64_t)n_users, g->ptr[0]);
   ICHK(g, hipGetLastError());
-  g->bytes_moved += 16.0 * (double)n + 12.0 * (double)nnz;
-  // row pointers = exclusive scan of the per-row counts
-  if (int rc = scan_u32(g, s, t.cnt_u, t.cnt_u, (int64_t)n_users + 1, nullptr)) return rc;
-  if (int rc = scan_u32(g, s, t.cnt_i, t.cnt_i, (int64_t)n_items + 1, nullptr)) return rc;
-  hipLaunchKernelGGL(widen_ptr_kernel, dim3(blocks_for((int64_t)n_users + 1)), dim3(256), 0, g->stream, t.cnt_u, (int64_t)n_users,
-                     (int64_t)nnz, g->ptr[0]);
-  hipLaunchKernelGGL(widen_ptr_kernel, dim3(blocks_for((int64_t)n_items + 1)), dim3(256), 0, g->stream, t.cnt_i, (int64_t)n_items,
-                     (int64_t)nnz, g->ptr[1]);
-  ICHK(g, hipGetLastError());
+  g->bytes_moved += 16.0 * (double)n + 16.0 * (double)nnz + 8.0 * (double)n_users;
   // 7. the transposed matrix: sort the surviving entries by (item, user)
   if (nnz > 0) {
     hipLaunchKernelGGL(transpose_keys_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, t.coo_row, g->col[0], (int64_t)nnz,
@@ -346,10 +336,14 @@ static int finish_impl(mals_ingest g) {
     int r2 = 0;
     if (int rc = radix_sort(g, s, (int64_t)nnz, &r2)) return rc;
     hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], g->val[0],
-                       (int64_t)nnz, g->col[1], g->val[1]);
+                       (int64_t)nnz, t.coo_row, g->col[1], g->val[1]);
     ICHK(g, hipGetLastError());
-    g->bytes_moved += 24.0 * (double)nnz;
+    g->bytes_moved += 28.0 * (double)nnz;
   }
+  hipLaunchKernelGGL(row_ptr_from_sorted_kernel, dim3(blocks_for((int64_t)nnz + 1)), dim3(256), 0, g->stream, t.coo_row, (int64_t)nnz,
+                     (int64_t)n_items, g->ptr[1]);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += 4.0 * (double)nnz + 8.0 * (double)n_items;
   ICHK(g, hipStreamSynchronize(g->stream));
   return MALS_OK;
 }

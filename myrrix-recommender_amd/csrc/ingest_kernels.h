@@ -29,10 +29,25 @@ __global__ __launch_bounds__(256) void rs_digit_totals_kernel(const uint64_t* __
   for (int i = threadIdx.x; i < 8 * 256; i += 256) h[i] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const uint64_t k = keys[i];
+  const int lane = threadIdx.x & 63;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += stride) {  // whole waves stay in the loop together
+    const int64_t i = i0 + threadIdx.x;
+    const bool ok = i < n;
+    const uint64_t k = ok ? keys[i] : 0;
+    const uint64_t active = __ballot(ok);
+    if (!active) continue;
+    const int leader = __ffsll((unsigned long long)active) - 1;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) atomicAdd(&h[d * 256 + (int)((k >> (8 * d)) & 255)], 1u);
+    for (int d = 0; d < 8; ++d) {
+      const int digit = (int)((k >> (8 * d)) & 255);
+      // the high digits of real ids agree across a wave almost always: one LDS atomic instead of 64
+      const int first = __builtin_amdgcn_readlane(digit, leader);
+      if (__ballot(ok && digit != first) == 0) {
+        if (lane == leader) atomicAdd(&h[d * 256 + first], (unsigned)__popcll(active));
+      } else if (ok) {
+        atomicAdd(&h[d * 256 + digit], 1u);
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 8 * 256; i += 256)
@@ -239,17 +254,23 @@ __global__ void compact_ids_kernel(const int64_t* __restrict__ id_table, const u
 __global__ void compact_pairs_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ keep,
                                      const unsigned* __restrict__ keep_scan, const float* __restrict__ pair_val, int64_t n,
                                      const unsigned* __restrict__ new_u, const unsigned* __restrict__ new_i,
-                                     int32_t* __restrict__ row, int32_t* __restrict__ col, float* __restrict__ val,
-                                     unsigned* __restrict__ row_count, unsigned* __restrict__ col_count) {
+                                     int32_t* __restrict__ row, int32_t* __restrict__ col, float* __restrict__ val) {
   MALS_GRID_STRIDE(i, n) {
     if (!keep[i]) continue;
     const unsigned p = keep_scan[i];
-    const unsigned r = new_u[(unsigned)(keys[i] >> 32)], c = new_i[(unsigned)(keys[i] & 0xffffffffu)];
-    row[p] = (int32_t)r;
-    col[p] = (int32_t)c;
+    row[p] = (int32_t)new_u[(unsigned)(keys[i] >> 32)];
+    col[p] = (int32_t)new_i[(unsigned)(keys[i] & 0xffffffffu)];
     val[p] = pair_val[i];
-    atomicAdd(&row_count[r], 1u);
-    atomicAdd(&col_count[c], 1u);
+  }
+}
+// Row pointers of a COO array sorted by row (rows without entries included): entry p opens every row
+// in (row[p-1], row[p]]; the rows after the last entry point at nnz.  No atomics: a popular item
+// would serialise millions of them on one counter.
+__global__ void row_ptr_from_sorted_kernel(const int32_t* __restrict__ row, int64_t nnz, int64_t n_rows, int64_t* __restrict__ ptr) {
+  MALS_GRID_STRIDE(p, nnz + 1) {
+    const int64_t lo = p == 0 ? 0 : (int64_t)row[p - 1] + 1;
+    const int64_t hi = p == nnz ? n_rows : (int64_t)row[p];
+    for (int64_t r = lo; r <= hi; ++r) ptr[r] = p;
   }
 }
 __global__ void transpose_keys_kernel(const int32_t* __restrict__ row, const int32_t* __restrict__ col, int64_t nnz,
@@ -260,15 +281,13 @@ __global__ void transpose_keys_kernel(const int32_t* __restrict__ row, const int
   }
 }
 __global__ void transpose_gather_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
-                                        const float* __restrict__ val, int64_t nnz, int32_t* __restrict__ t_col,
-                                        float* __restrict__ t_val) {
+                                        const float* __restrict__ val, int64_t nnz, int32_t* __restrict__ t_row,
+                                        int32_t* __restrict__ t_col, float* __restrict__ t_val) {
   MALS_GRID_STRIDE(i, nnz) {
+    t_row[i] = (int32_t)(keys[i] >> 32);          // the item index
     t_col[i] = (int32_t)(keys[i] & 0xffffffffu);  // the user index
     t_val[i] = val[pay[i]];
   }
-}
-__global__ void widen_ptr_kernel(const unsigned* __restrict__ scan, int64_t n_rows, int64_t nnz, int64_t* __restrict__ ptr) {
-  MALS_GRID_STRIDE(i, n_rows + 1) ptr[i] = i < n_rows ? (int64_t)scan[i] : nnz;
 }
 
 }  // namespace mals
