@@ -68,7 +68,7 @@ unsigned blocks_for(int64_t n, int per_block = 256, int64_t cap = 1 << 20) {
 struct Scratch {
   uint64_t* keys[2] = {nullptr, nullptr};
   unsigned* pay[2] = {nullptr, nullptr};
-  unsigned* counts = nullptr;     // 256 * n_waves
+  unsigned* counts = nullptr;     // 256 * n_blocks
   unsigned* tile_sums = nullptr;  // scan tiles
   unsigned long long* digit_tot = nullptr;  // [8][256]
   unsigned* total = nullptr;      // grand total of a scan
@@ -110,18 +110,18 @@ int radix_sort(mals_ingest g, Scratch& s, int64_t n, int* result) {
   ICHK(g, hipMemcpyAsync(tot.data(), s.digit_tot, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream));
   ICHK(g, hipStreamSynchronize(g->stream));
   g->bytes_moved += 8.0 * (double)n;
-  const int64_t n_waves = (n + RS_WAVE_TILE - 1) / RS_WAVE_TILE;
-  const unsigned grid = (unsigned)((n_waves + 3) / 4);
+  const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
+  const unsigned grid = (unsigned)n_blocks;
   int cur = 0;
   for (int d = 0; d < 8; ++d) {
     bool trivial = false;
     for (int b = 0; b < 256; ++b)
       if (tot[(size_t)d * 256 + b] == (unsigned long long)n) trivial = true;
     if (trivial) continue;
-    hipLaunchKernelGGL(rs_histogram_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], n, 8 * d, n_waves, s.counts);
+    hipLaunchKernelGGL(rs_histogram_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], n, 8 * d, n_blocks, s.counts);
     ICHK(g, hipGetLastError());
-    if (int rc = scan_u32(g, s, s.counts, s.counts, 256 * n_waves, nullptr)) return rc;
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], s.pay[cur], n, 8 * d, n_waves,
+    if (int rc = scan_u32(g, s, s.counts, s.counts, 256 * n_blocks, nullptr)) return rc;
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], s.pay[cur], n, 8 * d, n_blocks,
                        s.counts, s.keys[1 - cur], s.pay[1 - cur]);
     ICHK(g, hipGetLastError());
     g->bytes_moved += (8.0 + 12.0 + 12.0) * (double)n;  // histogram read; scatter read + write
@@ -271,14 +271,14 @@ static int finish_impl(mals_ingest g) {
   } t;
   Scratch s;
   unsigned n_u_all = 0, n_i_all = 0, n_users = 0, n_items = 0, nnz = 0;
-  const int64_t n_waves = (n + RS_WAVE_TILE - 1) / RS_WAVE_TILE;
-  const int64_t scan_len = std::max<int64_t>(n, 256 * n_waves);
+  const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
+  const int64_t scan_len = std::max<int64_t>(n, 256 * n_blocks);
   const int64_t tiles = (scan_len + SC_TILE - 1) / SC_TILE;
   for (int b = 0; b < 2; ++b) {
     ICHK(g, hipMalloc(&s.keys[b], sizeof(uint64_t) * (size_t)n));
     ICHK(g, hipMalloc(&s.pay[b], sizeof(unsigned) * (size_t)n));
   }
-  ICHK(g, hipMalloc(&s.counts, sizeof(unsigned) * (size_t)(256 * n_waves)));
+  ICHK(g, hipMalloc(&s.counts, sizeof(unsigned) * (size_t)(256 * n_blocks)));
   ICHK(g, hipMalloc(&s.tile_sums, sizeof(unsigned) * (size_t)tiles));
   ICHK(g, hipMalloc(&s.digit_tot, sizeof(unsigned long long) * 8 * 256));
   ICHK(g, hipMalloc(&s.total, sizeof(unsigned)));

@@ -19,8 +19,25 @@
 
 namespace mals {
 
-constexpr int RS_WAVE_TILE = 4096;  // keys per wave and pass (64 rounds of 64)
+constexpr int RS_WAVE_TILE = 1024;  // keys per wave and pass (16 rounds of 64)
 constexpr int RS_BLOCK_TILE = 4 * RS_WAVE_TILE;
+
+// exclusive scan of one value per thread over a 256-thread workgroup
+__device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v) {
+  __shared__ unsigned wsum[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned y = __shfl_up(x, off);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();
+  unsigned pre = 0;
+  for (int i = 0; i < w; ++i) pre += wsum[i];
+  return pre + x - v;
+}
 
 // ---- digit statistics of all 8 digits in one read: tot[8][256] (global atomics on block sums) -------
 __global__ __launch_bounds__(256) void rs_digit_totals_kernel(const uint64_t* __restrict__ keys, int64_t n,
@@ -54,43 +71,59 @@ __global__ __launch_bounds__(256) void rs_digit_totals_kernel(const uint64_t* __
     if (h[i]) atomicAdd(&tot[i], (unsigned long long)h[i]);
 }
 
-// ---- per-wave digit histogram: counts[digit * n_waves + wave] ------------------------------------
+// ---- per-block digit histogram: counts[digit * n_blocks + block] ---------------------------------
 __global__ __launch_bounds__(256) void rs_histogram_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
-                                                           int64_t n_waves, unsigned* __restrict__ counts) {
+                                                           int64_t n_blocks, unsigned* __restrict__ counts) {
   __shared__ unsigned h[4][256];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + w;
   for (int i = lane; i < 256; i += 64) h[w][i] = 0;
-  // wave-private LDS rows: no barrier needed, a wave executes in lock step
-  const int64_t b = wave * RS_WAVE_TILE;
+  // wave-private LDS rows while counting: no barrier needed, a wave executes in lock step
+  const int64_t b = (int64_t)blockIdx.x * RS_BLOCK_TILE + w * RS_WAVE_TILE;
   for (int r = 0; r < RS_WAVE_TILE / 64; ++r) {
     const int64_t i = b + 64 * r + lane;
     if (i < n) atomicAdd(&h[w][(int)((keys[i] >> shift) & 255)], 1u);
   }
-  if (wave < n_waves)
-    for (int d = lane; d < 256; d += 64) counts[(int64_t)d * n_waves + wave] = h[w][d];
+  __syncthreads();
+  const int d = threadIdx.x;
+  counts[(int64_t)d * n_blocks + blockIdx.x] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
 }
 
 // ---- stable scatter ------------------------------------------------------------------------------
+// A workgroup owns RS_BLOCK_TILE consecutive keys (wave w the w-th quarter, walked 64 at a time in
+// order).  Pass 1 ranks every key among the equal digits of its wave (8 ballots per round + a
+// wave-private running count); the four waves' counts give each digit a contiguous segment of the
+// tile; pass 2 moves the tile into LDS in digit order; pass 3 streams it out: consecutive LDS slots of
+// a digit go to consecutive global addresses, so the writes are runs of ~RS_BLOCK_TILE/256 keys
+// instead of isolated 8-byte stores that HBM would turn into read-modify-writes of whole lines.
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
-                                                         int64_t n, int shift, int64_t n_waves,
+                                                         int64_t n, int shift, int64_t n_blocks,
                                                          const unsigned* __restrict__ offsets,  // scanned counts
                                                          uint64_t* __restrict__ keys_out, unsigned* __restrict__ pay_out) {
-  __shared__ unsigned base[4][256];
+  constexpr int ROUNDS = RS_WAVE_TILE / 64;
+  __shared__ uint64_t skey[RS_BLOCK_TILE];
+  __shared__ unsigned spay[RS_BLOCK_TILE];
+  __shared__ unsigned cnt[4][256];   // per-wave digit counts, then per-wave offsets inside the digit's segment
+  __shared__ unsigned seg[256];      // start of the digit's segment in the tile
+  __shared__ unsigned gbase[256];    // global position of the segment's first key
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + w;
-  if (wave >= n_waves) return;
-  for (int d = lane; d < 256; d += 64) base[w][d] = offsets[(int64_t)d * n_waves + wave];
+  for (int i = lane; i < 256; i += 64) cnt[w][i] = 0;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  const int64_t b = wave * RS_WAVE_TILE;
-  for (int r = 0; r < RS_WAVE_TILE / 64; ++r) {
+  const int64_t b = (int64_t)blockIdx.x * RS_BLOCK_TILE + w * RS_WAVE_TILE;
+  uint64_t k[ROUNDS];
+  unsigned p[ROUNDS];
+  unsigned short lrank[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
     const int64_t i = b + 64 * r + lane;
     const bool ok = i < n;
-    const uint64_t k = ok ? keys[i] : 0;
-    const unsigned p = ok ? pay[i] : 0;
-    const int digit = (int)((k >> shift) & 255);
-    // lanes of this round with the same digit (inactive lanes match nobody)
-    uint64_t peers = __ballot(ok);
+    k[r] = ok ? keys[i] : ~0ull;
+    p[r] = ok ? pay[i] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const bool ok = b + 64 * r + lane < n;
+    const int digit = (int)((k[r] >> shift) & 255);
+    uint64_t peers = __ballot(ok);  // lanes of this round with the same digit (inactive lanes match nobody)
 #pragma unroll
     for (int bit = 0; bit < 8; ++bit) {
       const bool one = (digit >> bit) & 1;
@@ -98,14 +131,43 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t* __restr
       peers &= one ? m : ~m;
     }
     if (ok) {
-      const unsigned rank = (unsigned)__popcll(peers & lt);
-      const unsigned pos = base[w][digit] + rank;
-      keys_out[pos] = k;
-      pay_out[pos] = p;
-      // the highest peer advances the digit's running offset; every peer has read it already
-      // (LDS operations of one wave complete in program order)
-      if ((peers >> lane) == 1ull) base[w][digit] = pos + 1;
+      const unsigned pos = cnt[w][digit] + (unsigned)__popcll(peers & lt);
+      lrank[r] = (unsigned short)pos;
+      // the highest peer advances the digit's running count; every peer has read it already (LDS
+      // operations of one wave complete in program order)
+      if ((peers >> lane) == 1ull) cnt[w][digit] = pos + 1;
     }
+  }
+  __syncthreads();
+  {  // segment starts: exclusive scan over the 256 digit totals (one digit per thread)
+    const int d = threadIdx.x;
+    const unsigned c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+    const unsigned start = block_exclusive_scan_256(c0 + c1 + c2 + c3);
+    seg[d] = start;
+    gbase[d] = offsets[(int64_t)d * n_blocks + blockIdx.x];
+    cnt[0][d] = start;  // becomes: position of wave w's first key of digit d in the tile
+    cnt[1][d] = start + c0;
+    cnt[2][d] = start + c0 + c1;
+    cnt[3][d] = start + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    if (b + 64 * r + lane < n) {
+      const int digit = (int)((k[r] >> shift) & 255);
+      const unsigned q = cnt[w][digit] + lrank[r];
+      skey[q] = k[r];
+      spay[q] = p[r];
+    }
+  }
+  __syncthreads();
+  const int64_t tile_n = n - (int64_t)blockIdx.x * RS_BLOCK_TILE < RS_BLOCK_TILE ? n - (int64_t)blockIdx.x * RS_BLOCK_TILE : RS_BLOCK_TILE;
+  for (int q = threadIdx.x; q < tile_n; q += 256) {
+    const uint64_t kk = skey[q];
+    const int digit = (int)((kk >> shift) & 255);
+    const unsigned pos = gbase[digit] + ((unsigned)q - seg[digit]);
+    keys_out[pos] = kk;
+    pay_out[pos] = spay[q];
   }
 }
 
