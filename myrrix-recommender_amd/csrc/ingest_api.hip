@@ -98,9 +98,9 @@ int scan_u32(mals_ingest g, Scratch& s, const unsigned* in, unsigned* out, int64
   return MALS_OK;
 }
 
-// Stable LSD radix sort of (keys[0], pay[0]) by key; *result = index of the buffer pair holding the
-// sorted data.  Digits on which all keys agree are skipped.
-int radix_sort(mals_ingest g, Scratch& s, int64_t n, int* result) {
+// Stable LSD radix sort of (keys[0], pay[0]) by the key digits >= first_digit; *result = index of the
+// buffer pair holding the sorted data.  Digits on which all keys agree are skipped.
+int radix_sort(mals_ingest g, Scratch& s, int64_t n, int* result, int first_digit = 0) {
   *result = 0;
   if (n <= 1) return MALS_OK;
   ICHK(g, hipMemsetAsync(s.digit_tot, 0, 8 * 256 * sizeof(unsigned long long), g->stream));
@@ -113,7 +113,7 @@ int radix_sort(mals_ingest g, Scratch& s, int64_t n, int* result) {
   const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
   const unsigned grid = (unsigned)n_blocks;
   int cur = 0;
-  for (int d = 0; d < 8; ++d) {
+  for (int d = first_digit; d < 8; ++d) {
     bool trivial = false;
     for (int b = 0; b < 256; ++b)
       if (tot[(size_t)d * 256 + b] == (unsigned long long)n) trivial = true;
@@ -327,14 +327,15 @@ static int finish_impl(mals_ingest g) {
                      (int64_t)n_users, g->ptr[0]);
   ICHK(g, hipGetLastError());
   g->bytes_moved += 16.0 * (double)n + 16.0 * (double)nnz + 8.0 * (double)n_users;
-  // 7. the transposed matrix: sort the surviving entries by (item, user)
+  // 7. the transposed matrix: the entries are sorted by (user, item); a STABLE sort on the item half of
+  //    the key alone leaves the users ascending inside every item, so the four low digits are not sorted
   if (nnz > 0) {
     hipLaunchKernelGGL(transpose_keys_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, t.coo_row, g->col[0], (int64_t)nnz,
                        s.keys[0], s.pay[0]);
     ICHK(g, hipGetLastError());
     g->bytes_moved += 20.0 * (double)nnz;
     int r2 = 0;
-    if (int rc = radix_sort(g, s, (int64_t)nnz, &r2)) return rc;
+    if (int rc = radix_sort(g, s, (int64_t)nnz, &r2, 4)) return rc;
     hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], g->val[0],
                        (int64_t)nnz, t.coo_row, g->col[1], g->val[1]);
     ICHK(g, hipGetLastError());
