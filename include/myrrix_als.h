@@ -266,8 +266,10 @@ int mals_ingest_device_csr(mals_ingest g, int side, const int64_t** row_ptr, con
 /* mals_set_matrix(MALS_MEM_DEVICE) of both sides into a factorizer handle on the same device; the
  * handle borrows the arrays, so the ingest object must outlive their use. */
 int mals_ingest_install(mals_ingest g, mals_handle h);
-/* last finish: HIP-event milliseconds, algorithmic bytes read+written by all passes, radix passes run */
-int mals_ingest_stats(mals_ingest g, double* finish_ms, double* bytes_moved, int32_t* radix_passes);
+/* last finish: HIP-event milliseconds of the pipeline, host milliseconds spent (re)allocating its
+ * workspace (52 bytes per record, kept for later finishes; hipMalloc of tens of GB is slow), algorithmic
+ * bytes read+written by all passes, radix passes run */
+int mals_ingest_stats(mals_ingest g, double* finish_ms, double* workspace_ms, double* bytes_moved, int32_t* radix_passes);
 
 int mals_enable_timing(mals_handle h, int32_t on);
 int mals_reset_stats(mals_handle h);

@@ -91,7 +91,8 @@ SYMBOLS = {
     "mals_ingest_get_csr": (ctypes.c_int, [_H, ctypes.c_int, _P, _P, _P]),
     "mals_ingest_device_csr": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_P)]),
     "mals_ingest_install": (ctypes.c_int, [_H, _H]),
-    "mals_ingest_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I32)]),
+    "mals_ingest_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I32)]),
     "mals_enable_timing": (ctypes.c_int, [_H, _I32]),
     "mals_reset_stats": (ctypes.c_int, [_H]),
     "mals_get_stats": (ctypes.c_int, [_H, ctypes.POINTER(Stats)]),

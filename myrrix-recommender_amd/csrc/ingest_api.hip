@@ -7,8 +7,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -33,6 +35,13 @@ struct mals_ingest_s {
   int64_t* ptr[2] = {nullptr, nullptr};      // CSR row pointers (side X: by user, side Y: by item)
   int32_t* col[2] = {nullptr, nullptr};
   float* val[2] = {nullptr, nullptr};
+  // sort/scan workspace, kept between finishes (hipMalloc of tens of GB is slow).  One allocation per
+  // buffer: a single 52 GB arena was measured 2.6x slower to WORK in than ten separate buffers (the
+  // driver backs huge allocations with smaller fragments once memory has been recycled).
+  static constexpr int N_WS = 12;
+  void* ws[N_WS] = {};
+  size_t ws_bytes[N_WS] = {};
+  double last_workspace_ms = 0.0;  // host time spent (re)allocating the workspace in the last finish
   double last_finish_ms = 0.0;
   double bytes_moved = 0.0;  // algorithmic bytes of the last finish (reads + writes of every pass)
   int radix_passes = 0;
@@ -68,15 +77,13 @@ unsigned blocks_for(int64_t n, int per_block = 256, int64_t cap = 1 << 20) {
 struct Scratch {
   uint64_t* keys[2] = {nullptr, nullptr};
   unsigned* pay[2] = {nullptr, nullptr};
+  uint64_t* pay64[2] = {nullptr, nullptr};
   unsigned* counts = nullptr;     // 256 * n_blocks
   unsigned* tile_sums = nullptr;  // scan tiles
   unsigned long long* digit_tot = nullptr;  // [8][256]
   unsigned* total = nullptr;      // grand total of a scan
   int64_t n_alloc = 0, n_waves_alloc = 0, tiles_alloc = 0;
-  ~Scratch() {
-    dfree(keys[0]); dfree(keys[1]); dfree(pay[0]); dfree(pay[1]);
-    dfree(counts); dfree(tile_sums); dfree(digit_tot); dfree(total);
-  }
+  // all of it is carved out of the ingest object's arena
 };
 
 // exclusive scan of `n` uint32 (in != out allowed to alias); optional grand total copied to *host_total
@@ -100,7 +107,8 @@ int scan_u32(mals_ingest g, Scratch& s, const unsigned* in, unsigned* out, int64
 
 // Stable LSD radix sort of (keys[0], pay[0]) by the key digits >= first_digit; *result = index of the
 // buffer pair holding the sorted data.  Digits on which all keys agree are skipped.
-int radix_sort(mals_ingest g, Scratch& s, int64_t n, int* result, int first_digit = 0) {
+template <typename P>
+int radix_sort(mals_ingest g, Scratch& s, P* const (&pay)[2], int64_t n, int* result, int first_digit = 0) {
   *result = 0;
   if (n <= 1) return MALS_OK;
   ICHK(g, hipMemsetAsync(s.digit_tot, 0, 8 * 256 * sizeof(unsigned long long), g->stream));
@@ -121,10 +129,10 @@ int radix_sort(mals_ingest g, Scratch& s, int64_t n, int* result, int first_digi
     hipLaunchKernelGGL(rs_histogram_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], n, 8 * d, n_blocks, s.counts);
     ICHK(g, hipGetLastError());
     if (int rc = scan_u32(g, s, s.counts, s.counts, 256 * n_blocks, nullptr)) return rc;
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], s.pay[cur], n, 8 * d, n_blocks,
-                       s.counts, s.keys[1 - cur], s.pay[1 - cur]);
+    hipLaunchKernelGGL(rs_scatter_kernel<P>, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], pay[cur], n, 8 * d, n_blocks,
+                       s.counts, s.keys[1 - cur], pay[1 - cur]);
     ICHK(g, hipGetLastError());
-    g->bytes_moved += (8.0 + 12.0 + 12.0) * (double)n;  // histogram read; scatter read + write
+    g->bytes_moved += (8.0 + 2.0 * (8.0 + sizeof(P))) * (double)n;  // histogram read; scatter read + write
     ++g->radix_passes;
     cur = 1 - cur;
   }
@@ -141,24 +149,6 @@ void free_results(mals_ingest g) {
   }
   g->finished = false;
   g->n_users = g->n_items = g->nnz = 0;
-}
-
-// dense rank (among all ids seen) of every record's id in stream order + the ascending id table
-int rank_ids(mals_ingest g, Scratch& s, const int64_t* d_ids, int64_t n, unsigned* head, unsigned* head_scan,
-             unsigned* rank_of_record, int64_t* id_table, unsigned* n_ids) {
-  hipLaunchKernelGGL(id_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, d_ids, n, s.keys[0], s.pay[0]);
-  ICHK(g, hipGetLastError());
-  g->bytes_moved += 20.0 * (double)n;
-  int r = 0;
-  if (int rc = radix_sort(g, s, n, &r)) return rc;
-  hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], n, head);
-  ICHK(g, hipGetLastError());
-  if (int rc = scan_u32(g, s, head, head_scan, n, n_ids)) return rc;
-  hipLaunchKernelGGL(scatter_ranks_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], s.pay[r], head, head_scan, n,
-                     rank_of_record, id_table);
-  ICHK(g, hipGetLastError());
-  g->bytes_moved += (12.0 + 4.0 + 20.0 + 4.0) * (double)n;
-  return MALS_OK;
 }
 
 }  // namespace
@@ -187,6 +177,7 @@ int mals_ingest_destroy(mals_ingest g) {
   dfree(g->d_user);
   dfree(g->d_item);
   dfree(g->d_value);
+  for (int b = 0; b < mals_ingest_s::N_WS; ++b) dfree(g->ws[b]);
   delete g;
   return MALS_OK;
 }
@@ -250,23 +241,23 @@ static int alloc_results(mals_ingest g, unsigned n_users, unsigned n_items, unsi
   return MALS_OK;
 }
 
-static int finish_impl(mals_ingest g) {
+static int finish_impl(mals_ingest g, hipEvent_t e0) {
   const int64_t n = g->n;
   if (n == 0) {
+    ICHK(g, hipEventRecord(e0, g->stream));
     if (int rc = alloc_results(g, 0, 0, 0)) return rc;
     ICHK(g, hipMemsetAsync(g->ptr[0], 0, sizeof(int64_t), g->stream));
     ICHK(g, hipMemsetAsync(g->ptr[1], 0, sizeof(int64_t), g->stream));
     return MALS_OK;
   }
-  struct Tmp {  // per-finish device temporaries
-    unsigned *head = nullptr, *scan = nullptr, *ru = nullptr, *ri = nullptr, *keep = nullptr;
+  struct Tmp {  // small per-finish device temporaries (sized by the number of distinct ids)
+    unsigned *head = nullptr, *scan = nullptr, *ri = nullptr, *keep = nullptr;  // arena
+    float* pair_val = nullptr;                                                   // arena
+    int32_t* coo_row = nullptr;                                                  // arena
     unsigned *alive_u = nullptr, *alive_i = nullptr, *new_u = nullptr, *new_i = nullptr;
     int64_t *uid_all = nullptr, *iid_all = nullptr;
-    float* pair_val = nullptr;
-    int32_t* coo_row = nullptr;
     ~Tmp() {
-      dfree(head); dfree(scan); dfree(ru); dfree(ri); dfree(keep); dfree(alive_u); dfree(alive_i); dfree(new_u); dfree(new_i);
-      dfree(uid_all); dfree(iid_all); dfree(pair_val); dfree(coo_row);
+      dfree(alive_u); dfree(alive_i); dfree(new_u); dfree(new_i); dfree(uid_all); dfree(iid_all);
     }
   } t;
   Scratch s;
@@ -274,32 +265,70 @@ static int finish_impl(mals_ingest g) {
   const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
   const int64_t scan_len = std::max<int64_t>(n, 256 * n_blocks);
   const int64_t tiles = (scan_len + SC_TILE - 1) / SC_TILE;
-  for (int b = 0; b < 2; ++b) {
-    ICHK(g, hipMalloc(&s.keys[b], sizeof(uint64_t) * (size_t)n));
-    ICHK(g, hipMalloc(&s.pay[b], sizeof(unsigned) * (size_t)n));
+  {  // workspace: 52 bytes per record + the digit counts
+    const size_t k8 = sizeof(uint64_t) * (size_t)n, k4 = sizeof(unsigned) * (size_t)n;
+    const size_t want[mals_ingest_s::N_WS] = {k8, k8, k4, k4, k8, k8, k4, k4, k4, sizeof(unsigned) * (size_t)(256 * n_blocks),
+                                              sizeof(unsigned) * (size_t)tiles, sizeof(unsigned long long) * 8 * 256 + 256};
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int b = 0; b < mals_ingest_s::N_WS; ++b) {
+      if (want[b] > g->ws_bytes[b]) {
+        dfree(g->ws[b]);
+        g->ws_bytes[b] = 0;
+        ICHK(g, hipMalloc(&g->ws[b], want[b]));
+        g->ws_bytes[b] = want[b];
+      }
+    }
+    g->last_workspace_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s.keys[0] = (uint64_t*)g->ws[0];
+    s.keys[1] = (uint64_t*)g->ws[1];
+    s.pay[0] = (unsigned*)g->ws[2];
+    s.pay[1] = (unsigned*)g->ws[3];
+    s.pay64[0] = (uint64_t*)g->ws[4];
+    s.pay64[1] = (uint64_t*)g->ws[5];
+    t.head = (unsigned*)g->ws[6];
+    t.scan = (unsigned*)g->ws[7];
+    t.ri = (unsigned*)g->ws[8];
+    s.counts = (unsigned*)g->ws[9];
+    s.tile_sums = (unsigned*)g->ws[10];
+    s.digit_tot = (unsigned long long*)g->ws[11];
+    s.total = (unsigned*)((char*)g->ws[11] + sizeof(unsigned long long) * 8 * 256);
+    // dead after the composite sort: the 64-bit payload buffers carry the replay outputs
+    t.keep = (unsigned*)s.pay64[0];
+    t.pair_val = (float*)((char*)s.pay64[0] + k4);
+    t.coo_row = (int32_t*)s.pay64[1];
   }
-  ICHK(g, hipMalloc(&s.counts, sizeof(unsigned) * (size_t)(256 * n_blocks)));
-  ICHK(g, hipMalloc(&s.tile_sums, sizeof(unsigned) * (size_t)tiles));
-  ICHK(g, hipMalloc(&s.digit_tot, sizeof(unsigned long long) * 8 * 256));
-  ICHK(g, hipMalloc(&s.total, sizeof(unsigned)));
-  ICHK(g, hipMalloc(&t.head, sizeof(unsigned) * (size_t)n));
-  ICHK(g, hipMalloc(&t.scan, sizeof(unsigned) * (size_t)n));
-  ICHK(g, hipMalloc(&t.ru, sizeof(unsigned) * (size_t)n));
-  ICHK(g, hipMalloc(&t.ri, sizeof(unsigned) * (size_t)n));
-  ICHK(g, hipMalloc(&t.uid_all, sizeof(int64_t) * (size_t)n));
-  ICHK(g, hipMalloc(&t.iid_all, sizeof(int64_t) * (size_t)n));
-  // 1-2. dense ranks of the user and item ids (among all ids seen), back in stream order
-  if (int rc = rank_ids(g, s, g->d_user, n, t.head, t.scan, t.ru, t.uid_all, &n_u_all)) return rc;
-  if (int rc = rank_ids(g, s, g->d_item, n, t.head, t.scan, t.ri, t.iid_all, &n_i_all)) return rc;
-  // 3. records grouped by (user, item); the sort is stable, so stream order survives inside a group
-  hipLaunchKernelGGL(pair_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, t.ru, t.ri, n, s.keys[0], s.pay[0]);
+  ICHK(g, hipEventRecord(e0, g->stream));  // the pipeline proper starts here
+  // 1. records sorted by item id (stable: stream order inside an item); dense item rank of every position
+  hipLaunchKernelGGL(id_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_item, n, s.keys[0], s.pay[0]);
   ICHK(g, hipGetLastError());
   g->bytes_moved += 20.0 * (double)n;
-  int r = 0;
-  if (int rc = radix_sort(g, s, n, &r)) return rc;
+  int ra = 0;
+  if (int rc = radix_sort(g, s, s.pay, n, &ra)) return rc;
+  hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[ra], n, t.head);
+  ICHK(g, hipGetLastError());
+  if (int rc = scan_u32(g, s, t.head, t.scan, n, &n_i_all)) return rc;
+  ICHK(g, hipMalloc(&t.iid_all, sizeof(int64_t) * (size_t)n_i_all));
+  hipLaunchKernelGGL(position_ranks_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[ra], t.head, t.scan, n, t.ri,
+                     t.iid_all);
+  // 2. ... then by user id (stable again): the records are now ordered by (user, item, stream order) --
+  //    one sort of the composite key, with the item rank and the record index riding along
+  hipLaunchKernelGGL(user_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_user, s.pay[ra], t.ri, n, s.keys[0],
+                     s.pay64[0]);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += (12.0 + 4.0 + 12.0 + 4.0 + 8.0 + 4.0 + 16.0) * (double)n;
+  int rb = 0;
+  if (int rc = radix_sort(g, s, s.pay64, n, &rb)) return rc;
+  hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[rb], n, t.head);
+  ICHK(g, hipGetLastError());
+  if (int rc = scan_u32(g, s, t.head, t.scan, n, &n_u_all)) return rc;
+  ICHK(g, hipMalloc(&t.uid_all, sizeof(int64_t) * (size_t)n_u_all));
+  // 3. pair keys (user rank << 32 | item rank) and record indices in that order
+  const int r = 1 - rb;  // the other key buffer is free now
+  hipLaunchKernelGGL(pair_from_sorted_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[rb], s.pay64[rb], t.head, t.scan, n,
+                     s.keys[r], s.pay[r], t.uid_all);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += (12.0 + 4.0 + 16.0 + 8.0 + 12.0) * (double)n;
   // 4. replay every pair's records in order
-  ICHK(g, hipMalloc(&t.keep, sizeof(unsigned) * (size_t)n));
-  ICHK(g, hipMalloc(&t.pair_val, sizeof(float) * (size_t)n));
   ICHK(g, hipMalloc(&t.alive_u, sizeof(unsigned) * (size_t)n_u_all));
   ICHK(g, hipMalloc(&t.alive_i, sizeof(unsigned) * (size_t)n_i_all));
   ICHK(g, hipMalloc(&t.new_u, sizeof(unsigned) * (size_t)n_u_all));
@@ -316,7 +345,6 @@ static int finish_impl(mals_ingest g) {
   // 6. surviving entries (|value| >= threshold): already sorted by (user, item)
   if (int rc = scan_u32(g, s, t.keep, t.scan, n, &nnz)) return rc;
   if (int rc = alloc_results(g, n_users, n_items, nnz)) return rc;
-  ICHK(g, hipMalloc(&t.coo_row, sizeof(int32_t) * std::max<size_t>(nnz, 1)));
   hipLaunchKernelGGL(compact_ids_kernel, dim3(blocks_for(n_u_all)), dim3(256), 0, g->stream, t.uid_all, t.alive_u, t.new_u,
                      (int64_t)n_u_all, g->ids[0]);
   hipLaunchKernelGGL(compact_ids_kernel, dim3(blocks_for(n_i_all)), dim3(256), 0, g->stream, t.iid_all, t.alive_i, t.new_i,
@@ -335,7 +363,7 @@ static int finish_impl(mals_ingest g) {
     ICHK(g, hipGetLastError());
     g->bytes_moved += 20.0 * (double)nnz;
     int r2 = 0;
-    if (int rc = radix_sort(g, s, (int64_t)nnz, &r2, 4)) return rc;
+    if (int rc = radix_sort(g, s, s.pay, (int64_t)nnz, &r2, 4)) return rc;
     hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], g->val[0],
                        (int64_t)nnz, t.coo_row, g->col[1], g->val[1]);
     ICHK(g, hipGetLastError());
@@ -360,8 +388,8 @@ int mals_ingest_finish(mals_ingest g) {
   hipEvent_t e0, e1;
   ICHK(g, hipEventCreate(&e0));
   ICHK(g, hipEventCreate(&e1));
-  ICHK(g, hipEventRecord(e0, g->stream));
-  const int rc = finish_impl(g);
+  g->last_workspace_ms = 0.0;
+  const int rc = finish_impl(g, e0);
   if (rc != MALS_OK) {
     free_results(g);
     (void)hipEventDestroy(e0);
@@ -431,9 +459,10 @@ int mals_ingest_install(mals_ingest g, mals_handle h) {
   return MALS_OK;
 }
 
-int mals_ingest_stats(mals_ingest g, double* finish_ms, double* bytes_moved, int32_t* radix_passes) {
+int mals_ingest_stats(mals_ingest g, double* finish_ms, double* workspace_ms, double* bytes_moved, int32_t* radix_passes) {
   if (!g) return MALS_INVALID_ARG;
   if (finish_ms) *finish_ms = g->last_finish_ms;
+  if (workspace_ms) *workspace_ms = g->last_workspace_ms;
   if (bytes_moved) *bytes_moved = g->bytes_moved;
   if (radix_passes) *radix_passes = g->radix_passes;
   return MALS_OK;

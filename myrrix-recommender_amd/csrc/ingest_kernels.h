@@ -95,13 +95,14 @@ __global__ __launch_bounds__(256) void rs_histogram_kernel(const uint64_t* __res
 // tile; pass 2 moves the tile into LDS in digit order; pass 3 streams it out: consecutive LDS slots of
 // a digit go to consecutive global addresses, so the writes are runs of ~RS_BLOCK_TILE/256 keys
 // instead of isolated 8-byte stores that HBM would turn into read-modify-writes of whole lines.
-__global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
+template <typename P>  // payload: uint32_t or uint64_t
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t* __restrict__ keys, const P* __restrict__ pay,
                                                          int64_t n, int shift, int64_t n_blocks,
                                                          const unsigned* __restrict__ offsets,  // scanned counts
-                                                         uint64_t* __restrict__ keys_out, unsigned* __restrict__ pay_out) {
+                                                         uint64_t* __restrict__ keys_out, P* __restrict__ pay_out) {
   constexpr int ROUNDS = RS_WAVE_TILE / 64;
   __shared__ uint64_t skey[RS_BLOCK_TILE];
-  __shared__ unsigned spay[RS_BLOCK_TILE];
+  __shared__ P spay[RS_BLOCK_TILE];
   __shared__ unsigned cnt[4][256];   // per-wave digit counts, then per-wave offsets inside the digit's segment
   __shared__ unsigned seg[256];      // start of the digit's segment in the tile
   __shared__ unsigned gbase[256];    // global position of the segment's first key
@@ -110,14 +111,14 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t* __restr
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const int64_t b = (int64_t)blockIdx.x * RS_BLOCK_TILE + w * RS_WAVE_TILE;
   uint64_t k[ROUNDS];
-  unsigned p[ROUNDS];
+  P p[ROUNDS];
   unsigned short lrank[ROUNDS];
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const int64_t i = b + 64 * r + lane;
     const bool ok = i < n;
     k[r] = ok ? keys[i] : ~0ull;
-    p[r] = ok ? pay[i] : 0u;
+    p[r] = ok ? pay[i] : (P)0;
   }
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
@@ -264,6 +265,39 @@ __global__ void scatter_ranks_kernel(const uint64_t* __restrict__ keys, const un
     const unsigned r = head_scan[i] + head[i] - 1;  // inclusive scan - 1
     rank_of_record[pay[i]] = r;
     if (head[i]) id_table[r] = key_to_id(keys[i]);
+  }
+}
+// item-sorted order: dense item rank of every position + the ascending item id table
+__global__ void position_ranks_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ head,
+                                      const unsigned* __restrict__ head_scan, int64_t n, unsigned* __restrict__ rank_of_position,
+                                      int64_t* __restrict__ id_table) {
+  MALS_GRID_STRIDE(i, n) {
+    const unsigned r = head_scan[i] + head[i] - 1;
+    rank_of_position[i] = r;
+    if (head[i]) id_table[r] = key_to_id(keys[i]);
+  }
+}
+// second stage of the composite sort: key = the record's user id (gathered through the item-sorted
+// permutation), payload = (item rank << 32 | record index)
+__global__ void user_stage_kernel(const int64_t* __restrict__ user_ids, const unsigned* __restrict__ idx,
+                                  const unsigned* __restrict__ item_rank, int64_t n, uint64_t* __restrict__ keys,
+                                  uint64_t* __restrict__ pay) {
+  MALS_GRID_STRIDE(i, n) {
+    const unsigned j = idx[i];
+    keys[i] = id_to_key(user_ids[j]);
+    pay[i] = ((uint64_t)item_rank[i] << 32) | j;
+  }
+}
+// (user id, item rank, stream order) sorted records -> the pair keys and record indices replay_pairs wants
+__global__ void pair_from_sorted_kernel(const uint64_t* __restrict__ ukeys, const uint64_t* __restrict__ pay,
+                                        const unsigned* __restrict__ head, const unsigned* __restrict__ head_scan, int64_t n,
+                                        uint64_t* __restrict__ pair_keys, unsigned* __restrict__ idx,
+                                        int64_t* __restrict__ user_table) {
+  MALS_GRID_STRIDE(i, n) {
+    const unsigned ru = head_scan[i] + head[i] - 1;
+    pair_keys[i] = ((uint64_t)ru << 32) | (pay[i] >> 32);
+    idx[i] = (unsigned)(pay[i] & 0xffffffffu);
+    if (head[i]) user_table[ru] = key_to_id(ukeys[i]);
   }
 }
 __global__ void pair_keys_kernel(const unsigned* __restrict__ ru, const unsigned* __restrict__ ri, int64_t n,

@@ -92,9 +92,9 @@ class Ingest:
         core._keep[("ingest",)] = self
 
     def stats(self):
-        ms, by, p = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
-        self._chk(self._L.mals_ingest_stats(self._g, ctypes.byref(ms), ctypes.byref(by), ctypes.byref(p)))
-        return {"finish_ms": ms.value, "bytes_moved": by.value, "radix_passes": p.value}
+        ms, ws, by, p = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+        self._chk(self._L.mals_ingest_stats(self._g, ctypes.byref(ms), ctypes.byref(ws), ctypes.byref(by), ctypes.byref(p)))
+        return {"finish_ms": ms.value, "workspace_ms": ws.value, "bytes_moved": by.value, "radix_passes": p.value}
 
 
 def readInputRecords(user_ids, item_ids, values, device=0, zero_threshold=None):
