@@ -13,6 +13,8 @@
 //   wave-private LDS array, so the scatter is stable without any atomics.
 //   Digits on which all keys agree are skipped (one preliminary histogram of all 8 digits), which
 //   is most of them for ids below 2^32 and for (row,col) keys of realistic shapes.
+// Pipeline (ingest_api.hip): composite sort by (user id, item id) in two stable stages with the dense
+// ranks read off the sorted orders, per-pair replay, compaction, transpose by a sort on the item half.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
