@@ -5,12 +5,13 @@
 // (user, item, value | NaN) records, restated as sorts, scans and one sequential pass per pair.
 //
 // All of it is HBM-bound integer work: an LSD radix sort (8-bit digits, stable) of 64-bit keys with a
-// 32-bit payload, prefix sums, and elementwise passes.  Nothing here is shaped into a GEMM.
-//   radix pass = histogram kernel (one read of the keys) + scan of the per-wave digit counts +
-//   scatter kernel (one read of keys+payload, one scattered write).  Each wave owns a contiguous
-//   sub-tile and walks it 64 keys at a time in order; the rank of a key among the equal digits of
-//   its round comes from 8 ballots ("multi-split"), the running per-digit offsets live in a
-//   wave-private LDS array, so the scatter is stable without any atomics.
+// 32- or 64-bit payload, prefix sums, and elementwise passes.  Nothing here is shaped into a GEMM.
+//   radix pass = histogram kernel (one read of the keys) + prefix sum of the per-workgroup digit
+//   counts + scatter kernel (one read of keys+payload, one write).  A workgroup owns 4096 consecutive
+//   keys; every wave walks its quarter 64 keys at a time in order and ranks a key among the equal
+//   digits of its round with 8 ballots ("multi-split"), running counts in a wave-private LDS row, so
+//   the sort is stable without atomics; the tile is then ordered by digit in LDS and written out in
+//   runs instead of isolated 8-byte stores.
 //   Digits on which all keys agree are skipped (one preliminary histogram of all 8 digits), which
 //   is most of them for ids below 2^32 and for (row,col) keys of realistic shapes.
 // Pipeline (ingest_api.hip): composite sort by (user id, item id) in two stable stages with the dense
@@ -259,16 +260,6 @@ __global__ void id_keys_kernel(const int64_t* __restrict__ ids, int64_t n, uint6
 __global__ void heads_kernel(const uint64_t* __restrict__ keys, int64_t n, unsigned* __restrict__ head) {
   MALS_GRID_STRIDE(i, n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 }
-// rank of every record's id (dense index among all ids seen) back in stream order + the id table
-__global__ void scatter_ranks_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
-                                     const unsigned* __restrict__ head, const unsigned* __restrict__ head_scan, int64_t n,
-                                     unsigned* __restrict__ rank_of_record, int64_t* __restrict__ id_table) {
-  MALS_GRID_STRIDE(i, n) {
-    const unsigned r = head_scan[i] + head[i] - 1;  // inclusive scan - 1
-    rank_of_record[pay[i]] = r;
-    if (head[i]) id_table[r] = key_to_id(keys[i]);
-  }
-}
 // item-sorted order: dense item rank of every position + the ascending item id table
 __global__ void position_ranks_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ head,
                                       const unsigned* __restrict__ head_scan, int64_t n, unsigned* __restrict__ rank_of_position,
@@ -300,13 +291,6 @@ __global__ void pair_from_sorted_kernel(const uint64_t* __restrict__ ukeys, cons
     pair_keys[i] = ((uint64_t)ru << 32) | (pay[i] >> 32);
     idx[i] = (unsigned)(pay[i] & 0xffffffffu);
     if (head[i]) user_table[ru] = key_to_id(ukeys[i]);
-  }
-}
-__global__ void pair_keys_kernel(const unsigned* __restrict__ ru, const unsigned* __restrict__ ri, int64_t n,
-                                 uint64_t* __restrict__ keys, unsigned* __restrict__ pay) {
-  MALS_GRID_STRIDE(i, n) {
-    keys[i] = ((uint64_t)ru[i] << 32) | ri[i];
-    pay[i] = (unsigned)i;
   }
 }
 // One thread per (user,item) pair = per run of equal keys in the stably sorted record array: replays
