@@ -156,10 +156,15 @@ def main():
             halves[name] = {kk: round(h[kk + "_ms"], 3) for kk in ("rows", "segments", "finish", "gramian")}
             halves[name]["rows_GBps"] = round(h["rows_bytes"] / max(h["rows_ms"], 1e-9) / 1e6, 1)
         core.enable_timing(False)
+    # untimed quality figure: ReconstructionEvaluator's mean over the observed entries (8(f) row 3)
+    rec_sum, rec_cnt = core.reconstruction_error()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        q = torch.tensor([rec_sum, float(rec_cnt)], dtype=torch.float64, device=device)
+        dist.all_reduce(q)
+        rec_sum, rec_cnt = float(q[0].item()), int(q[1].item())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -203,6 +208,9 @@ def main():
                          "launches": st["rows_launches"]},
             "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian")},
             "half_iteration_kernel_ms": halves,
+            "reconstruction_error": {"mean": rec_sum / max(rec_cnt, 1), "entries": rec_cnt,
+                                     "what": "mean over stored entries of max(0, 1 - x_u.y_i) after warmup+steps iterations "
+                                             "(ReconstructionEvaluator.java:91-102), untimed"},
         }
         if world == 1 and not args.no_cpu_baseline:
             X = als.factors(pkg.SIDE_X)

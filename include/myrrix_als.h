@@ -236,6 +236,14 @@ int mals_solver_solve_dtof(mals_solver s, const double* b, float* x);
 int mals_solver_solve_ftod(mals_solver s, const float* b, double* x);
 int mals_solver_destroy(mals_solver s);
 
+/* ---- reconstruction metric on the device -------------------------------
+ * ReconstructionEvaluator.evaluate (online/src/net/myrrix/online/eval/ReconstructionEvaluator.java:
+ * 91-102): over every stored entry (u,i) of the local rows of side X, err = max(0, 1 - dot(X_u, Y_i))
+ * with SimpleVectorMath.dot (fp32 products, fp64 sum).  Returns the sum and the number of entries; the
+ * evaluator's result is sum/count (a multi-GPU caller adds the ranks' sums and counts first).
+ * (The convergence statistic of call() already crosses PCIe as 200 sampled rows only, mals_factorize.) */
+int mals_reconstruction_error(mals_handle h, double* sum_out, int64_t* count_out);
+
 /* ---- ingest -> CSR ------------------------------------------------------
  * What InputFilesReader.readInputFiles (online-local/src/net/myrrix/online/generation/
  * InputFilesReader.java:64-211) does to the parsed records of the input files, on the device: the

@@ -300,6 +300,12 @@ class ALSCore:
     def cancel(self):
         self._chk(self._L.mals_cancel(self._h))
 
+    def reconstruction_error(self):
+        """ReconstructionEvaluator's sum and count over the local user rows (mean = sum / count)."""
+        sm, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)
+        self._chk(self._L.mals_reconstruction_error(self._h, ctypes.byref(sm), ctypes.byref(cnt)))
+        return sm.value, cnt.value
+
     def recompute_solver(self, side):
         """Generation.recomputeSolver (Generation.java:142-158) for `side`'s factors.  Returns
         (HostSolver or None for an empty side, norm)."""

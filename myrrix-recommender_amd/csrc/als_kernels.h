@@ -1067,6 +1067,52 @@ __global__ void max_abs_kernel(const float* __restrict__ v, int64_t n, unsigned*
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// Reconstruction error over the stored entries of the local rows of R:
+// sum over (u,i) of max(0, 1 - x_u . y_i), the quantity ReconstructionEvaluator averages
+// (online/src/net/myrrix/online/eval/ReconstructionEvaluator.java:91-102), with the reference's dot
+// (SimpleVectorMath.java:34-41: fp32 products, fp64 sum).  One wave per row, four entries per step
+// like the fp32 gather; per-wave partial sums, summed in a fixed order by the caller.
+template <int T>
+__global__ __launch_bounds__(256) void reconstruction_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                                             const float* __restrict__ X, const float* __restrict__ Y, int k,
+                                                             int64_t n_rows, double* __restrict__ partial_sum,
+                                                             unsigned long long* __restrict__ partial_cnt) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  double acc = 0.0;
+  unsigned long long cnt = 0;
+  for (int64_t row = wave; row < n_rows; row += n_waves) {
+    const int64_t b = row_ptr[row], e = row_ptr[row + 1];
+    float x[T];
+#pragma unroll
+    for (int v = 0; v < T; ++v) x[v] = 16 * v + c < k ? X[row * k + 16 * v + c] : 0.f;
+    for (int64_t s = b; s < e; s += 4) {
+      const bool ok = s + g < e;
+      const float* y = Y + (int64_t)col[ok ? s + g : b] * k;
+      double d = 0.0;
+#pragma unroll
+      for (int v = 0; v < T; ++v) {
+        const float yv = 16 * v + c < k ? y[16 * v + c] : 0.f;
+        d += (double)__fmul_rn(x[v], yv);  // the reference's float * float, widened before the sum
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off);  // over the 16 lanes of the entry
+      if (ok && c == 0) {
+        acc += fmax(0.0, 1.0 - d);
+        ++cnt;
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  cnt += __shfl_xor(cnt, 16);
+  cnt += __shfl_xor(cnt, 32);
+  if (lane == 0) {
+    partial_sum[wave] = acc;
+    partial_cnt[wave] = cnt;
+  }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ F, const int64_t* __restrict__ idx, int n, int k,
                                    float* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -450,6 +450,17 @@ double dot_f(const float* x, const float* y, int k) {
 
 }  // namespace
 
+namespace {
+template <int T>
+int launch_reconstruction(mals_handle h, SideState& s, SideState& o, unsigned grid, double* d_sum, unsigned long long* d_cnt) {
+  hipLaunchKernelGGL((reconstruction_kernel<T>), dim3(grid), dim3(256), 0, h->stream, s.row_ptr, s.col,
+                     s.F + s.row_offset * h->cfg.features, o.F, h->cfg.features, s.n_local, d_sum, d_cnt);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+}  // namespace
+
+
 // ================================================================================================
 extern "C" {
 
@@ -1090,6 +1101,54 @@ int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iter
     if (!std::isfinite(mean)) break;                                       // ALS:248-251
     if (!(random_y && it == 1) && mean < convergence_threshold) break;     // ALS:253-256
   }
+  return MALS_OK;
+}
+
+int mals_reconstruction_error(mals_handle h, double* sum_out, int64_t* count_out) {
+  if (!h || !sum_out || !count_out) return MALS_INVALID_ARG;
+  SideState& s = h->side[MALS_SIDE_X];
+  SideState& o = h->side[MALS_SIDE_Y];
+  if (!s.has_matrix || !s.F || !o.F) return fail(h, MALS_INVALID_ARG, "needs the user-side matrix and both factor replicas");
+  if (int rc = use_device(h)) return rc;
+  *sum_out = 0.0;
+  *count_out = 0;
+  if (s.n_local == 0) return MALS_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>((s.n_local + 3) / 4, (int64_t)h->n_cu * 32);
+  const size_t n_waves = (size_t)grid * 4;
+  double* d_sum = nullptr;
+  unsigned long long* d_cnt = nullptr;
+  HIPCHK(h, hipMalloc(&d_sum, sizeof(double) * n_waves));
+  HIPCHK(h, hipMalloc(&d_cnt, sizeof(unsigned long long) * n_waves));
+  int rc = MALS_INVALID_ARG;
+  switch (h->T) {
+    case 1: rc = launch_reconstruction<1>(h, s, o, grid, d_sum, d_cnt); break;
+    case 2: rc = launch_reconstruction<2>(h, s, o, grid, d_sum, d_cnt); break;
+    case 3: rc = launch_reconstruction<3>(h, s, o, grid, d_sum, d_cnt); break;
+    case 4: rc = launch_reconstruction<4>(h, s, o, grid, d_sum, d_cnt); break;
+    case 5: rc = launch_reconstruction<5>(h, s, o, grid, d_sum, d_cnt); break;
+    case 6: rc = launch_reconstruction<6>(h, s, o, grid, d_sum, d_cnt); break;
+    case 7: rc = launch_reconstruction<7>(h, s, o, grid, d_sum, d_cnt); break;
+    case 8: rc = launch_reconstruction<8>(h, s, o, grid, d_sum, d_cnt); break;
+  }
+  std::vector<double> hs(n_waves);
+  std::vector<unsigned long long> hc(n_waves);
+  if (rc == MALS_OK) {
+    hipError_t e = hipMemcpyAsync(hs.data(), d_sum, sizeof(double) * n_waves, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hc.data(), d_cnt, sizeof(unsigned long long) * n_waves, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = fail(h, MALS_HIP_ERROR, hipGetErrorString(e));
+  }
+  (void)hipFree(d_sum);
+  (void)hipFree(d_cnt);
+  if (rc != MALS_OK) return rc;
+  double sum = 0.0;
+  unsigned long long cnt = 0;
+  for (size_t w = 0; w < n_waves; ++w) {  // fixed order: deterministic
+    sum += hs[w];
+    cnt += hc[w];
+  }
+  *sum_out = sum;
+  *count_out = (int64_t)cnt;
   return MALS_OK;
 }
 

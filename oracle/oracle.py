@@ -190,3 +190,18 @@ def dense_to_csr(R):
                 np.array(vals, dtype=np.float32))
 
     return one(R), one(R.T)
+
+
+def reconstruction_error(row_ptr, col_idx, val, X, Y):
+    """ReconstructionEvaluator.evaluate (online/src/net/myrrix/online/eval/ReconstructionEvaluator.java:91-102):
+    mean over the stored entries (u,i) of max(0, 1 - dot(X_u, Y_i)), dot = fp32 products summed in
+    fp64 (SimpleVectorMath.java:34-41).  Returns (sum, count)."""
+    row_ptr, col_idx, val = _csr(row_ptr, col_idx, val)
+    X, Y = _f32(X), _f32(Y)
+    rows = np.repeat(np.arange(len(row_ptr) - 1), np.diff(row_ptr))
+    total, step = 0.0, 1 << 20
+    for lo in range(0, len(col_idx), step):
+        p = (X[rows[lo:lo + step]] * Y[col_idx[lo:lo + step]]).astype(np.float32)      # float * float
+        d = np.cumsum(p.astype(np.float64), axis=1)[:, -1] if p.shape[1] else np.zeros(len(p))  # sequential fp64 sum
+        total += float(np.sum(np.maximum(0.0, 1.0 - d)))
+    return total, int(len(col_idx))
