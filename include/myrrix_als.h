@@ -244,6 +244,25 @@ int mals_solver_destroy(mals_solver s);
  * (The convergence statistic of call() already crosses PCIe as 200 sampled rows only, mals_factorize.) */
 int mals_reconstruction_error(mals_handle h, double* sum_out, int64_t* count_out);
 
+/* ---- top-N scoring -------------------------------------------------------
+ * ServerRecommender.recommend(userID, howMany, considerKnownItems, null) (online/src/net/myrrix/online/
+ * ServerRecommender.java:382-441) -> multithreadedTopN (:443-508) -> RecommendIterator (RecommendIterator.
+ * java:62-109) -> TopN (common/src/net/myrrix/common/TopN.java:49-128), for a batch of model users given by
+ * their dense indices: score of item i = (float) dot(Y_i, X_u) with SimpleVectorMath.dot (fp32 products,
+ * fp64 sum); the user's known items (the entries of its row of R on this handle) are skipped unless
+ * consider_known_items; the how_many best come back best first, equal scores in ascending item index
+ * (the reference leaves ties in hash order).  item_idx_out / score_out: n_queries x how_many, padded with
+ * -1 / -inf; n_out (may be NULL): results per query.  Rescorers, candidate filters and tags stay with
+ * the caller.  Y is streamed once per 64 queries. */
+int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, int32_t how_many, int32_t consider_known_items,
+                   int64_t* item_idx_out, float* score_out, int32_t* n_out);
+/* The same for caller-supplied query vectors (n_queries x features, host) -- anonymous users / fold-in
+ * (SR:561-606) -- with optional per-query lists of item indices to skip (CSR: exclude_ptr has
+ * n_queries+1 entries; both NULL = none). */
+int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_queries, int32_t how_many,
+                           const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
+                           int32_t* n_out);
+
 /* ---- ingest -> CSR ------------------------------------------------------
  * What InputFilesReader.readInputFiles (online-local/src/net/myrrix/online/generation/
  * InputFilesReader.java:64-211) does to the parsed records of the input files, on the device: the

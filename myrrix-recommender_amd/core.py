@@ -300,6 +300,37 @@ class ALSCore:
     def cancel(self):
         self._chk(self._L.mals_cancel(self._h))
 
+    def recommend(self, user_idx, how_many, consider_known_items=False):
+        """ServerRecommender.recommend for model users (dense indices): (item_idx [q][how_many] int64,
+        scores float32, counts)."""
+        u = _host(user_idx, np.int64)
+        idx = np.empty((len(u), how_many), dtype=np.int64)
+        sc = np.empty((len(u), how_many), dtype=np.float32)
+        cnt = np.empty(len(u), dtype=np.int32)
+        self._chk(self._L.mals_recommend(self._h, u.ctypes.data_as(ctypes.c_void_p), len(u), int(how_many),
+                                         1 if consider_known_items else 0, idx.ctypes.data_as(ctypes.c_void_p),
+                                         sc.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
+        return idx, sc, cnt
+
+    def recommend_vectors(self, vectors, how_many, exclude=None):
+        """Top-N for caller-supplied query vectors; exclude: optional list of item-index lists."""
+        v = _host(vectors, np.float32)
+        assert v.ndim == 2 and v.shape[1] == self.features
+        idx = np.empty((len(v), how_many), dtype=np.int64)
+        sc = np.empty((len(v), how_many), dtype=np.float32)
+        cnt = np.empty(len(v), dtype=np.int32)
+        ep = ei = None
+        if exclude is not None:
+            ptr = np.zeros(len(v) + 1, dtype=np.int64)
+            ptr[1:] = np.cumsum([len(e) for e in exclude])
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(e, np.int64) for e in exclude]) if ptr[-1] else np.zeros(0, np.int64))
+            ep, ei = ptr.ctypes.data_as(ctypes.c_void_p), flat.ctypes.data_as(ctypes.c_void_p)
+            self._keep[("excl",)] = (ptr, flat)
+        self._chk(self._L.mals_recommend_vectors(self._h, v.ctypes.data_as(ctypes.c_void_p), len(v), int(how_many), ep, ei,
+                                                 idx.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p),
+                                                 cnt.ctypes.data_as(ctypes.c_void_p)))
+        return idx, sc, cnt
+
     def reconstruction_error(self):
         """ReconstructionEvaluator's sum and count over the local user rows (mean = sum / count)."""
         sm, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)

@@ -6,6 +6,7 @@
 #include "../../include/myrrix_als.h"
 #include "als_kernels.h"
 #include "host_solver.h"
+#include "topn_kernels.h"
 
 #include <hip/hip_runtime.h>
 
@@ -460,6 +461,97 @@ int launch_reconstruction(mals_handle h, SideState& s, SideState& o, unsigned gr
 }
 }  // namespace
 
+
+namespace {
+template <int T>
+int launch_topn_scores(mals_handle h, const float* Y, int64_t n_items, const float* dQ, int nq, float* d_scores) {
+  const unsigned grid = (unsigned)std::min<int64_t>((n_items + 15) / 16, (int64_t)h->n_cu * 16);
+  hipLaunchKernelGGL((topn_scores_kernel<T>), dim3(grid), dim3(256), 0, h->stream, Y, n_items, h->cfg.features, dQ, nq, d_scores);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+
+// Score + mask + select for up to TOPN_MAX_QUERIES query vectors already on the device.
+// query_row (device, may be NULL): local user row whose known items are masked, -1 = none.
+int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const int64_t* d_excl_ptr, const int64_t* d_excl_idx,
+               int nq, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
+  SideState& y = h->side[MALS_SIDE_Y];
+  SideState& x = h->side[MALS_SIDE_X];
+  const int64_t n_items = y.n_total;
+  const int cap = how_many + 1024;
+  float* d_scores = nullptr;
+  uint32_t* d_out = nullptr;
+  const size_t out_words = (size_t)nq * (4 + 2 * (size_t)cap);
+  HIPCHK(h, hipMalloc(&d_scores, sizeof(float) * (size_t)nq * (size_t)n_items));
+  if (hipMalloc(&d_out, sizeof(uint32_t) * out_words) != hipSuccess) {
+    (void)hipFree(d_scores);
+    return fail(h, MALS_OOM, "top-N selection buffer");
+  }
+  int rc = MALS_INVALID_ARG;
+  switch (h->T) {
+    case 1: rc = launch_topn_scores<1>(h, y.F, n_items, dQ, nq, d_scores); break;
+    case 2: rc = launch_topn_scores<2>(h, y.F, n_items, dQ, nq, d_scores); break;
+    case 3: rc = launch_topn_scores<3>(h, y.F, n_items, dQ, nq, d_scores); break;
+    case 4: rc = launch_topn_scores<4>(h, y.F, n_items, dQ, nq, d_scores); break;
+    case 5: rc = launch_topn_scores<5>(h, y.F, n_items, dQ, nq, d_scores); break;
+    case 6: rc = launch_topn_scores<6>(h, y.F, n_items, dQ, nq, d_scores); break;
+    case 7: rc = launch_topn_scores<7>(h, y.F, n_items, dQ, nq, d_scores); break;
+    case 8: rc = launch_topn_scores<8>(h, y.F, n_items, dQ, nq, d_scores); break;
+  }
+  std::vector<uint32_t> out(out_words);
+  std::vector<float> row;
+  if (rc == MALS_OK) {
+    if (d_query_row) hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, nq, n_items, d_scores);
+    if (d_excl_ptr) hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, d_excl_ptr, d_excl_idx, nq, n_items, d_scores);
+    hipLaunchKernelGGL(topn_select_kernel, dim3((unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, how_many, cap, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, sizeof(uint32_t) * out_words, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) rc = fail(h, MALS_HIP_ERROR, hipGetErrorString(e));
+  }
+  for (int q = 0; q < nq && rc == MALS_OK; ++q) {
+    const uint32_t* o = &out[(size_t)q * (4 + 2 * (size_t)cap)];
+    const uint32_t above = o[0], ties_total = o[1], ties_stored = o[2];
+    struct Cand { uint32_t key; int64_t idx; };
+    std::vector<Cand> cand;
+    const uint32_t need_ties = above < (uint32_t)how_many ? (uint32_t)how_many - above : 0;
+    if (above > (uint32_t)cap || (ties_stored < ties_total && ties_stored < need_ties)) {
+      // more ties at the N-th score than the selection buffer holds (e.g. a block of identical items):
+      // resolve this query from its score row on the host
+      row.resize((size_t)n_items);
+      hipError_t e = hipMemcpy(row.data(), d_scores + (size_t)q * (size_t)n_items, sizeof(float) * (size_t)n_items, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { rc = fail(h, MALS_HIP_ERROR, hipGetErrorString(e)); break; }
+      const uint32_t ninf = score_key(-std::numeric_limits<float>::infinity());
+      for (int64_t i = 0; i < n_items; ++i) {
+        const uint32_t kk = score_key(row[(size_t)i]);
+        if (kk > ninf && kk >= o[3]) cand.push_back({kk, i});
+      }
+    } else {
+      for (uint32_t p = 0; p < above + ties_stored; ++p) cand.push_back({o[4 + 2 * p + 1], (int64_t)o[4 + 2 * p]});
+    }
+    // best score first; equal scores in ascending item index (the reference's order among ties is its hash order)
+    std::sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) { return a.key != b.key ? a.key > b.key : a.idx < b.idx; });
+    const int n = (int)std::min<size_t>(cand.size(), (size_t)how_many);
+    if (n_out) n_out[q] = n;
+    for (int j = 0; j < how_many; ++j) {
+      if (j < n) {
+        const uint32_t kk = cand[(size_t)j].key;
+        const uint32_t bits = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;
+        float f;
+        std::memcpy(&f, &bits, 4);
+        item_idx_out[(size_t)q * how_many + j] = cand[(size_t)j].idx;
+        score_out[(size_t)q * how_many + j] = f;
+      } else {
+        item_idx_out[(size_t)q * how_many + j] = -1;
+        score_out[(size_t)q * how_many + j] = -std::numeric_limits<float>::infinity();
+      }
+    }
+  }
+  (void)hipFree(d_scores);
+  (void)hipFree(d_out);
+  return rc;
+}
+}  // namespace
 
 // ================================================================================================
 extern "C" {
@@ -1149,6 +1241,88 @@ int mals_reconstruction_error(mals_handle h, double* sum_out, int64_t* count_out
   }
   *sum_out = sum;
   *count_out = (int64_t)cnt;
+  return MALS_OK;
+}
+
+int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, int32_t how_many, int32_t consider_known_items,
+                   int64_t* item_idx_out, float* score_out, int32_t* n_out) {
+  if (!h) return MALS_INVALID_ARG;
+  SideState& x = h->side[MALS_SIDE_X];
+  SideState& y = h->side[MALS_SIDE_Y];
+  if (!x.F || !y.F || y.n_total == 0) return fail(h, MALS_INVALID_ARG, "factor replicas not available");
+  if (n_queries < 0 || how_many <= 0 || how_many > 4096 || (n_queries > 0 && (!user_idx || !item_idx_out || !score_out)))
+    return fail(h, MALS_INVALID_ARG, "bad recommend arguments (how_many in 1..4096)");
+  if (!consider_known_items && !x.has_matrix) return fail(h, MALS_INVALID_ARG, "the user-side matrix is needed to skip known items");
+  for (int q = 0; q < n_queries; ++q) {
+    if (user_idx[q] < 0 || user_idx[q] >= x.n_total) return fail(h, MALS_INVALID_ARG, "user index outside the factor replica");
+    if (!consider_known_items && (user_idx[q] < x.row_offset || user_idx[q] >= x.row_offset + x.n_local))
+      return fail(h, MALS_INVALID_ARG, "known items of this user are not on this handle (row outside the local shard)");
+  }
+  if (int rc = use_device(h)) return rc;
+  const int k = h->cfg.features;
+  for (int q0 = 0; q0 < n_queries; q0 += TOPN_MAX_QUERIES) {
+    const int nq = std::min(TOPN_MAX_QUERIES, n_queries - q0);
+    float* dQ = nullptr;
+    int64_t *d_idx = nullptr, *d_row = nullptr;
+    HIPCHK(h, hipMalloc(&dQ, sizeof(float) * (size_t)nq * k));
+    HIPCHK(h, hipMalloc(&d_idx, sizeof(int64_t) * (size_t)nq));
+    HIPCHK(h, hipMalloc(&d_row, sizeof(int64_t) * (size_t)nq));
+    std::vector<int64_t> rows((size_t)nq);
+    for (int q = 0; q < nq; ++q) rows[(size_t)q] = consider_known_items ? -1 : user_idx[q0 + q] - x.row_offset;
+    hipError_t e = hipMemcpyAsync(d_idx, user_idx + q0, sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_row, rows.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nq * k + 255) / 256)), dim3(256), 0, h->stream, x.F, d_idx, nq, k, dQ);
+      e = hipGetLastError();
+    }
+    int rc = e == hipSuccess ? MALS_OK : fail(h, MALS_HIP_ERROR, hipGetErrorString(e));
+    if (rc == MALS_OK)
+      rc = topn_batch(h, dQ, d_row, nullptr, nullptr, nq, how_many, item_idx_out + (size_t)q0 * how_many, score_out + (size_t)q0 * how_many,
+                      n_out ? n_out + q0 : nullptr);
+    (void)hipFree(dQ);
+    (void)hipFree(d_idx);
+    (void)hipFree(d_row);
+    if (rc != MALS_OK) return rc;
+  }
+  return MALS_OK;
+}
+
+int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_queries, int32_t how_many,
+                           const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
+                           int32_t* n_out) {
+  if (!h) return MALS_INVALID_ARG;
+  SideState& y = h->side[MALS_SIDE_Y];
+  if (!y.F || y.n_total == 0) return fail(h, MALS_INVALID_ARG, "item factor replica not available");
+  if (n_queries < 0 || how_many <= 0 || how_many > 4096 || (n_queries > 0 && (!query_vectors || !item_idx_out || !score_out)))
+    return fail(h, MALS_INVALID_ARG, "bad recommend arguments (how_many in 1..4096)");
+  if ((exclude_ptr == nullptr) != (exclude_idx == nullptr) && exclude_ptr && exclude_ptr[n_queries] > 0)
+    return fail(h, MALS_INVALID_ARG, "exclude_ptr and exclude_idx go together");
+  if (int rc = use_device(h)) return rc;
+  const int k = h->cfg.features;
+  for (int q0 = 0; q0 < n_queries; q0 += TOPN_MAX_QUERIES) {
+    const int nq = std::min(TOPN_MAX_QUERIES, n_queries - q0);
+    float* dQ = nullptr;
+    int64_t *d_ptr = nullptr, *d_ex = nullptr;
+    HIPCHK(h, hipMalloc(&dQ, sizeof(float) * (size_t)nq * k));
+    hipError_t e = hipMemcpyAsync(dQ, query_vectors + (size_t)q0 * k, sizeof(float) * (size_t)nq * k, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && exclude_ptr) {
+      std::vector<int64_t> ptr((size_t)nq + 1);
+      for (int q = 0; q <= nq; ++q) ptr[(size_t)q] = exclude_ptr[q0 + q] - exclude_ptr[q0];
+      const int64_t n_ex = ptr[(size_t)nq];
+      e = hipMalloc(&d_ptr, sizeof(int64_t) * ((size_t)nq + 1));
+      if (e == hipSuccess) e = hipMalloc(&d_ex, sizeof(int64_t) * (size_t)std::max<int64_t>(n_ex, 1));
+      if (e == hipSuccess) e = hipMemcpy(d_ptr, ptr.data(), sizeof(int64_t) * ((size_t)nq + 1), hipMemcpyHostToDevice);
+      if (e == hipSuccess && n_ex) e = hipMemcpy(d_ex, exclude_idx + exclude_ptr[q0], sizeof(int64_t) * (size_t)n_ex, hipMemcpyHostToDevice);
+    }
+    int rc = e == hipSuccess ? MALS_OK : fail(h, MALS_HIP_ERROR, hipGetErrorString(e));
+    if (rc == MALS_OK)
+      rc = topn_batch(h, dQ, nullptr, d_ptr, d_ex, nq, how_many, item_idx_out + (size_t)q0 * how_many, score_out + (size_t)q0 * how_many,
+                      n_out ? n_out + q0 : nullptr);
+    (void)hipFree(dQ);
+    if (d_ptr) (void)hipFree(d_ptr);
+    if (d_ex) (void)hipFree(d_ex);
+    if (rc != MALS_OK) return rc;
+  }
   return MALS_OK;
 }
 
