@@ -97,6 +97,12 @@ struct mals_handle_s {
   mals_stats stats;
   std::vector<PendingEvent> pending;
   unsigned long long* d_trace = nullptr;  // MALS_DEBUG_TRACE
+  // top-N workspace (grow-only): score rows, selection output, state, histograms
+  float* tn_scores = nullptr;
+  uint32_t* tn_out = nullptr;
+  void* tn_state = nullptr;
+  unsigned* tn_hist = nullptr;
+  size_t tn_scores_cap = 0, tn_out_cap = 0;
   int64_t* d_idx = nullptr;  // gather scratch
   float* d_rows = nullptr;
   int32_t idx_cap = 0;
@@ -478,15 +484,31 @@ int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const
   SideState& y = h->side[MALS_SIDE_Y];
   SideState& x = h->side[MALS_SIDE_X];
   const int64_t n_items = y.n_total;
-  const int cap = how_many + 1024;
+  const int cap_ties = 1024;
   float* d_scores = nullptr;
   uint32_t* d_out = nullptr;
-  const size_t out_words = (size_t)nq * (4 + 2 * (size_t)cap);
-  HIPCHK(h, hipMalloc(&d_scores, sizeof(float) * (size_t)nq * (size_t)n_items));
-  if (hipMalloc(&d_out, sizeof(uint32_t) * out_words) != hipSuccess) {
-    (void)hipFree(d_scores);
-    return fail(h, MALS_OOM, "top-N selection buffer");
+  TopnState* d_st = nullptr;
+  unsigned* d_hist = nullptr;
+  const size_t per_q = 2 * ((size_t)how_many + cap_ties);
+  const size_t out_words = (size_t)nq * per_q;
+  if (h->tn_scores_cap < (size_t)nq * (size_t)n_items) {
+    free_dev(h->tn_scores);
+    h->tn_scores_cap = 0;
+    HIPCHK(h, hipMalloc(&h->tn_scores, sizeof(float) * (size_t)TOPN_MAX_QUERIES * (size_t)n_items));
+    h->tn_scores_cap = (size_t)TOPN_MAX_QUERIES * (size_t)n_items;
   }
+  if (h->tn_out_cap < out_words) {
+    free_dev(h->tn_out);
+    h->tn_out_cap = 0;
+    HIPCHK(h, hipMalloc(&h->tn_out, sizeof(uint32_t) * (size_t)TOPN_MAX_QUERIES * per_q));
+    h->tn_out_cap = (size_t)TOPN_MAX_QUERIES * per_q;
+  }
+  if (!h->tn_state) HIPCHK(h, hipMalloc(&h->tn_state, sizeof(TopnState) * TOPN_MAX_QUERIES));
+  if (!h->tn_hist) HIPCHK(h, hipMalloc(&h->tn_hist, sizeof(unsigned) * 256 * TOPN_MAX_QUERIES));
+  d_scores = h->tn_scores;
+  d_out = h->tn_out;
+  d_st = (TopnState*)h->tn_state;
+  d_hist = h->tn_hist;
   int rc = MALS_INVALID_ARG;
   switch (h->T) {
     case 1: rc = launch_topn_scores<1>(h, y.F, n_items, dQ, nq, d_scores); break;
@@ -499,35 +521,48 @@ int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const
     case 8: rc = launch_topn_scores<8>(h, y.F, n_items, dQ, nq, d_scores); break;
   }
   std::vector<uint32_t> out(out_words);
+  std::vector<TopnState> st((size_t)nq);
   std::vector<float> row;
   if (rc == MALS_OK) {
+    for (int q = 0; q < nq; ++q) st[(size_t)q] = TopnState{0u, (uint32_t)how_many, 0u, 0u};
+    hipError_t e = hipMemcpyAsync(d_st, st.data(), sizeof(TopnState) * (size_t)nq, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, sizeof(unsigned) * 256 * (size_t)nq, h->stream);
     if (d_query_row) hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, nq, n_items, d_scores);
     if (d_excl_ptr) hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, d_excl_ptr, d_excl_idx, nq, n_items, d_scores);
-    hipLaunchKernelGGL(topn_select_kernel, dim3((unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, how_many, cap, d_out);
-    hipError_t e = hipGetLastError();
+    // slabs per query: enough workgroups to fill the chip whatever the batch size
+    const unsigned slabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_items + 4095) / 4096, (int64_t)(h->n_cu * 8 + nq - 1) / nq));
+    for (int pass = 0; pass < 4; ++pass) {
+      hipLaunchKernelGGL(topn_hist_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, pass, d_st, d_hist);
+      hipLaunchKernelGGL(topn_pick_kernel, dim3((unsigned)nq), dim3(256), 0, h->stream, d_st, d_hist, pass);
+    }
+    hipLaunchKernelGGL(topn_collect_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, d_st, how_many, cap_ties, d_out);
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, sizeof(uint32_t) * out_words, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(st.data(), d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) rc = fail(h, MALS_HIP_ERROR, hipGetErrorString(e));
   }
   for (int q = 0; q < nq && rc == MALS_OK; ++q) {
-    const uint32_t* o = &out[(size_t)q * (4 + 2 * (size_t)cap)];
-    const uint32_t above = o[0], ties_total = o[1], ties_stored = o[2];
+    const uint32_t* o = &out[(size_t)q * per_q];
+    const uint32_t above = st[(size_t)q].above, ties_total = st[(size_t)q].ties;
+    const uint32_t ties_stored = std::min<uint32_t>(ties_total, (uint32_t)cap_ties);
     struct Cand { uint32_t key; int64_t idx; };
     std::vector<Cand> cand;
     const uint32_t need_ties = above < (uint32_t)how_many ? (uint32_t)how_many - above : 0;
-    if (above > (uint32_t)cap || (ties_stored < ties_total && ties_stored < need_ties)) {
-      // more ties at the N-th score than the selection buffer holds (e.g. a block of identical items):
-      // resolve this query from its score row on the host
+    if (above > (uint32_t)how_many || (ties_stored < ties_total && ties_stored < need_ties) || (ties_stored < ties_total && need_ties > 0)) {
+      // more ties at the N-th score than the selection buffer holds (e.g. a block of identical items): which of
+      // them have the lowest indices is not known from an unordered subset -- resolve this query on the host
       row.resize((size_t)n_items);
       hipError_t e = hipMemcpy(row.data(), d_scores + (size_t)q * (size_t)n_items, sizeof(float) * (size_t)n_items, hipMemcpyDeviceToHost);
       if (e != hipSuccess) { rc = fail(h, MALS_HIP_ERROR, hipGetErrorString(e)); break; }
       const uint32_t ninf = score_key(-std::numeric_limits<float>::infinity());
       for (int64_t i = 0; i < n_items; ++i) {
         const uint32_t kk = score_key(row[(size_t)i]);
-        if (kk > ninf && kk >= o[3]) cand.push_back({kk, i});
+        if (kk > ninf && kk >= st[(size_t)q].prefix) cand.push_back({kk, i});
       }
     } else {
-      for (uint32_t p = 0; p < above + ties_stored; ++p) cand.push_back({o[4 + 2 * p + 1], (int64_t)o[4 + 2 * p]});
+      for (uint32_t p = 0; p < above; ++p) cand.push_back({o[2 * p + 1], (int64_t)o[2 * p]});
+      for (uint32_t p = 0; p < ties_stored; ++p) cand.push_back({o[2 * (how_many + p) + 1], (int64_t)o[2 * (how_many + p)]});
     }
     // best score first; equal scores in ascending item index (the reference's order among ties is its hash order)
     std::sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) { return a.key != b.key ? a.key > b.key : a.idx < b.idx; });
@@ -547,8 +582,6 @@ int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const
       }
     }
   }
-  (void)hipFree(d_scores);
-  (void)hipFree(d_out);
   return rc;
 }
 }  // namespace
@@ -656,6 +689,10 @@ int mals_destroy(mals_handle h) {
   if (h->h_bad) (void)hipHostFree(h->h_bad);
   free_dev(h->d_idx);
   free_dev(h->d_rows);
+  free_dev(h->tn_scores);
+  free_dev(h->tn_out);
+  free_dev(h->tn_state);
+  free_dev(h->tn_hist);
   delete h;
   return MALS_OK;
 }

@@ -8,9 +8,9 @@
 //            item read, so Y is streamed once per batch: HBM-bound (n_items * 4k bytes).  The dot is
 //            the reference's (SimpleVectorMath.java:34-41): fp32 products, fp64 sum, cast to fp32.
 //   mask     known items of each query's user -> -inf (RecommendIterator.java:75-82).
-//   select   one workgroup per query: 4-pass radix select (8-bit digits of an order-preserving
-//            integer image of the score) finds the N-th largest score exactly, then everything above
-//            it plus the ties are handed back; no sort of the whole row.
+//   select   4-pass radix select (8-bit digits of an order-preserving integer image of the score,
+//            grid-wide histograms per query) finds the N-th largest score exactly, then everything
+//            above it plus the ties are handed back; no sort of the whole row.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -80,79 +80,93 @@ __global__ void topn_exclude_kernel(const int64_t* __restrict__ excl_ptr, const 
   }
 }
 
-// One workgroup per query.  out layout per query: header {n_above, n_ties_total, n_ties_stored, key},
-// then up to cap (index, score-bits) pairs: first the n_above items strictly above the N-th score, then
-// the stored ties.  -inf scores (masked items) never qualify.
-__global__ __launch_bounds__(256) void topn_select_kernel(const float* __restrict__ scores, int64_t n_items, int how_many,
-                                                          int cap, uint32_t* __restrict__ out) {
-  __shared__ unsigned hist[256];
-  __shared__ unsigned s_prefix, s_remaining, s_above, s_ties, s_stored;
-  const float* row = scores + (int64_t)blockIdx.x * n_items;
-  uint32_t* o = out + (int64_t)blockIdx.x * (4 + 2 * (int64_t)cap);
+// Selection state per query: {prefix, remaining} + a 256-bin histogram.  The N-th largest score is
+// found by a 4-pass radix select, most significant digit first; every pass is one grid-wide scan of
+// the score rows (grid = slabs x queries) into the per-query histogram, followed by a one-thread-per-
+// query pick of the digit in which the N-th score lies.  -inf scores (masked items) never qualify.
+struct TopnState {
+  uint32_t prefix;     // digits decided so far (in place, high bits)
+  uint32_t remaining;  // rank of the N-th score inside the candidates that match the prefix
+  uint32_t above;      // collected: scores strictly above the N-th
+  uint32_t ties;       // collected: scores equal to the N-th (all of them counted, cap_ties stored)
+};
+
+__global__ __launch_bounds__(256) void topn_hist_kernel(const float* __restrict__ scores, int64_t n_items, int pass,
+                                                        const TopnState* __restrict__ st, unsigned* __restrict__ hist) {
+  __shared__ unsigned h[256];
+  const int q = blockIdx.y;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int shift = 24 - 8 * pass;
+  const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+  const uint32_t prefix = st[q].prefix;
   const uint32_t ninf_key = score_key(-__builtin_huge_valf());
-  if (threadIdx.x == 0) {
-    s_prefix = 0;
-    s_remaining = (unsigned)how_many;
-    s_above = s_ties = s_stored = 0;
+  const float* row = scores + (int64_t)q * n_items;
+  const int lane = threadIdx.x & 63;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n_items; i0 += (int64_t)gridDim.x * 256) {  // whole waves iterate together
+    const int64_t i = i0 + threadIdx.x;
+    const uint32_t key = i < n_items ? score_key(row[i]) : 0u;
+    const bool cand = i < n_items && key > ninf_key && (key & mask) == prefix;
+    const int digit = (int)((key >> shift) & 255);
+    // scores of one query crowd into a few digits: aggregate equal digits of a wave with ballots and
+    // let one lane add the count (an LDS atomic per lane on the same bin serialises)
+    uint64_t peers = __ballot(cand);
+    if (!peers) continue;
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool one = (digit >> bit) & 1;
+      const uint64_t m = __ballot(one);
+      peers &= one ? m : ~m;
+    }
+    if (cand && (peers & ((1ull << lane) - 1)) == 0) atomicAdd(&h[digit], (unsigned)__popcll(peers));
   }
   __syncthreads();
-  // radix select of the how_many-th largest key, most significant digit first
-  for (int pass = 0; pass < 4; ++pass) {
+  if (h[threadIdx.x]) atomicAdd(&hist[q * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+// one workgroup per query: pick the digit, clear the histogram for the next pass
+__global__ __launch_bounds__(256) void topn_pick_kernel(TopnState* __restrict__ st, unsigned* __restrict__ hist, int pass) {
+  __shared__ unsigned h[256];
+  const int q = blockIdx.x;
+  h[threadIdx.x] = hist[q * 256 + threadIdx.x];
+  hist[q * 256 + threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
     const int shift = 24 - 8 * pass;
-    const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-    hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t prefix = s_prefix;
-    for (int64_t i = threadIdx.x; i < n_items; i += 256) {
-      const uint32_t key = score_key(row[i]);
-      if (key > ninf_key && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+    unsigned rem = st[q].remaining, d = 255;
+    for (;; --d) {
+      if (h[d] >= rem || d == 0) break;  // fewer candidates than asked for: ends at digit 0
+      rem -= h[d];
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned rem = s_remaining, d = 255;
-      for (;; --d) {
-        if (hist[d] >= rem || d == 0) break;
-        rem -= hist[d];
-      }
-      // fewer than how_many candidates in total: d reaches 0 with rem still larger than hist[0]
-      s_prefix = prefix | ((uint32_t)d << shift);
-      s_remaining = rem;
-    }
-    __syncthreads();
+    st[q].prefix |= (uint32_t)d << shift;
+    st[q].remaining = rem;
   }
-  const uint32_t thr = s_prefix;  // key of the how_many-th best score (or the smallest candidate key)
-  for (int64_t i = threadIdx.x; i < n_items; i += 256) {
-    const float sc = row[i];
-    const uint32_t key = score_key(sc);
-    if (key <= ninf_key) continue;
+}
+
+// out per query: [how_many] (index, key) pairs strictly above the N-th score, then [cap_ties] pairs of ties
+__global__ __launch_bounds__(256) void topn_collect_kernel(const float* __restrict__ scores, int64_t n_items, TopnState* __restrict__ st,
+                                                           int how_many, int cap_ties, uint32_t* __restrict__ out) {
+  const int q = blockIdx.y;
+  const uint32_t thr = st[q].prefix;
+  const uint32_t ninf_key = score_key(-__builtin_huge_valf());
+  const float* row = scores + (int64_t)q * n_items;
+  uint32_t* o = out + (int64_t)q * 2 * ((int64_t)how_many + cap_ties);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 256) {
+    const uint32_t key = score_key(row[i]);
+    if (key <= ninf_key || key < thr) continue;
     if (key > thr) {
-      const unsigned p = atomicAdd(&s_above, 1u);
-      if ((int)p < cap) {
-        o[4 + 2 * p] = (uint32_t)i;
-        o[4 + 2 * p + 1] = key;
+      const unsigned p = atomicAdd(&st[q].above, 1u);
+      if ((int)p < how_many) {
+        o[2 * p] = (uint32_t)i;
+        o[2 * p + 1] = key;
       }
-    } else if (key == thr) {
-      atomicAdd(&s_ties, 1u);
-    }
-  }
-  __syncthreads();
-  // ties after the strictly better ones, as many as fit
-  const unsigned above = s_above < (unsigned)cap ? s_above : (unsigned)cap;
-  for (int64_t i = threadIdx.x; i < n_items; i += 256) {
-    if (score_key(row[i]) == thr && thr > ninf_key) {
-      const unsigned p = atomicAdd(&s_stored, 1u);
-      if (above + p < (unsigned)cap) {
-        o[4 + 2 * (above + p)] = (uint32_t)i;
-        o[4 + 2 * (above + p) + 1] = thr;
+    } else {
+      const unsigned p = atomicAdd(&st[q].ties, 1u);
+      if ((int)p < cap_ties) {
+        o[2 * (how_many + p)] = (uint32_t)i;
+        o[2 * (how_many + p) + 1] = key;
       }
     }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    o[0] = s_above;
-    o[1] = s_ties;
-    o[2] = (above + s_stored <= (unsigned)cap) ? s_stored : (unsigned)cap - above;
-    o[3] = thr;
   }
 }
 
