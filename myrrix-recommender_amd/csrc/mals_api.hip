@@ -471,7 +471,7 @@ int launch_reconstruction(mals_handle h, SideState& s, SideState& o, unsigned gr
 namespace {
 template <int T>
 int launch_topn_scores(mals_handle h, const float* Y, int64_t n_items, const float* dQ, int nq, float* d_scores) {
-  const unsigned grid = (unsigned)std::min<int64_t>((n_items + 15) / 16, (int64_t)h->n_cu * 16);
+  const unsigned grid = (unsigned)std::min<int64_t>((n_items + 63) / 64, (int64_t)h->n_cu * 16);
   hipLaunchKernelGGL((topn_scores_kernel<T>), dim3(grid), dim3(256), 0, h->stream, Y, n_items, h->cfg.features, dQ, nq, d_scores);
   HIPCHK(h, hipGetLastError());
   return MALS_OK;

@@ -3,10 +3,10 @@
 // does with RecommendIterator (RecommendIterator.java:62-109) and TopN (common/.../TopN.java:49-128):
 // score every item against the query vector, skip the user's known items, keep the N best.
 //
-//   scores   one wave per 4 items and step, lane (g,c) = item 4*step+g, feature lanes c of every
-//            16-block (the gather layout of the factorizer); all queries of the batch are scored per
-//            item read, so Y is streamed once per batch: HBM-bound (n_items * 4k bytes).  The dot is
-//            the reference's (SimpleVectorMath.java:34-41): fp32 products, fp64 sum, cast to fp32.
+//   scores   fp64 matrix cores, 16 items x 16 queries x 4 features per instruction; all queries of
+//            the batch are scored per item read, so Y is streamed once per batch: HBM-bound
+//            (n_items * 4k bytes).  fp64 accumulation like the reference's dot
+//            (SimpleVectorMath.java:34-41), cast to fp32 at the end.
 //   mask     known items of each query's user -> -inf (RecommendIterator.java:75-82).
 //   select   4-pass radix select (8-bit digits of an order-preserving integer image of the score,
 //            grid-wide histograms per query) finds the N-th largest score exactly, then everything
@@ -26,32 +26,74 @@ __device__ __host__ __forceinline__ uint32_t score_key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Scores on the fp64 matrix cores: D[item][query] += A[item][feature] * B[feature][query] with
+// v_mfma_f64_16x16x4_f64 -- 16 items x 16 queries x 4 features per instruction, operands widened
+// from fp32 (their product is exact in fp64), fp64 accumulation, one cast to fp32 at the end.  The
+// reference rounds each product to fp32 before it widens (SimpleVectorMath.java:37); the difference
+// is below half an fp32 ulp of the score, so a score can differ from the reference's in its last bit
+// (tests compare at 2 ulp).  A wave owns 16 consecutive items and all query tiles; the queries sit
+// in LDS as doubles in operand order.  Y is read once per batch: HBM-bound (n_items * 4k bytes).
+typedef double f64x4_t __attribute__((ext_vector_type(4)));
 template <int T>
 __global__ __launch_bounds__(256) void topn_scores_kernel(const float* __restrict__ Y, int64_t n_items, int k,
                                                           const float* __restrict__ Q, int n_queries,
                                                           float* __restrict__ scores) {  // [n_queries][n_items]
-  __shared__ float sq[TOPN_MAX_QUERIES * 16 * T];
-  for (int i = threadIdx.x; i < n_queries * 16 * T; i += 256) {
-    const int q = i / (16 * T), f = i % (16 * T);
-    sq[i] = f < k ? Q[(int64_t)q * k + f] : 0.f;
+  constexpr int KP = 16 * T;                                  // padded feature count
+  __shared__ double sq[(TOPN_MAX_QUERIES / 16) * KP * 16];    // [query tile][feature][query in tile]
+  const int n_tiles = (n_queries + 15) >> 4;
+  for (int i = threadIdx.x; i < n_tiles * KP * 16; i += 256) {
+    const int j = i & 15, f = (i >> 4) % KP, qt = i / (16 * KP);
+    const int q = 16 * qt + j;
+    sq[i] = (q < n_queries && f < k) ? (double)Q[(int64_t)q * k + f] : 0.0;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int lane = threadIdx.x & 63, kk = lane >> 4, c = lane & 15;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-  for (int64_t i0 = wave * 4; i0 < n_items; i0 += n_waves * 4) {
-    const int64_t item = i0 + g;
+  // The order of the features inside the contraction is free (it only moves fp64 rounding), so lane
+  // (kk, c) takes the CONTIGUOUS quarter [kk*4T, (kk+1)*4T) of item c's row: at k = 64 exactly one
+  // 64-byte line per lane, read with T 16-byte loads.  MFMA step s contracts feature kk*4T + s.
+  constexpr int CH = 4 * T;
+  for (int64_t i0 = wave * 16; i0 < n_items; i0 += n_waves * 16) {
+    const int64_t item = i0 + c;
     const bool ok = item < n_items;
-    const float* y = Y + (ok ? item : 0) * k;
-    float yv[T];
+    const float* y = Y + (ok ? item : 0) * k + kk * CH;
+    float yv[CH];
+    if (k == KP) {
+      const float4* y4 = reinterpret_cast<const float4*>(y);
 #pragma unroll
-    for (int v = 0; v < T; ++v) yv[v] = (ok && 16 * v + c < k) ? y[16 * v + c] : 0.f;
-    for (int q = 0; q < n_queries; ++q) {
-      double d = 0.0;
+      for (int v = 0; v < T; ++v) {
+        const float4 t4 = y4[v];
+        yv[4 * v] = t4.x; yv[4 * v + 1] = t4.y; yv[4 * v + 2] = t4.z; yv[4 * v + 3] = t4.w;
+      }
+    } else {
 #pragma unroll
-      for (int v = 0; v < T; ++v) d += (double)__fmul_rn(yv[v], sq[q * 16 * T + 16 * v + c]);
+      for (int s = 0; s < CH; ++s) yv[s] = kk * CH + s < k ? y[s] : 0.f;
+    }
+    f64x4_t acc[TOPN_MAX_QUERIES / 16];
 #pragma unroll
-      for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off);
-      if (ok && c == 0) scores[(int64_t)q * n_items + item] = (float)d;  // RecommendIterator.java:104
+    for (int t = 0; t < TOPN_MAX_QUERIES / 16; ++t) acc[t] = f64x4_t{0., 0., 0., 0.};
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      const double a = ok ? (double)yv[s] : 0.0;
+#pragma unroll
+      for (int t = 0; t < TOPN_MAX_QUERIES / 16; ++t) {
+        if (t < n_tiles) {                                    // wave-uniform
+          const double b = sq[(t * KP + kk * CH + s) * 16 + c];  // lane (kk, c) = feature kk*4T+s, query c
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    // D layout: lane (g = lane>>4, c) reg r = D[row = g + 4r][col = c]: item i0+g+4r, query 16t+c
+#pragma unroll
+    for (int t = 0; t < TOPN_MAX_QUERIES / 16; ++t) {
+      const int q = 16 * t + c;
+      if (t < n_tiles && q < n_queries) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t it = i0 + kk + 4 * r;
+          if (it < n_items) scores[(int64_t)q * n_items + it] = (float)acc[t][r];  // RecommendIterator.java:104
+        }
+      }
     }
   }
 }
