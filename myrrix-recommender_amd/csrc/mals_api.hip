@@ -103,6 +103,8 @@ struct mals_handle_s {
   void* tn_state = nullptr;
   unsigned* tn_hist = nullptr;
   size_t tn_scores_cap = 0, tn_out_cap = 0;
+  float* tn_q = nullptr;       // query vectors of one pass
+  int64_t* tn_qidx = nullptr;  // [2][TOPN_MAX_QUERIES]: user indices, local rows
   int64_t* d_idx = nullptr;  // gather scratch
   float* d_rows = nullptr;
   int32_t idx_cap = 0;
@@ -693,6 +695,8 @@ int mals_destroy(mals_handle h) {
   free_dev(h->tn_out);
   free_dev(h->tn_state);
   free_dev(h->tn_hist);
+  free_dev(h->tn_q);
+  free_dev(h->tn_qidx);
   delete h;
   return MALS_OK;
 }
@@ -1299,11 +1303,10 @@ int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, in
   const int k = h->cfg.features;
   for (int q0 = 0; q0 < n_queries; q0 += TOPN_MAX_QUERIES) {
     const int nq = std::min(TOPN_MAX_QUERIES, n_queries - q0);
-    float* dQ = nullptr;
-    int64_t *d_idx = nullptr, *d_row = nullptr;
-    HIPCHK(h, hipMalloc(&dQ, sizeof(float) * (size_t)nq * k));
-    HIPCHK(h, hipMalloc(&d_idx, sizeof(int64_t) * (size_t)nq));
-    HIPCHK(h, hipMalloc(&d_row, sizeof(int64_t) * (size_t)nq));
+    if (!h->tn_q) HIPCHK(h, hipMalloc(&h->tn_q, sizeof(float) * TOPN_MAX_QUERIES * 128));
+    if (!h->tn_qidx) HIPCHK(h, hipMalloc(&h->tn_qidx, sizeof(int64_t) * 2 * TOPN_MAX_QUERIES));
+    float* dQ = h->tn_q;
+    int64_t *d_idx = h->tn_qidx, *d_row = h->tn_qidx + TOPN_MAX_QUERIES;
     std::vector<int64_t> rows((size_t)nq);
     for (int q = 0; q < nq; ++q) rows[(size_t)q] = consider_known_items ? -1 : user_idx[q0 + q] - x.row_offset;
     hipError_t e = hipMemcpyAsync(d_idx, user_idx + q0, sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, h->stream);
@@ -1316,9 +1319,6 @@ int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, in
     if (rc == MALS_OK)
       rc = topn_batch(h, dQ, d_row, nullptr, nullptr, nq, how_many, item_idx_out + (size_t)q0 * how_many, score_out + (size_t)q0 * how_many,
                       n_out ? n_out + q0 : nullptr);
-    (void)hipFree(dQ);
-    (void)hipFree(d_idx);
-    (void)hipFree(d_row);
     if (rc != MALS_OK) return rc;
   }
   return MALS_OK;
@@ -1338,9 +1338,9 @@ int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_
   const int k = h->cfg.features;
   for (int q0 = 0; q0 < n_queries; q0 += TOPN_MAX_QUERIES) {
     const int nq = std::min(TOPN_MAX_QUERIES, n_queries - q0);
-    float* dQ = nullptr;
+    if (!h->tn_q) HIPCHK(h, hipMalloc(&h->tn_q, sizeof(float) * TOPN_MAX_QUERIES * 128));
+    float* dQ = h->tn_q;
     int64_t *d_ptr = nullptr, *d_ex = nullptr;
-    HIPCHK(h, hipMalloc(&dQ, sizeof(float) * (size_t)nq * k));
     hipError_t e = hipMemcpyAsync(dQ, query_vectors + (size_t)q0 * k, sizeof(float) * (size_t)nq * k, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && exclude_ptr) {
       std::vector<int64_t> ptr((size_t)nq + 1);
@@ -1355,7 +1355,6 @@ int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_
     if (rc == MALS_OK)
       rc = topn_batch(h, dQ, nullptr, d_ptr, d_ex, nq, how_many, item_idx_out + (size_t)q0 * how_many, score_out + (size_t)q0 * how_many,
                       n_out ? n_out + q0 : nullptr);
-    (void)hipFree(dQ);
     if (d_ptr) (void)hipFree(d_ptr);
     if (d_ex) (void)hipFree(d_ex);
     if (rc != MALS_OK) return rc;

@@ -53,11 +53,10 @@ __global__ __launch_bounds__(256) void topn_scores_kernel(const float* __restric
   // (kk, c) takes the CONTIGUOUS quarter [kk*4T, (kk+1)*4T) of item c's row: at k = 64 exactly one
   // 64-byte line per lane, read with T 16-byte loads.  MFMA step s contracts feature kk*4T + s.
   constexpr int CH = 4 * T;
-  for (int64_t i0 = wave * 16; i0 < n_items; i0 += n_waves * 16) {
+  auto load_rows16 = [&](int64_t i0, float (&yv)[CH]) {
     const int64_t item = i0 + c;
     const bool ok = item < n_items;
     const float* y = Y + (ok ? item : 0) * k + kk * CH;
-    float yv[CH];
     if (k == KP) {
       const float4* y4 = reinterpret_cast<const float4*>(y);
 #pragma unroll
@@ -69,6 +68,15 @@ __global__ __launch_bounds__(256) void topn_scores_kernel(const float* __restric
 #pragma unroll
       for (int s = 0; s < CH; ++s) yv[s] = kk * CH + s < k ? y[s] : 0.f;
     }
+  };
+  float ynext[CH];
+  if (wave * 16 < n_items) load_rows16(wave * 16, ynext);
+  for (int64_t i0 = wave * 16; i0 < n_items; i0 += n_waves * 16) {
+    const bool ok = i0 + c < n_items;
+    float yv[CH];
+#pragma unroll
+    for (int s = 0; s < CH; ++s) yv[s] = ynext[s];
+    if (i0 + n_waves * 16 < n_items) load_rows16(i0 + n_waves * 16, ynext);  // next tile's rows fly during the MFMAs
     f64x4_t acc[TOPN_MAX_QUERIES / 16];
 #pragma unroll
     for (int t = 0; t < TOPN_MAX_QUERIES / 16; ++t) acc[t] = f64x4_t{0., 0., 0., 0.};
