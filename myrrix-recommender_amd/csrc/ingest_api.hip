@@ -82,7 +82,6 @@ struct Scratch {
   unsigned* tile_sums = nullptr;  // scan tiles
   unsigned long long* digit_tot = nullptr;  // [8][256]
   unsigned* total = nullptr;      // grand total of a scan
-  int64_t n_alloc = 0, n_waves_alloc = 0, tiles_alloc = 0;
   // all of it is carved out of the ingest object's arena
 };
 

@@ -64,3 +64,20 @@ def test_no_cpu_fallback_without_gpu():
     als = pkg.AlternatingLeastSquares({0: {0: 1.0}}, {0: {0: 1.0}}, 2, 0.001, 1)
     with pytest.raises(pkg.ExecutionException):
         als.call()
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """Host-only argument checks of the section 8(f) entry points (no device work)."""
+    L = _lib.load()
+    g = ctypes.c_void_p()
+    assert L.mals_ingest_create(0, ctypes.c_float(-1.0), ctypes.byref(g)) == _lib.INVALID_ARG     # negative threshold
+    assert L.mals_ingest_create(0, ctypes.c_float(1e-4), None) == _lib.INVALID_ARG
+    assert L.mals_ingest_finish(None) == _lib.INVALID_ARG
+    assert L.mals_ingest_append(None, 0, None, None, None, 0) == _lib.INVALID_ARG
+    assert L.mals_recommend(None, None, 0, 10, 0, None, None, None) == _lib.INVALID_ARG
+    assert L.mals_recommend_vectors(None, None, 0, 10, None, None, None, None, None) == _lib.INVALID_ARG
+    s, c = ctypes.c_double(), ctypes.c_int64()
+    assert L.mals_reconstruction_error(None, ctypes.byref(s), ctypes.byref(c)) == _lib.INVALID_ARG
+    solver, rank = ctypes.c_void_p(), ctypes.c_int32()
+    assert L.mals_solver_create(None, 3, 1e-5, ctypes.byref(solver), ctypes.byref(rank)) == _lib.INVALID_ARG
+    assert L.mals_solver_dim(None) == 0
