@@ -27,6 +27,9 @@ WORKLOADS = {
     "c2": (162_541, 59_047, 25_000_095, 50, "C2 MovieLens-25M shape 162541 x 59047, 25M interactions requested, k=50"),
     "c3": (480_189, 17_770, 100_480_507, 100, "C3 Netflix shape 480189 x 17770, 100M interactions requested, k=100"),
     "c4shard8": (1_250_000, 1_000_000, 125_000_000, 64, "one rank's user rows of C4 at 8 GPUs (1.25M x 1M, 125M interactions requested), k=64"),
+    "c5shard8": (12_500_000, 10_000_000, 625_000_000, 128, "one rank's user rows of C5 at 8 GPUs (12.5M x 10M, 625M interactions requested), k=128"),
+    "k128long": (1_000_000, 100_000, 400_000_000, 128, "k=128 with long rows (1M x 100K, 400M interactions requested)"),
+    "k112": (2_000_000, 200_000, 200_000_000, 112, "k=112 (2M x 200K, 200M interactions requested)"),
     "small": (200_000, 50_000, 10_000_000, 64, "small smoke workload 200K x 50K, 10M interactions requested, k=64"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
