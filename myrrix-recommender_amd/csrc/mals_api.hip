@@ -480,35 +480,93 @@ int launch_reconstruction(mals_handle h, SideState& s, SideState& o, unsigned gr
 
 
 namespace {
-template <int T>
-int launch_topn_scores(mals_handle h, const float* Y, int64_t n_items, const float* dQ, int nq, float* d_scores) {
-  const unsigned grid = (unsigned)std::min<int64_t>((n_items + 63) / 64, (int64_t)h->n_cu * 16);
-  hipLaunchKernelGGL((topn_scores_kernel<T>), dim3(grid), dim3(256), 0, h->stream, Y, n_items, h->cfg.features, dQ, nq, d_scores);
+template <int T, int MODE>
+int launch_topn_scores_T(mals_handle h, const float* Y, int64_t n_items, const float* dQ, int nq, int tile_stride, int64_t n_out,
+                         float* d_scores, TopnState* d_st, int cap, uint32_t* d_cand) {
+  const int64_t tiles = (n_items + 16 * (int64_t)tile_stride - 1) / (16 * (int64_t)tile_stride);
+  int per_cu = 16;
+  if (const char* e = std::getenv("MALS_TOPN_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e));  // tuning override
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, (int64_t)h->n_cu * per_cu));
+#define MALS_TOPN_LAUNCH(NT)                                                                                                 \
+  hipLaunchKernelGGL((topn_scores_kernel<T, MODE, NT>), dim3(grid), dim3(256), 0, h->stream, Y, n_items, h->cfg.features, dQ, nq, \
+                     tile_stride, n_out, d_scores, d_st, cap, d_cand)
+  switch ((nq + 15) / 16) {
+    case 1: MALS_TOPN_LAUNCH(1); break;
+    case 2: MALS_TOPN_LAUNCH(2); break;
+    case 3: MALS_TOPN_LAUNCH(3); break;
+    default: MALS_TOPN_LAUNCH(4); break;
+  }
+#undef MALS_TOPN_LAUNCH
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
 }
+template <int MODE>
+int launch_topn_scores(mals_handle h, const float* Y, int64_t n_items, const float* dQ, int nq, int tile_stride, int64_t n_out,
+                       float* d_scores, TopnState* d_st, int cap, uint32_t* d_cand) {
+  switch (h->T) {
+    case 1: return launch_topn_scores_T<1, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
+    case 2: return launch_topn_scores_T<2, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
+    case 3: return launch_topn_scores_T<3, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
+    case 4: return launch_topn_scores_T<4, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
+    case 5: return launch_topn_scores_T<5, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
+    case 6: return launch_topn_scores_T<6, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
+    case 7: return launch_topn_scores_T<7, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
+    case 8: return launch_topn_scores_T<8, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
+  }
+  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
 
-// Score + mask + select for up to TOPN_MAX_QUERIES query vectors already on the device.
-// query_row (device, may be NULL): local user row whose known items are masked, -1 = none.
-int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const int64_t* d_excl_ptr, const int64_t* d_excl_idx,
-               int nq, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
-  SideState& y = h->side[MALS_SIDE_Y];
-  SideState& x = h->side[MALS_SIDE_X];
-  const int64_t n_items = y.n_total;
-  const int cap_ties = 1024;
-  float* d_scores = nullptr;
-  uint32_t* d_out = nullptr;
-  TopnState* d_st = nullptr;
-  unsigned* d_hist = nullptr;
-  const size_t per_q = 2 * ((size_t)how_many + cap_ties);
-  const size_t out_words = (size_t)nq * per_q;
-  if (h->tn_scores_cap < (size_t)nq * (size_t)n_items) {
+struct TopnCand {
+  uint32_t key;
+  int64_t idx;
+};
+void topn_emit(std::vector<TopnCand>& cand, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
+  // best score first; equal scores in ascending item index (the reference's order among ties is its hash order)
+  std::sort(cand.begin(), cand.end(), [](const TopnCand& a, const TopnCand& b) { return a.key != b.key ? a.key > b.key : a.idx < b.idx; });
+  const int n = (int)std::min<size_t>(cand.size(), (size_t)how_many);
+  if (n_out) *n_out = n;
+  for (int j = 0; j < how_many; ++j) {
+    if (j < n) {
+      const uint32_t kk = cand[(size_t)j].key;
+      const uint32_t bits = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;
+      float f;
+      std::memcpy(&f, &bits, 4);
+      item_idx_out[j] = cand[(size_t)j].idx;
+      score_out[j] = f;
+    } else {
+      item_idx_out[j] = -1;
+      score_out[j] = -std::numeric_limits<float>::infinity();
+    }
+  }
+}
+
+// radix select of the how_many-th best score of every query over score rows of length n_row
+int topn_select_threshold(mals_handle h, const float* d_scores, int64_t n_row, int nq, int how_many, TopnState* d_st, unsigned* d_hist,
+                          unsigned* slabs_out) {
+  std::vector<TopnState> st((size_t)nq, TopnState{0u, (uint32_t)how_many, 0u, 0u});
+  HIPCHK(h, hipMemcpyAsync(d_st, st.data(), sizeof(TopnState) * (size_t)nq, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // st lives on the host stack
+  HIPCHK(h, hipMemsetAsync(d_hist, 0, sizeof(unsigned) * 256 * (size_t)nq, h->stream));
+  // slabs per query: enough workgroups to fill the chip whatever the batch size
+  const unsigned slabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_row + 4095) / 4096, (int64_t)(h->n_cu * 8 + nq - 1) / nq));
+  for (int pass = 0; pass < 4; ++pass) {
+    hipLaunchKernelGGL(topn_hist_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_row, pass, d_st, d_hist);
+    hipLaunchKernelGGL(topn_pick_kernel, dim3((unsigned)nq), dim3(256), 0, h->stream, d_st, d_hist, pass);
+  }
+  HIPCHK(h, hipGetLastError());
+  *slabs_out = slabs;
+  return MALS_OK;
+}
+
+int topn_workspace(mals_handle h, int64_t n_items, int how_many, int cap_ties) {
+  const size_t per_q = 2 * ((size_t)how_many + (size_t)cap_ties);
+  if (h->tn_scores_cap < (size_t)TOPN_MAX_QUERIES * (size_t)n_items) {
     free_dev(h->tn_scores);
     h->tn_scores_cap = 0;
     HIPCHK(h, hipMalloc(&h->tn_scores, sizeof(float) * (size_t)TOPN_MAX_QUERIES * (size_t)n_items));
     h->tn_scores_cap = (size_t)TOPN_MAX_QUERIES * (size_t)n_items;
   }
-  if (h->tn_out_cap < out_words) {
+  if (h->tn_out_cap < (size_t)TOPN_MAX_QUERIES * per_q) {
     free_dev(h->tn_out);
     h->tn_out_cap = 0;
     HIPCHK(h, hipMalloc(&h->tn_out, sizeof(uint32_t) * (size_t)TOPN_MAX_QUERIES * per_q));
@@ -516,56 +574,48 @@ int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const
   }
   if (!h->tn_state) HIPCHK(h, hipMalloc(&h->tn_state, sizeof(TopnState) * TOPN_MAX_QUERIES));
   if (!h->tn_hist) HIPCHK(h, hipMalloc(&h->tn_hist, sizeof(unsigned) * 256 * TOPN_MAX_QUERIES));
-  d_scores = h->tn_scores;
-  d_out = h->tn_out;
-  d_st = (TopnState*)h->tn_state;
-  d_hist = h->tn_hist;
-  int rc = MALS_INVALID_ARG;
-  switch (h->T) {
-    case 1: rc = launch_topn_scores<1>(h, y.F, n_items, dQ, nq, d_scores); break;
-    case 2: rc = launch_topn_scores<2>(h, y.F, n_items, dQ, nq, d_scores); break;
-    case 3: rc = launch_topn_scores<3>(h, y.F, n_items, dQ, nq, d_scores); break;
-    case 4: rc = launch_topn_scores<4>(h, y.F, n_items, dQ, nq, d_scores); break;
-    case 5: rc = launch_topn_scores<5>(h, y.F, n_items, dQ, nq, d_scores); break;
-    case 6: rc = launch_topn_scores<6>(h, y.F, n_items, dQ, nq, d_scores); break;
-    case 7: rc = launch_topn_scores<7>(h, y.F, n_items, dQ, nq, d_scores); break;
-    case 8: rc = launch_topn_scores<8>(h, y.F, n_items, dQ, nq, d_scores); break;
-  }
+  return MALS_OK;
+}
+
+// Exact path: every score is materialised (one row per query), the N-th best found by radix select
+// over the full rows, everything above it and the ties handed back.
+int topn_batch_full(mals_handle h, const float* dQ, const int64_t* d_query_row, const int64_t* d_excl_ptr, const int64_t* d_excl_idx,
+                    int nq, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
+  SideState& y = h->side[MALS_SIDE_Y];
+  SideState& x = h->side[MALS_SIDE_X];
+  const int64_t n_items = y.n_total;
+  const int cap_ties = 1024;
+  if (int rc = topn_workspace(h, n_items, how_many, cap_ties)) return rc;
+  float* d_scores = h->tn_scores;
+  uint32_t* d_out = h->tn_out;
+  TopnState* d_st = (TopnState*)h->tn_state;
+  const size_t per_q = 2 * ((size_t)how_many + cap_ties);
+  const size_t out_words = (size_t)nq * per_q;
+  if (int rc = launch_topn_scores<0>(h, y.F, n_items, dQ, nq, 1, n_items, d_scores, d_st, 0, nullptr)) return rc;
+  if (d_query_row) hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, nq, 1, n_items, d_scores);
+  if (d_excl_ptr) hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, d_excl_ptr, d_excl_idx, nq, n_items, 1, n_items, d_scores);
+  unsigned slabs = 1;
+  if (int rc = topn_select_threshold(h, d_scores, n_items, nq, how_many, d_st, h->tn_hist, &slabs)) return rc;
+  hipLaunchKernelGGL(topn_collect_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, d_st, how_many, cap_ties, d_out);
+  HIPCHK(h, hipGetLastError());
   std::vector<uint32_t> out(out_words);
   std::vector<TopnState> st((size_t)nq);
+  HIPCHK(h, hipMemcpyAsync(out.data(), d_out, sizeof(uint32_t) * out_words, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(st.data(), d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   std::vector<float> row;
-  if (rc == MALS_OK) {
-    for (int q = 0; q < nq; ++q) st[(size_t)q] = TopnState{0u, (uint32_t)how_many, 0u, 0u};
-    hipError_t e = hipMemcpyAsync(d_st, st.data(), sizeof(TopnState) * (size_t)nq, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, sizeof(unsigned) * 256 * (size_t)nq, h->stream);
-    if (d_query_row) hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, nq, n_items, d_scores);
-    if (d_excl_ptr) hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, d_excl_ptr, d_excl_idx, nq, n_items, d_scores);
-    // slabs per query: enough workgroups to fill the chip whatever the batch size
-    const unsigned slabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_items + 4095) / 4096, (int64_t)(h->n_cu * 8 + nq - 1) / nq));
-    for (int pass = 0; pass < 4; ++pass) {
-      hipLaunchKernelGGL(topn_hist_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, pass, d_st, d_hist);
-      hipLaunchKernelGGL(topn_pick_kernel, dim3((unsigned)nq), dim3(256), 0, h->stream, d_st, d_hist, pass);
-    }
-    hipLaunchKernelGGL(topn_collect_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, d_st, how_many, cap_ties, d_out);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, sizeof(uint32_t) * out_words, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(st.data(), d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) rc = fail(h, MALS_HIP_ERROR, hipGetErrorString(e));
-  }
-  for (int q = 0; q < nq && rc == MALS_OK; ++q) {
+  std::vector<TopnCand> cand;
+  for (int q = 0; q < nq; ++q) {
     const uint32_t* o = &out[(size_t)q * per_q];
     const uint32_t above = st[(size_t)q].above, ties_total = st[(size_t)q].ties;
     const uint32_t ties_stored = std::min<uint32_t>(ties_total, (uint32_t)cap_ties);
-    struct Cand { uint32_t key; int64_t idx; };
-    std::vector<Cand> cand;
     const uint32_t need_ties = above < (uint32_t)how_many ? (uint32_t)how_many - above : 0;
-    if (above > (uint32_t)how_many || (ties_stored < ties_total && ties_stored < need_ties) || (ties_stored < ties_total && need_ties > 0)) {
+    cand.clear();
+    if (above > (uint32_t)how_many || (ties_stored < ties_total && need_ties > 0)) {
       // more ties at the N-th score than the selection buffer holds (e.g. a block of identical items): which of
       // them have the lowest indices is not known from an unordered subset -- resolve this query on the host
       row.resize((size_t)n_items);
-      hipError_t e = hipMemcpy(row.data(), d_scores + (size_t)q * (size_t)n_items, sizeof(float) * (size_t)n_items, hipMemcpyDeviceToHost);
-      if (e != hipSuccess) { rc = fail(h, MALS_HIP_ERROR, hipGetErrorString(e)); break; }
+      HIPCHK(h, hipMemcpy(row.data(), d_scores + (size_t)q * (size_t)n_items, sizeof(float) * (size_t)n_items, hipMemcpyDeviceToHost));
       const uint32_t ninf = score_key(-std::numeric_limits<float>::infinity());
       for (int64_t i = 0; i < n_items; ++i) {
         const uint32_t kk = score_key(row[(size_t)i]);
@@ -575,25 +625,76 @@ int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const
       for (uint32_t p = 0; p < above; ++p) cand.push_back({o[2 * p + 1], (int64_t)o[2 * p]});
       for (uint32_t p = 0; p < ties_stored; ++p) cand.push_back({o[2 * (how_many + p) + 1], (int64_t)o[2 * (how_many + p)]});
     }
-    // best score first; equal scores in ascending item index (the reference's order among ties is its hash order)
-    std::sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) { return a.key != b.key ? a.key > b.key : a.idx < b.idx; });
-    const int n = (int)std::min<size_t>(cand.size(), (size_t)how_many);
-    if (n_out) n_out[q] = n;
-    for (int j = 0; j < how_many; ++j) {
-      if (j < n) {
-        const uint32_t kk = cand[(size_t)j].key;
-        const uint32_t bits = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;
-        float f;
-        std::memcpy(&f, &bits, 4);
-        item_idx_out[(size_t)q * how_many + j] = cand[(size_t)j].idx;
-        score_out[(size_t)q * how_many + j] = f;
-      } else {
-        item_idx_out[(size_t)q * how_many + j] = -1;
-        score_out[(size_t)q * how_many + j] = -std::numeric_limits<float>::infinity();
-      }
-    }
+    topn_emit(cand, how_many, item_idx_out + (size_t)q * how_many, score_out + (size_t)q * how_many, n_out ? n_out + q : nullptr);
   }
-  return rc;
+  return MALS_OK;
+}
+
+// Filter path (large catalogues): score rows are never materialised.  A 1/16 sample of the items
+// (every 16th 16-item tile) is scored and radix-selected exactly like above: its N-th best score is a
+// lower bound of the true N-th best.  One pass over all of Y then appends only the (item, score)
+// pairs that reach that bound -- about 16 N of them -- and the host sorts those.  Every item scoring
+// at least the true N-th best is in the list, so the result (ties included) is exact.  *done = false
+// when a candidate list overflowed or the sample was too thin: the caller takes the full path.
+int topn_batch_filter(mals_handle h, const float* dQ, const int64_t* d_query_row, const int64_t* d_excl_ptr, const int64_t* d_excl_idx,
+                      int nq, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out, bool* done) {
+  *done = false;
+  SideState& y = h->side[MALS_SIDE_Y];
+  SideState& x = h->side[MALS_SIDE_X];
+  const int64_t n_items = y.n_total;
+  const int stride = 16;
+  const int64_t n_sample = ((n_items + 16 * stride - 1) / (16 * stride)) * 16;
+  const int cap = 48 * how_many + 2048;  // expected ~16 N candidates; the buffer is (how_many + cap_ties) pairs per query
+  if (int rc = topn_workspace(h, n_items, how_many, cap - how_many)) return rc;
+  float* d_scores = h->tn_scores;
+  uint32_t* d_cand = h->tn_out;
+  TopnState* d_st = (TopnState*)h->tn_state;
+  if (int rc = launch_topn_scores<0>(h, y.F, n_items, dQ, nq, stride, n_sample, d_scores, d_st, 0, nullptr)) return rc;
+  if (d_query_row) hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, nq, stride, n_sample, d_scores);
+  if (d_excl_ptr) hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, d_excl_ptr, d_excl_idx, nq, n_items, stride, n_sample, d_scores);
+  unsigned slabs = 1;
+  if (int rc = topn_select_threshold(h, d_scores, n_sample, nq, how_many, d_st, h->tn_hist, &slabs)) return rc;
+  // st[q].prefix now is the sample's N-th best key (st[q].above still 0: it becomes the candidate counter)
+  if (int rc = launch_topn_scores<1>(h, y.F, n_items, dQ, nq, 1, n_items, nullptr, d_st, cap, d_cand)) return rc;
+  if (d_query_row || d_excl_ptr)
+    hipLaunchKernelGGL(topn_strike_kernel, dim3(16, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, d_excl_ptr, d_excl_idx, nq,
+                       d_st, cap, d_cand);
+  HIPCHK(h, hipGetLastError());
+  std::vector<TopnState> st((size_t)nq);
+  std::vector<uint32_t> out((size_t)nq * 2 * (size_t)cap);
+  HIPCHK(h, hipMemcpyAsync(st.data(), d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out.data(), d_cand, sizeof(uint32_t) * out.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const uint32_t ninf = score_key(-std::numeric_limits<float>::infinity());
+  for (int q = 0; q < nq; ++q)
+    if (st[(size_t)q].above > (uint32_t)cap || st[(size_t)q].prefix <= ninf || st[(size_t)q].remaining > 0x7fffffffu) return MALS_OK;  // overflow / thin sample
+  std::vector<TopnCand> cand;
+  for (int q = 0; q < nq; ++q) {
+    cand.clear();
+    const uint32_t* o = &out[(size_t)q * 2 * (size_t)cap];
+    int valid = 0;
+    for (uint32_t p = 0; p < st[(size_t)q].above; ++p)
+      if (o[2 * p + 1] > ninf) {
+        cand.push_back({o[2 * p + 1], (int64_t)o[2 * p]});
+        ++valid;
+      }
+    if (valid < how_many) return MALS_OK;  // cannot happen with a valid bound; be safe and let the full path answer
+    topn_emit(cand, how_many, item_idx_out + (size_t)q * how_many, score_out + (size_t)q * how_many, n_out ? n_out + q : nullptr);
+  }
+  *done = true;
+  return MALS_OK;
+}
+
+int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const int64_t* d_excl_ptr, const int64_t* d_excl_idx,
+               int nq, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
+  const int64_t n_items = h->side[MALS_SIDE_Y].n_total;
+  // the sample must hold comfortably more than how_many candidates for its N-th best to be a useful bound
+  if (n_items >= 65536 && n_items / 16 >= 64 * (int64_t)how_many && !std::getenv("MALS_TOPN_FULL")) {
+    bool done = false;
+    if (int rc = topn_batch_filter(h, dQ, d_query_row, d_excl_ptr, d_excl_idx, nq, how_many, item_idx_out, score_out, n_out, &done)) return rc;
+    if (done) return MALS_OK;
+  }
+  return topn_batch_full(h, dQ, d_query_row, d_excl_ptr, d_excl_idx, nq, how_many, item_idx_out, score_out, n_out);
 }
 }  // namespace
 

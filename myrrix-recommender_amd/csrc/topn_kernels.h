@@ -34,21 +34,41 @@ __device__ __host__ __forceinline__ uint32_t score_key(float f) {
 // (tests compare at 2 ulp).  A wave owns 16 consecutive items and all query tiles; the queries sit
 // in LDS as doubles in operand order.  Y is read once per batch: HBM-bound (n_items * 4k bytes).
 typedef double f64x4_t __attribute__((ext_vector_type(4)));
-template <int T>
+struct TopnState {
+  uint32_t prefix;     // digits decided so far (in place, high bits); after 4 passes the N-th best key
+  uint32_t remaining;  // rank of the N-th score inside the candidates that match the prefix
+  uint32_t above;      // collected: scores strictly above the N-th (filter path: all candidates)
+  uint32_t ties;       // collected: scores equal to the N-th (all of them counted, cap_ties stored)
+};
+__device__ __forceinline__ uint32_t topn_threshold(const TopnState* st, int q) { return st[q].prefix; }
+__device__ __forceinline__ unsigned topn_append(TopnState* st, int q) { return atomicAdd(&st[q].above, 1u); }
+__device__ __forceinline__ unsigned topn_count(const TopnState* st, int q) { return st[q].above; }
+
+// MODE 0: dense score rows for the 16-item tiles whose index is a multiple of tile_stride
+//         (1 = every item; 16 = the 1/16 sample that yields the filter thresholds), row length n_out;
+// MODE 1: filter -- only (item, score) pairs whose score reaches the query's threshold key are
+//         appended to the query's candidate list (st[q].above counts them, also past the capacity).
+// NT = query tiles of 16 (compile time: the MFMA block below is straight-line code; a wave-uniform
+// runtime test per MFMA made the fully unrolled kernel 2x slower).
+template <int T, int MODE, int NT>
 __global__ __launch_bounds__(256) void topn_scores_kernel(const float* __restrict__ Y, int64_t n_items, int k,
-                                                          const float* __restrict__ Q, int n_queries,
-                                                          float* __restrict__ scores) {  // [n_queries][n_items]
+                                                          const float* __restrict__ Q, int n_queries, int tile_stride,
+                                                          int64_t n_out, float* __restrict__ scores,  // MODE 0: [n_queries][n_out]
+                                                          TopnState* __restrict__ st, int cap, uint32_t* __restrict__ cand) {
   constexpr int KP = 16 * T;                                  // padded feature count
-  __shared__ double sq[(TOPN_MAX_QUERIES / 16) * KP * 16];    // [query tile][feature][query in tile]
-  const int n_tiles = (n_queries + 15) >> 4;
+  __shared__ double sq[NT * KP * 16];                          // [query tile][feature][query in tile]
+  constexpr int n_tiles = NT;
   for (int i = threadIdx.x; i < n_tiles * KP * 16; i += 256) {
     const int j = i & 15, f = (i >> 4) % KP, qt = i / (16 * KP);
     const int q = 16 * qt + j;
     sq[i] = (q < n_queries && f < k) ? (double)Q[(int64_t)q * k + f] : 0.0;
   }
+  __shared__ uint32_t sthr[TOPN_MAX_QUERIES];
+  if (MODE == 1 && threadIdx.x < TOPN_MAX_QUERIES) sthr[threadIdx.x] = threadIdx.x < n_queries ? topn_threshold(st, threadIdx.x) : 0xffffffffu;
   __syncthreads();
   const int lane = threadIdx.x & 63, kk = lane >> 4, c = lane & 15;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+  const int64_t step = (int64_t)tile_stride * 16;             // items between processed tiles
   // The order of the features inside the contraction is free (it only moves fp64 rounding), so lane
   // (kk, c) takes the CONTIGUOUS quarter [kk*4T, (kk+1)*4T) of item c's row: at k = 64 exactly one
   // 64-byte line per lane, read with T 16-byte loads.  MFMA step s contracts feature kk*4T + s.
@@ -70,36 +90,47 @@ __global__ __launch_bounds__(256) void topn_scores_kernel(const float* __restric
     }
   };
   float ynext[CH];
-  if (wave * 16 < n_items) load_rows16(wave * 16, ynext);
-  for (int64_t i0 = wave * 16; i0 < n_items; i0 += n_waves * 16) {
+  if (wave * step < n_items) load_rows16(wave * step, ynext);
+  for (int64_t i0 = wave * step; i0 < n_items; i0 += n_waves * step) {
     const bool ok = i0 + c < n_items;
     float yv[CH];
 #pragma unroll
     for (int s = 0; s < CH; ++s) yv[s] = ynext[s];
-    if (i0 + n_waves * 16 < n_items) load_rows16(i0 + n_waves * 16, ynext);  // next tile's rows fly during the MFMAs
-    f64x4_t acc[TOPN_MAX_QUERIES / 16];
+    if (i0 + n_waves * step < n_items) load_rows16(i0 + n_waves * step, ynext);  // next tile's rows fly during the MFMAs
+    f64x4_t acc[NT];
 #pragma unroll
-    for (int t = 0; t < TOPN_MAX_QUERIES / 16; ++t) acc[t] = f64x4_t{0., 0., 0., 0.};
+    for (int t = 0; t < NT; ++t) acc[t] = f64x4_t{0., 0., 0., 0.};
 #pragma unroll
     for (int s = 0; s < CH; ++s) {
       const double a = ok ? (double)yv[s] : 0.0;
 #pragma unroll
-      for (int t = 0; t < TOPN_MAX_QUERIES / 16; ++t) {
-        if (t < n_tiles) {                                    // wave-uniform
-          const double b = sq[(t * KP + kk * CH + s) * 16 + c];  // lane (kk, c) = feature kk*4T+s, query c
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-        }
+      for (int t = 0; t < NT; ++t) {
+        const double b = sq[(t * KP + kk * CH + s) * 16 + c];  // lane (kk, c) = feature kk*4T+s, query c
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
       }
     }
     // D layout: lane (g = lane>>4, c) reg r = D[row = g + 4r][col = c]: item i0+g+4r, query 16t+c
 #pragma unroll
-    for (int t = 0; t < TOPN_MAX_QUERIES / 16; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int q = 16 * t + c;
-      if (t < n_tiles && q < n_queries) {
+      if (q < n_queries) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t it = i0 + kk + 4 * r;
-          if (it < n_items) scores[(int64_t)q * n_items + it] = (float)acc[t][r];  // RecommendIterator.java:104
+          if (it >= n_items) continue;
+          const float sc = (float)acc[t][r];                  // RecommendIterator.java:104
+          if (MODE == 0) {
+            scores[(int64_t)q * n_out + (i0 / step) * 16 + kk + 4 * r] = sc;
+          } else {
+            const uint32_t key = score_key(sc);
+            if (key >= sthr[q]) {
+              const unsigned p = topn_append(st, q);
+              if ((int)p < cap) {
+                cand[((int64_t)q * cap + p) * 2] = (uint32_t)it;
+                cand[((int64_t)q * cap + p) * 2 + 1] = key;
+              }
+            }
+          }
         }
       }
     }
@@ -107,26 +138,61 @@ __global__ __launch_bounds__(256) void topn_scores_kernel(const float* __restric
 }
 
 // known items of the query's user are never recommended (RecommendIterator.java:75-82)
+// position of an item in a score row that holds every tile_stride-th 16-item tile (-1: not in it)
+__device__ __forceinline__ int64_t topn_row_slot(int64_t item, int tile_stride) {
+  const int64_t tile = item >> 4;
+  return tile % tile_stride ? -1 : (tile / tile_stride) * 16 + (item & 15);
+}
 __global__ void topn_mask_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                                 const int64_t* __restrict__ query_row, int n_queries, int64_t n_items,
+                                 const int64_t* __restrict__ query_row, int n_queries, int tile_stride, int64_t n_out,
                                  float* __restrict__ scores) {
   const int q = blockIdx.y;
   if (q >= n_queries) return;
   const int64_t r = query_row[q];
   if (r < 0) return;
   const int64_t b = row_ptr[r], e = row_ptr[r + 1];
-  for (int64_t i = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x)
-    scores[(int64_t)q * n_items + col[i]] = -__builtin_huge_valf();
+  for (int64_t i = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t slot = topn_row_slot(col[i], tile_stride);
+    if (slot >= 0) scores[(int64_t)q * n_out + slot] = -__builtin_huge_valf();
+  }
 }
 // caller-supplied exclusion lists (anonymous users: the items they were built from, SR:561-606)
 __global__ void topn_exclude_kernel(const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx, int n_queries,
-                                    int64_t n_items, float* __restrict__ scores) {
+                                    int64_t n_items, int tile_stride, int64_t n_out, float* __restrict__ scores) {
   const int q = blockIdx.y;
   if (q >= n_queries) return;
   const int64_t b = excl_ptr[q], e = excl_ptr[q + 1];
   for (int64_t i = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t it = excl_idx[i];
-    if (it >= 0 && it < n_items) scores[(int64_t)q * n_items + it] = -__builtin_huge_valf();
+    const int64_t slot = (it >= 0 && it < n_items) ? topn_row_slot(it, tile_stride) : -1;
+    if (slot >= 0) scores[(int64_t)q * n_out + slot] = -__builtin_huge_valf();
+  }
+}
+// Filter path: candidates that are known / excluded items are struck out (key 0 never qualifies).
+// One workgroup row per query; a query has a few hundred candidates, so every list entry is compared
+// against all of them.
+__global__ __launch_bounds__(256) void topn_strike_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                                          const int64_t* __restrict__ query_row,
+                                                          const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx,
+                                                          int n_queries, const TopnState* __restrict__ st, int cap,
+                                                          uint32_t* __restrict__ cand) {
+  const int q = blockIdx.y;
+  if (q >= n_queries) return;
+  int64_t b = 0, e = 0;
+  const int64_t* list64 = nullptr;
+  const int32_t* list32 = nullptr;
+  if (query_row) {
+    const int64_t r = query_row[q];
+    if (r >= 0) { b = row_ptr[r]; e = row_ptr[r + 1]; list32 = col; }
+  } else if (excl_ptr) {
+    b = excl_ptr[q]; e = excl_ptr[q + 1]; list64 = excl_idx;
+  }
+  const unsigned n_c = topn_count(st, q) < (unsigned)cap ? topn_count(st, q) : (unsigned)cap;
+  uint32_t* cq = cand + (int64_t)q * cap * 2;
+  for (int64_t i = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t it = list32 ? (int64_t)list32[i] : list64[i];
+    for (unsigned p = 0; p < n_c; ++p)
+      if ((int64_t)cq[2 * p] == it) cq[2 * p + 1] = 0u;
   }
 }
 
@@ -134,12 +200,6 @@ __global__ void topn_exclude_kernel(const int64_t* __restrict__ excl_ptr, const 
 // found by a 4-pass radix select, most significant digit first; every pass is one grid-wide scan of
 // the score rows (grid = slabs x queries) into the per-query histogram, followed by a one-thread-per-
 // query pick of the digit in which the N-th score lies.  -inf scores (masked items) never qualify.
-struct TopnState {
-  uint32_t prefix;     // digits decided so far (in place, high bits)
-  uint32_t remaining;  // rank of the N-th score inside the candidates that match the prefix
-  uint32_t above;      // collected: scores strictly above the N-th
-  uint32_t ties;       // collected: scores equal to the N-th (all of them counted, cap_ties stored)
-};
 
 __global__ __launch_bounds__(256) void topn_hist_kernel(const float* __restrict__ scores, int64_t n_items, int pass,
                                                         const TopnState* __restrict__ st, unsigned* __restrict__ hist) {

@@ -96,3 +96,62 @@ def test_argument_checks():
             core.recommend(np.array([7], np.int64), 5, consider_known_items=True)
         idx, sc, cnt = core.recommend(np.array([1], np.int64), 5, consider_known_items=True)
         assert cnt[0] == 3                                            # three items, all scoring 0
+
+
+# ---- large catalogues: the threshold-filter path (1/16 sample -> bound -> one filtered pass over Y) ------
+def big_core(k, n_items, n_users, deg, seed):
+    rng = np.random.default_rng(seed)
+    Y = (rng.standard_normal((n_items, k)) / np.sqrt(k)).astype(np.float32)
+    X = (rng.standard_normal((n_users, k)) / np.sqrt(k)).astype(np.float32)
+    rp = np.arange(n_users + 1, dtype=np.int64) * deg
+    col = np.concatenate([np.sort(rng.choice(n_items, deg, replace=False)) for _ in range(n_users)]).astype(np.int32)
+    core = pkg.ALSCore(k)
+    core.set_factor_rows(pkg.SIDE_X, n_users)
+    core.set_factor_rows(pkg.SIDE_Y, n_items)
+    core.set_factors(pkg.SIDE_X, X)
+    core.set_factors(pkg.SIDE_Y, Y)
+    core.set_matrix(pkg.SIDE_X, rp, col, np.ones(len(col), np.float32))
+    return core, X, Y, rp, col
+
+
+@pytest.mark.parametrize("k,n_items,how_many", [(64, 100_000, 10), (16, 300_000, 50), (100, 70_000, 5)])
+def test_filter_path_matches_oracle(k, n_items, how_many):
+    core, X, Y, rp, col = big_core(k, n_items, 70, 300, 11 + k)
+    with core:
+        users = np.arange(70, dtype=np.int64)
+        idx, sc, cnt = core.recommend(users, how_many)
+        idx2, sc2, _ = core.recommend(users, how_many, consider_known_items=True)
+        for q in (0, 1, 33, 63, 64, 69):
+            known = col[rp[q]:rp[q + 1]]
+            oidx, osc = to.recommend(Y, X[q], how_many, known)
+            assert cnt[q] == how_many
+            same_ranking(idx[q], sc[q], oidx, osc)
+            assert not set(idx[q].tolist()) & set(known.tolist())
+            oidx, osc = to.recommend(Y, X[q], how_many)
+            same_ranking(idx2[q], sc2[q], oidx, osc)
+
+
+def test_filter_path_equals_full_path(monkeypatch):
+    core, X, Y, rp, col = big_core(32, 120_000, 20, 500, 3)
+    with core:
+        users = np.arange(20, dtype=np.int64)
+        a = core.recommend(users, 25)
+        monkeypatch.setenv("MALS_TOPN_FULL", "1")
+        b = core.recommend(users, 25)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_filter_path_with_massive_ties_and_exclusions():
+    k, n_items = 8, 200_000
+    Y = np.zeros((n_items, k), np.float32)
+    Y[:, 0] = (np.arange(n_items) % 7).astype(np.float32)             # 7 distinct scores, ~28K items each
+    with pkg.ALSCore(k) as core:
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_factors(pkg.SIDE_Y, Y)
+        q = np.zeros((2, k), np.float32)
+        q[:, 0] = 1.0
+        excl = [[6, 13, 20], []]                                       # the three lowest-index items scoring 6
+        idx, sc, cnt = core.recommend_vectors(q, 12, exclude=excl)
+        for j in range(2):
+            oidx, osc = to.recommend(Y, q[j], 12, excl[j])
+            assert np.array_equal(idx[j], oidx) and np.array_equal(sc[j], osc)
