@@ -103,6 +103,8 @@ struct mals_handle_s {
   void* tn_state = nullptr;
   unsigned* tn_hist = nullptr;
   size_t tn_scores_cap = 0, tn_out_cap = 0;
+  uint32_t* tn_host = nullptr;  // pinned staging for the selection results
+  size_t tn_host_words = 0;
   float* tn_q = nullptr;       // query vectors of one pass
   int64_t* tn_qidx = nullptr;  // [2][TOPN_MAX_QUERIES]: user indices, local rows
   int64_t* d_idx = nullptr;  // gather scratch
@@ -543,10 +545,7 @@ void topn_emit(std::vector<TopnCand>& cand, int how_many, int64_t* item_idx_out,
 // radix select of the how_many-th best score of every query over score rows of length n_row
 int topn_select_threshold(mals_handle h, const float* d_scores, int64_t n_row, int nq, int how_many, TopnState* d_st, unsigned* d_hist,
                           unsigned* slabs_out) {
-  std::vector<TopnState> st((size_t)nq, TopnState{0u, (uint32_t)how_many, 0u, 0u});
-  HIPCHK(h, hipMemcpyAsync(d_st, st.data(), sizeof(TopnState) * (size_t)nq, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // st lives on the host stack
-  HIPCHK(h, hipMemsetAsync(d_hist, 0, sizeof(unsigned) * 256 * (size_t)nq, h->stream));
+  hipLaunchKernelGGL(topn_init_kernel, dim3((unsigned)((nq * 256 + 255) / 256)), dim3(256), 0, h->stream, d_st, d_hist, nq, how_many);
   // slabs per query: enough workgroups to fill the chip whatever the batch size
   const unsigned slabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_row + 4095) / 4096, (int64_t)(h->n_cu * 8 + nq - 1) / nq));
   for (int pass = 0; pass < 4; ++pass) {
@@ -571,6 +570,14 @@ int topn_workspace(mals_handle h, int64_t n_items, int how_many, int cap_ties) {
     h->tn_out_cap = 0;
     HIPCHK(h, hipMalloc(&h->tn_out, sizeof(uint32_t) * (size_t)TOPN_MAX_QUERIES * per_q));
     h->tn_out_cap = (size_t)TOPN_MAX_QUERIES * per_q;
+  }
+  const size_t host_words = (size_t)TOPN_MAX_QUERIES * (per_q + 4);
+  if (h->tn_host_words < host_words) {
+    if (h->tn_host) (void)hipHostFree(h->tn_host);
+    h->tn_host = nullptr;
+    h->tn_host_words = 0;
+    HIPCHK(h, hipHostMalloc(&h->tn_host, sizeof(uint32_t) * host_words));
+    h->tn_host_words = host_words;
   }
   if (!h->tn_state) HIPCHK(h, hipMalloc(&h->tn_state, sizeof(TopnState) * TOPN_MAX_QUERIES));
   if (!h->tn_hist) HIPCHK(h, hipMalloc(&h->tn_hist, sizeof(unsigned) * 256 * TOPN_MAX_QUERIES));
@@ -598,10 +605,10 @@ int topn_batch_full(mals_handle h, const float* dQ, const int64_t* d_query_row, 
   if (int rc = topn_select_threshold(h, d_scores, n_items, nq, how_many, d_st, h->tn_hist, &slabs)) return rc;
   hipLaunchKernelGGL(topn_collect_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, d_st, how_many, cap_ties, d_out);
   HIPCHK(h, hipGetLastError());
-  std::vector<uint32_t> out(out_words);
-  std::vector<TopnState> st((size_t)nq);
-  HIPCHK(h, hipMemcpyAsync(out.data(), d_out, sizeof(uint32_t) * out_words, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(st.data(), d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+  uint32_t* out = h->tn_host;
+  TopnState* st = reinterpret_cast<TopnState*>(h->tn_host + (size_t)TOPN_MAX_QUERIES * per_q);
+  HIPCHK(h, hipMemcpyAsync(out, d_out, sizeof(uint32_t) * out_words, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(st, d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   std::vector<float> row;
   std::vector<TopnCand> cand;
@@ -660,10 +667,10 @@ int topn_batch_filter(mals_handle h, const float* dQ, const int64_t* d_query_row
     hipLaunchKernelGGL(topn_strike_kernel, dim3(16, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, d_excl_ptr, d_excl_idx, nq,
                        d_st, cap, d_cand);
   HIPCHK(h, hipGetLastError());
-  std::vector<TopnState> st((size_t)nq);
-  std::vector<uint32_t> out((size_t)nq * 2 * (size_t)cap);
-  HIPCHK(h, hipMemcpyAsync(st.data(), d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(out.data(), d_cand, sizeof(uint32_t) * out.size(), hipMemcpyDeviceToHost, h->stream));
+  uint32_t* out = h->tn_host;
+  TopnState* st = reinterpret_cast<TopnState*>(h->tn_host + (size_t)TOPN_MAX_QUERIES * 2 * (size_t)cap);
+  HIPCHK(h, hipMemcpyAsync(st, d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out, d_cand, sizeof(uint32_t) * (size_t)nq * 2 * (size_t)cap, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const uint32_t ninf = score_key(-std::numeric_limits<float>::infinity());
   for (int q = 0; q < nq; ++q)
@@ -807,6 +814,7 @@ int mals_destroy(mals_handle h) {
   free_dev(h->tn_hist);
   free_dev(h->tn_q);
   free_dev(h->tn_qidx);
+  if (h->tn_host) (void)hipHostFree(h->tn_host);
   delete h;
   return MALS_OK;
 }

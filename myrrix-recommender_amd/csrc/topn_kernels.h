@@ -201,6 +201,12 @@ __global__ __launch_bounds__(256) void topn_strike_kernel(const int64_t* __restr
 // the score rows (grid = slabs x queries) into the per-query histogram, followed by a one-thread-per-
 // query pick of the digit in which the N-th score lies.  -inf scores (masked items) never qualify.
 
+__global__ void topn_init_kernel(TopnState* __restrict__ st, unsigned* __restrict__ hist, int n_queries, int how_many) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_queries) st[i] = TopnState{0u, (uint32_t)how_many, 0u, 0u};
+  if (i < n_queries * 256) hist[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void topn_hist_kernel(const float* __restrict__ scores, int64_t n_items, int pass,
                                                         const TopnState* __restrict__ st, unsigned* __restrict__ hist) {
   __shared__ unsigned h[256];
