@@ -54,6 +54,7 @@ def check_half(core, side, csr, M_host, G, n_rows, rng, torch, n_sample=300, n_l
 
 @pytest.mark.parametrize("name,n_users,n_items,nnz,k", [
     ("C2 MovieLens-25M shape", 162_541, 59_047, 25_000_095, 50),
+    ("C3 Netflix-Prize shape", 480_189, 17_770, 100_480_507, 100),
     ("C4 synthetic 10M x 1M", 10_000_000, 1_000_000, 1_000_000_000, 64),
 ])
 def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
@@ -99,8 +100,8 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
         core.solve_side(pkg.SIDE_Y)
         core.check()
         max_len_y = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, Gx, n_items, rng, torch)
-        if "C4" in name:
-            assert max_len_y > 4096, "C4 must exercise the long-row (segments) path"
+        if "C4" in name or "C3" in name:
+            assert max_len_y > 4096, "C3 / C4 must exercise the long-row (segments) path"
         Y = core.get_factors(pkg.SIDE_Y)
         assert np.all(np.isfinite(Y))
         # a solved factor matrix is not degenerate
