@@ -35,9 +35,9 @@ struct mals_ingest_s {
   int64_t* ptr[2] = {nullptr, nullptr};      // CSR row pointers (side X: by user, side Y: by item)
   int32_t* col[2] = {nullptr, nullptr};
   float* val[2] = {nullptr, nullptr};
-  // sort/scan workspace, kept between finishes (hipMalloc of tens of GB is slow).  One allocation per
-  // buffer: a single 52 GB arena was measured 2.6x slower to WORK in than ten separate buffers (the
-  // driver backs huge allocations with smaller fragments once memory has been recycled).
+  // sort/scan workspace, kept between finishes, one allocation per buffer.  On some boxes a fresh
+  // hipMalloc of tens of GB takes 1-1.5 s and returns memory in which this pipeline runs ~2x slower
+  // (driver memory placement, not under the library's control); workspace_ms reports the former.
   static constexpr int N_WS = 12;
   void* ws[N_WS] = {};
   size_t ws_bytes[N_WS] = {};
@@ -298,11 +298,11 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
   }
   ICHK(g, hipEventRecord(e0, g->stream));  // the pipeline proper starts here
   // 1. records sorted by item id (stable: stream order inside an item); dense item rank of every position
-  hipLaunchKernelGGL(id_keys_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_item, n, s.keys[0], s.pay[0]);
+  hipLaunchKernelGGL(item_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_item, g->d_value, n, s.keys[0], s.pay64[0]);
   ICHK(g, hipGetLastError());
-  g->bytes_moved += 20.0 * (double)n;
+  g->bytes_moved += 28.0 * (double)n;
   int ra = 0;
-  if (int rc = radix_sort(g, s, s.pay, n, &ra)) return rc;
+  if (int rc = radix_sort(g, s, s.pay64, n, &ra)) return rc;
   hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[ra], n, t.head);
   ICHK(g, hipGetLastError());
   if (int rc = scan_u32(g, s, t.head, t.scan, n, &n_i_all)) return rc;
@@ -311,10 +311,11 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
                      t.iid_all);
   // 2. ... then by user id (stable again): the records are now ordered by (user, item, stream order) --
   //    one sort of the composite key, with the item rank and the record index riding along
-  hipLaunchKernelGGL(user_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_user, s.pay[ra], t.ri, n, s.keys[0],
+  // (reads pay64[ra][i] and writes pay64[0][i]: the same thread, the same index -- safe when ra == 0)
+  hipLaunchKernelGGL(user_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_user, s.pay64[ra], t.ri, n, s.keys[0],
                      s.pay64[0]);
   ICHK(g, hipGetLastError());
-  g->bytes_moved += (12.0 + 4.0 + 12.0 + 4.0 + 8.0 + 4.0 + 16.0) * (double)n;
+  g->bytes_moved += (12.0 + 4.0 + 12.0 + 8.0 + 8.0 + 4.0 + 16.0) * (double)n;
   int rb = 0;
   if (int rc = radix_sort(g, s, s.pay64, n, &rb)) return rc;
   hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[rb], n, t.head);
@@ -323,8 +324,9 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
   ICHK(g, hipMalloc(&t.uid_all, sizeof(int64_t) * (size_t)n_u_all));
   // 3. pair keys (user rank << 32 | item rank) and record indices in that order
   const int r = 1 - rb;  // the other key buffer is free now
+  float* sorted_val = reinterpret_cast<float*>(s.pay[0]);
   hipLaunchKernelGGL(pair_from_sorted_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[rb], s.pay64[rb], t.head, t.scan, n,
-                     s.keys[r], s.pay[r], t.uid_all);
+                     s.keys[r], sorted_val, t.uid_all);
   ICHK(g, hipGetLastError());
   g->bytes_moved += (12.0 + 4.0 + 16.0 + 8.0 + 12.0) * (double)n;
   // 4. replay every pair's records in order
@@ -334,10 +336,10 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
   ICHK(g, hipMalloc(&t.new_i, sizeof(unsigned) * (size_t)n_i_all));
   ICHK(g, hipMemsetAsync(t.alive_u, 0, sizeof(unsigned) * (size_t)n_u_all, g->stream));
   ICHK(g, hipMemsetAsync(t.alive_i, 0, sizeof(unsigned) * (size_t)n_i_all, g->stream));
-  hipLaunchKernelGGL(replay_pairs_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], s.pay[r], g->d_value, n,
-                     g->zero_threshold, t.keep, t.pair_val, t.alive_u, t.alive_i);
+  hipLaunchKernelGGL(replay_pairs_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], sorted_val, n, g->zero_threshold,
+                     t.keep, t.pair_val, t.alive_u, t.alive_i);
   ICHK(g, hipGetLastError());
-  g->bytes_moved += (8.0 + 4.0 + 4.0 + 8.0) * (double)n;
+  g->bytes_moved += (8.0 + 4.0 + 8.0) * (double)n;
   // 5. ids that still own an entry, renumbered densely (ascending id)
   if (int rc = scan_u32(g, s, t.alive_u, t.new_u, n_u_all, &n_users)) return rc;
   if (int rc = scan_u32(g, s, t.alive_i, t.new_i, n_i_all, &n_items)) return rc;
@@ -357,16 +359,16 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
   // 7. the transposed matrix: the entries are sorted by (user, item); a STABLE sort on the item half of
   //    the key alone leaves the users ascending inside every item, so the four low digits are not sorted
   if (nnz > 0) {
-    hipLaunchKernelGGL(transpose_keys_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, t.coo_row, g->col[0], (int64_t)nnz,
-                       s.keys[0], s.pay[0]);
+    hipLaunchKernelGGL(transpose_keys_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, t.coo_row, g->col[0], g->val[0],
+                       (int64_t)nnz, s.keys[0], s.pay[0]);
     ICHK(g, hipGetLastError());
-    g->bytes_moved += 20.0 * (double)nnz;
+    g->bytes_moved += 24.0 * (double)nnz;
     int r2 = 0;
     if (int rc = radix_sort(g, s, s.pay, (int64_t)nnz, &r2, 4)) return rc;
-    hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], g->val[0],
-                       (int64_t)nnz, t.coo_row, g->col[1], g->val[1]);
+    hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], (int64_t)nnz,
+                       t.coo_row, g->col[1], g->val[1]);
     ICHK(g, hipGetLastError());
-    g->bytes_moved += 28.0 * (double)nnz;
+    g->bytes_moved += 24.0 * (double)nnz;
   }
   hipLaunchKernelGGL(row_ptr_from_sorted_kernel, dim3(blocks_for((int64_t)nnz + 1)), dim3(256), 0, g->stream, t.coo_row, (int64_t)nnz,
                      (int64_t)n_items, g->ptr[1]);

@@ -250,10 +250,14 @@ __global__ __launch_bounds__(256) void scan_add_kernel(unsigned* __restrict__ ou
 __device__ __host__ __forceinline__ uint64_t id_to_key(int64_t id) { return (uint64_t)id ^ 0x8000000000000000ull; }
 __device__ __host__ __forceinline__ int64_t key_to_id(uint64_t k) { return (int64_t)(k ^ 0x8000000000000000ull); }
 
-__global__ void id_keys_kernel(const int64_t* __restrict__ ids, int64_t n, uint64_t* __restrict__ keys, unsigned* __restrict__ pay) {
+// first stage of the composite sort: key = item id, payload = (value bits << 32 | record index): the
+// value rides along through both stages, so nothing has to be gathered by record index later except
+// the user id
+__global__ void item_stage_kernel(const int64_t* __restrict__ item_ids, const float* __restrict__ values, int64_t n,
+                                  uint64_t* __restrict__ keys, uint64_t* __restrict__ pay) {
   MALS_GRID_STRIDE(i, n) {
-    keys[i] = id_to_key(ids[i]);
-    pay[i] = (unsigned)i;
+    keys[i] = id_to_key(item_ids[i]);
+    pay[i] = ((uint64_t)__float_as_uint(values[i]) << 32) | (uint64_t)i;
   }
 }
 // head[i] = 1 where a new key starts in a sorted key array
@@ -271,25 +275,25 @@ __global__ void position_ranks_kernel(const uint64_t* __restrict__ keys, const u
   }
 }
 // second stage of the composite sort: key = the record's user id (gathered through the item-sorted
-// permutation), payload = (item rank << 32 | record index)
-__global__ void user_stage_kernel(const int64_t* __restrict__ user_ids, const unsigned* __restrict__ idx,
+// permutation), payload = (item rank << 32 | value bits)
+__global__ void user_stage_kernel(const int64_t* __restrict__ user_ids, const uint64_t* __restrict__ pay_a,
                                   const unsigned* __restrict__ item_rank, int64_t n, uint64_t* __restrict__ keys,
                                   uint64_t* __restrict__ pay) {
   MALS_GRID_STRIDE(i, n) {
-    const unsigned j = idx[i];
-    keys[i] = id_to_key(user_ids[j]);
-    pay[i] = ((uint64_t)item_rank[i] << 32) | j;
+    const uint64_t pa = pay_a[i];
+    keys[i] = id_to_key(user_ids[(unsigned)(pa & 0xffffffffu)]);
+    pay[i] = ((uint64_t)item_rank[i] << 32) | (pa >> 32);
   }
 }
-// (user id, item rank, stream order) sorted records -> the pair keys and record indices replay_pairs wants
+// (user id, item rank, stream order) sorted records -> the pair keys and values replay_pairs wants
 __global__ void pair_from_sorted_kernel(const uint64_t* __restrict__ ukeys, const uint64_t* __restrict__ pay,
                                         const unsigned* __restrict__ head, const unsigned* __restrict__ head_scan, int64_t n,
-                                        uint64_t* __restrict__ pair_keys, unsigned* __restrict__ idx,
+                                        uint64_t* __restrict__ pair_keys, float* __restrict__ sorted_val,
                                         int64_t* __restrict__ user_table) {
   MALS_GRID_STRIDE(i, n) {
     const unsigned ru = head_scan[i] + head[i] - 1;
     pair_keys[i] = ((uint64_t)ru << 32) | (pay[i] >> 32);
-    idx[i] = (unsigned)(pay[i] & 0xffffffffu);
+    sorted_val[i] = __uint_as_float((unsigned)(pay[i] & 0xffffffffu));
     if (head[i]) user_table[ru] = key_to_id(ukeys[i]);
   }
 }
@@ -297,8 +301,8 @@ __global__ void pair_from_sorted_kernel(const uint64_t* __restrict__ ukeys, cons
 // the pair's records in stream order exactly as the reference does (IFR:165-171): NaN removes the
 // entry (MU:102-125), a value starts it or is added to it in fp32 (FBIFM:129-138).  Marks the ids
 // that own a live entry (MU:81-92: a row exists while it has entries).
-__global__ void replay_pairs_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
-                                    const float* __restrict__ values, int64_t n, float zero_threshold,
+__global__ void replay_pairs_kernel(const uint64_t* __restrict__ keys, const float* __restrict__ values,  // both in sorted order
+                                    int64_t n, float zero_threshold,
                                     unsigned* __restrict__ keep, float* __restrict__ pair_val,
                                     unsigned* __restrict__ user_alive, unsigned* __restrict__ item_alive) {
   MALS_GRID_STRIDE(i, n) {
@@ -308,7 +312,7 @@ __global__ void replay_pairs_kernel(const uint64_t* __restrict__ keys, const uns
     bool present = false;
     float v = 0.f;
     for (int64_t t = i; t < n && keys[t] == k; ++t) {
-      const float x = values[pay[t]];
+      const float x = values[t];
       if (x != x) {
         present = false;
       } else if (!present) {
@@ -355,20 +359,21 @@ __global__ void row_ptr_from_sorted_kernel(const int32_t* __restrict__ row, int6
     for (int64_t r = lo; r <= hi; ++r) ptr[r] = p;
   }
 }
-__global__ void transpose_keys_kernel(const int32_t* __restrict__ row, const int32_t* __restrict__ col, int64_t nnz,
-                                      uint64_t* __restrict__ keys, unsigned* __restrict__ pay) {
+__global__ void transpose_keys_kernel(const int32_t* __restrict__ row, const int32_t* __restrict__ col,
+                                      const float* __restrict__ val, int64_t nnz, uint64_t* __restrict__ keys,
+                                      unsigned* __restrict__ pay) {
   MALS_GRID_STRIDE(i, nnz) {
     keys[i] = ((uint64_t)(uint32_t)col[i] << 32) | (uint32_t)row[i];
-    pay[i] = (unsigned)i;
+    pay[i] = __float_as_uint(val[i]);  // the value rides along: no gather after the sort
   }
 }
 __global__ void transpose_gather_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay,
-                                        const float* __restrict__ val, int64_t nnz, int32_t* __restrict__ t_row,
-                                        int32_t* __restrict__ t_col, float* __restrict__ t_val) {
+                                        int64_t nnz, int32_t* __restrict__ t_row, int32_t* __restrict__ t_col,
+                                        float* __restrict__ t_val) {
   MALS_GRID_STRIDE(i, nnz) {
     t_row[i] = (int32_t)(keys[i] >> 32);          // the item index
     t_col[i] = (int32_t)(keys[i] & 0xffffffffu);  // the user index
-    t_val[i] = val[pay[i]];
+    t_val[i] = __uint_as_float(pay[i]);
   }
 }
 
