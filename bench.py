@@ -202,7 +202,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": desc, "users": n_users, "items": n_items, "nnz": int(prob["nnz"]), "features": k,
-                       "alpha": 1.0, "lambda": 0.1, "sharding": "rows x%d, %s all-gather + kxk all-reduce" % (world, "in-place" if chunk_rows == 0 else "chunked (%d rows) pipelined" % chunk_rows),
+                       "alpha": 1.0, "lambda": 0.1,
+                       "arithmetic": ("per-row Gramian: operands split into two f16 halves (22 significand bits), exact products, fp32 accumulate"
+                                      if split else "per-row Gramian: fp32 products, fp32 accumulate") +
+                                     "; M^T M: fp64; Cholesky and solves: fp32; factors stored fp32 like the reference",
+                       "sharding": "rows x%d, %s all-gather + kxk all-reduce" % (world, "in-place" if chunk_rows == 0 else "chunked (%d rows) pipelined" % chunk_rows),
                        "setup_s": round(t_gen, 2)},
             "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
