@@ -159,6 +159,20 @@ def main():
             halves[name] = {kk: round(h[kk + "_ms"], 3) for kk in ("rows", "segments", "finish", "gramian")}
             halves[name]["rows_GBps"] = round(h["rows_bytes"] / max(h["rows_ms"], 1e-9) / 1e6, 1)
         core.enable_timing(False)
+    # untimed: the exchange on its own ("report all-gather time separately") -- the
+    # un-pipelined in-place all-gather of each side's freshly solved slices into every replica
+    exchange = None
+    if world > 1 or force:
+        exchange = {}
+        for side, name in ((pkg.SIDE_X, "x_ms"), (pkg.SIDE_Y, "y_ms")):
+            als._all_gather(side)
+            barrier()
+            te = time.perf_counter()
+            for _ in range(3):
+                als._all_gather(side)
+            barrier()
+            exchange[name] = (time.perf_counter() - te) / 3 * 1e3
+        exchange["bytes_received_per_rank"] = {"x": (world - 1) * als.per[pkg.SIDE_X] * k * 4, "y": (world - 1) * als.per[pkg.SIDE_Y] * k * 4}
     # untimed quality figure: ReconstructionEvaluator's mean over the observed entries (8(f) row 3)
     rec_sum, rec_cnt = core.reconstruction_error()
     if world > 1:
@@ -215,6 +229,7 @@ def main():
                          "launches": st["rows_launches"]},
             "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian")},
             "half_iteration_kernel_ms": halves,
+            "all_gather_alone_ms": exchange,
             "reconstruction_error": {"mean": rec_sum / max(rec_cnt, 1), "entries": rec_cnt,
                                      "what": "mean over stored entries of max(0, 1 - x_u.y_i) after warmup+steps iterations "
                                              "(ReconstructionEvaluator.java:91-102), untimed"},
