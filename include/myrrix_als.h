@@ -78,7 +78,8 @@ typedef struct mals_config {
   int32_t gramian_mode;         /* arithmetic of the per-row Gramian sum (c-1) y y^T (ALS:471-477):
                                    MALS_GRAMIAN_FP32: fp32 products, fp32 accumulate;
                                    MALS_GRAMIAN_SPLIT_F16: operands split into two f16 halves (22
-                                   significand bits), exact products, fp32 accumulate -- 2.5x less
+                                   significand bits), exact products, fp32 accumulate (the rank-16
+                                   updates of the factorization use the same operands) -- 2.5x less
                                    matrix-pipe time, rounding error on a par with FP32 (measured
                                    2-4e-7 vs the fp64 reference for both);
                                    MALS_GRAMIAN_AUTO (default): FP32 for features <= 32 (where the

@@ -191,9 +191,50 @@ __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   return Uinv;
 }
 
+// ---- split-precision tile products for the rank-16 updates of the factorization (SYRK) ------------
+// Same idea as the split-precision gather (gather_row_h): U_ki^T U_kj with both operands cut into two
+// f16 halves (22 significand bits, exact products, fp32 accumulate) costs 3 x 17 cycles on the f16
+// matrix pipe instead of 4 x 33 on the fp32 one.  The operands are entries of U, bounded by
+// sqrt(max_i W_ii): the row's system is scaled by a power of two s^2 first (row_scale) so that they
+// stay below 2^13 -- f16 cannot overflow, and entries down to 2^-17 of the largest keep 22 bits.
+typedef _Float16 f16x4h __attribute__((ext_vector_type(4)));
+typedef int i32x2h __attribute__((ext_vector_type(2)));
+struct TileH {
+  i32x2h h, l;  // contraction index 4g + r: reg 0 = (r0 | r1 << 16), reg 1 = (r2 | r3 << 16)
+};
+__device__ __forceinline__ int pk_rtz16(float a, float b) { return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+__device__ __forceinline__ TileH split_tile(const f32x4& t) {
+  float h[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h[r] = __int_as_float(__float_as_int(t[r]) & 0xffffe000);
+  TileH o;
+  o.h[0] = pk_rtz16(h[0], h[1]);
+  o.h[1] = pk_rtz16(h[2], h[3]);
+  o.l[0] = pk_rtz16(t[0] - h[0], t[1] - h[1]);
+  o.l[1] = pk_rtz16(t[2] - h[2], t[3] - h[3]);
+  return o;
+}
+__device__ __forceinline__ TileH negate_tile(const TileH& t) {
+  TileH o;
+  o.h = t.h ^ (int)0x80008000;
+  o.l = t.l ^ (int)0x80008000;
+  return o;
+}
+__device__ __forceinline__ f32x4 mfma16h(const i32x2h& a, const i32x2h& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4h, a), __builtin_bit_cast(f16x4h, b), c, 0, 0, 0);
+}
+// C += P^T Q for acc-layout tiles given as split operands (the lo x lo term, < 2^-22 relative, is dropped)
+__device__ __forceinline__ f32x4 tile_ptq_h(const TileH& P, const TileH& Q, f32x4 C) {
+  C = mfma16h(P.h, Q.h, C);
+  C = mfma16h(P.h, Q.l, C);
+  C = mfma16h(P.l, Q.h, C);
+  return C;
+}
+
 // K3b: blocked right-looking Cholesky W = U^T U on the upper tiles.  On return the off-diagonal
 // tiles hold U_ij and the diagonal tiles hold U_ii^{-1}.  TRSM and SYRK run on the matrix cores.
-template <int T>
+// SPLIT: the SYRK products on the f16 matrix pipe (the caller has scaled the system, row_scale).
+template <int T, bool SPLIT = false>
 __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
 #pragma unroll
   for (int kb = 0; kb < T; ++kb) {
@@ -204,11 +245,24 @@ __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, f
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       acc[tidx(T, kb, j)] = tile_ptq(Uinv, acc[tidx(T, kb, j)], zero);
     }
+    if constexpr (SPLIT) {
+      TileH q[T];
 #pragma unroll
-    for (int i = kb + 1; i < T; ++i) {
+      for (int j = kb + 1; j < T; ++j) q[j] = split_tile(acc[tidx(T, kb, j)]);
 #pragma unroll
-      for (int j = i; j < T; ++j)       // A_ij -= U_ki^T U_kj
-        acc[tidx(T, i, j)] = tile_neg_ptq(acc[tidx(T, kb, i)], acc[tidx(T, kb, j)], acc[tidx(T, i, j)]);
+      for (int i = kb + 1; i < T; ++i) {
+        const TileH np = negate_tile(q[i]);
+#pragma unroll
+        for (int j = i; j < T; ++j)     // A_ij -= U_ki^T U_kj
+          acc[tidx(T, i, j)] = tile_ptq_h(np, q[j], acc[tidx(T, i, j)]);
+      }
+    } else {
+#pragma unroll
+      for (int i = kb + 1; i < T; ++i) {
+#pragma unroll
+        for (int j = i; j < T; ++j)     // A_ij -= U_ki^T U_kj
+          acc[tidx(T, i, j)] = tile_neg_ptq(acc[tidx(T, kb, i)], acc[tidx(T, kb, j)], acc[tidx(T, i, j)]);
+      }
     }
   }
 }
@@ -662,6 +716,38 @@ __device__ __forceinline__ void add_ridge(const SolveParams& p, f32x4 (&acc)[tri
   }
 }
 
+// Scale the row's system W x = b by s^2 = 2^(2p) with s * sqrt(max_i W_ii) <= 2^13 (entries of the
+// Cholesky factor of s^2 W are then <= 2^13): exact, and undone by comparing the pivots against
+// threshold * s^2 (the caller multiplies minpiv by the returned 1/s^2) -- x itself is unchanged.
+template <int T>
+__device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T], int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  float m = 0.f;
+#pragma unroll
+  for (int v = 0; v < T; ++v) {
+    const f32x4& d = acc[tidx(T, v, v)];
+    m = fmaxf(m, select4(c & 3, d[0], d[1], d[2], d[3]));  // D[4g + (c&3)][c]: a diagonal element iff c>>2 == g
+  }
+  m = ((c >> 2) == g) ? m : 0.f;
+  m = fmaxf(m, row_ror<8>(m));
+  m = fmaxf(m, row_ror<4>(m));
+  m = fmaxf(m, row_ror<2>(m));
+  m = fmaxf(m, row_ror<1>(m));
+  m = fmaxf(m, bperm((lane ^ 16) << 2, m));
+  m = fmaxf(m, bperm((lane ^ 32) << 2, m));
+  const int e = ((__float_as_int(m) >> 23) & 255) - 126;  // m < 2^e
+  int p2 = 2 * (13 - ((e + 1) >> 1));
+  p2 = p2 < -100 ? -100 : (p2 > 100 ? 100 : p2);
+  const float s2 = __int_as_float((p2 + 127) << 23), inv_s2 = __int_as_float((127 - p2) << 23);
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] *= s2;
+#pragma unroll
+  for (int v = 0; v < T; ++v) bcol[v] *= s2;
+  return inv_s2;
+}
+
 // store x (the cast to fp32 of CMS:40-42 is implicit: all arithmetic here is fp32); flag non-PD rows
 template <int T>
 __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T], float minpiv, int row, int lane) {
@@ -706,7 +792,9 @@ __device__ __forceinline__ WorkItem load_item(const SolveParams& p, int64_t it) 
 
 // Lists A (MODE 0: rows no longer than segment_nnz, fused K2+K3) and B (MODE 1: segments of long
 // rows, K2 only, partial tiles + RHS to scratch).  Persistent waves, see the K2 header comment.
-template <int T, int D, int MODE, bool FULL>
+// KS: the factorization's rank-16 updates on the f16 matrix pipe (cholesky_tiles<T, true>) although the
+// gather is fp32 -- what AUTO uses for short rows at k > 112, where the factorization dominates.
+template <int T, int D, int MODE, bool FULL, bool KS = false>
 __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kernel(SolveParams p) {
   __shared__ f32x4 sG[MODE == 0 ? tri(T) * 64 : 1];
   const int lane = threadIdx.x & 63;
@@ -778,7 +866,13 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
       } else
 #endif
       {
-        cholesky_tiles<T>(acc, lane, minpiv);
+        if constexpr (KS) {
+          const float inv_s2row = row_scale<T>(acc, bcol, lane);
+          cholesky_tiles<T, true>(acc, lane, minpiv);
+          minpiv *= inv_s2row;
+        } else {
+          cholesky_tiles<T>(acc, lane, minpiv);
+        }
 #ifdef MALS_PROFILING
         if (tr) t2 = __builtin_readcyclecounter();
 #endif
@@ -880,7 +974,13 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
         add_ridge<T>(p, acc, cur.len, lane);
         float minpiv = 3.0e38f;
         float xcol[T];
-        cholesky_tiles<T>(acc, lane, minpiv);
+        if constexpr (T >= 2) {  // the rank-16 updates of the factorization on the f16 pipe as well
+          const float inv_s2row = row_scale<T>(acc, bcol, lane);
+          cholesky_tiles<T, true>(acc, lane, minpiv);
+          minpiv *= inv_s2row;
+        } else {
+          cholesky_tiles<T>(acc, lane, minpiv);
+        }
         solve_tiles<T>(acc, bcol, xcol, lane);
         store_row<T>(p, xcol, minpiv, cur.id, lane);
       } else {

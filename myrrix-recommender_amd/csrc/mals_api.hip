@@ -417,6 +417,10 @@ int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk
   }
   if (split)
     return launch_lists(h, s, p, chunk, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>, als_finish_kernel<T>);
+  if constexpr (T == 8) {
+    if (h->split_f16)  // AUTO fell back to the fp32 gather: the factorization still takes its rank-16 updates on the f16 pipe
+      return launch_lists(h, s, p, chunk, als_persistent_kernel<T, D, 0, FULL, true>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
+  }
   return launch_lists(h, s, p, chunk, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
 }
 

@@ -220,9 +220,48 @@ def wave_factor_diag(D):
     return Uinv, minpiv
 
 
-def wave_cholesky(acc, T):
+def mfma_16x16x16_f16(a, b, acc):
+    """acc: [4][64] fp32 acc layout; a, b: [4][64] f16-representable values, reg r of lane (g,c) =
+    contraction index 4g+r (an acc-layout tile used as operand: D = P^T Q).  Exact products, the
+    16-term dot taken exactly and rounded once (see mfma_16x16x32_f16)."""
+    P = np.zeros((16, 16), np.float64)   # P[k][i]
+    Q = np.zeros((16, 16), np.float64)   # Q[k][j]
+    for r in range(4):
+        for g in range(4):
+            P[4 * g + r, :] = a[r][16 * g:16 * g + 16]
+            Q[4 * g + r, :] = b[r][16 * g:16 * g + 16]
+    D = P.T @ Q
+    out = np.zeros((4, 64), dtype=np.float32)
+    for row in range(16):
+        sl = slice(16 * (row >> 2), 16 * (row >> 2) + 16)
+        out[row & 3][sl] = (acc[row & 3][sl].astype(np.float64) + D[row]).astype(np.float32)
+    return out
+
+
+def split_tile(t):
+    """split_tile: every register of an acc-layout tile -> (top 11 significand bits, next 11 toward zero)."""
+    t = np.asarray(t, np.float32)
+    h = (t.view(np.uint32) & np.uint32(0xffffe000)).view(np.float32)
+    return f16_rtz(h), f16_rtz((t - h).astype(np.float32))
+
+
+def row_scale(acc, bcol, T):
+    """row_scale: s^2 = 2^(2p) with s * sqrt(max diag) <= 2^13; returns 1/s^2."""
+    m = np.float32(0)
+    for v in range(T):
+        m = max(m, np.float32(np.max(np.diag(tile_to_dense(acc[(v, v)])))))
+    e = ((int(np.float32(m).view(np.uint32)) >> 23) & 255) - 126
+    p2 = int(np.clip(2 * (13 - ((e + 1) >> 1)), -100, 100))
+    s2, inv_s2 = np.float32(np.ldexp(1.0, p2)), np.float32(np.ldexp(1.0, -p2))
+    for key in acc:
+        acc[key] = (acc[key] * s2).astype(np.float32)
+    return [(b * s2).astype(np.float32) for b in bcol], inv_s2
+
+
+def wave_cholesky(acc, T, split_syrk=False):
     """Blocked right-looking Cholesky on the upper tiles.  On return acc[(i,j)], i<j hold U tiles
-    and acc[(i,i)] hold Uinv_ii."""
+    and acc[(i,i)] hold Uinv_ii.  split_syrk: cholesky_tiles<T, true> (the rank-16 updates with
+    split f16 operands; the caller has applied row_scale)."""
     minpiv = np.inf
     zero = np.zeros((4, 64), np.float32)
     for kb in range(T):
@@ -235,12 +274,19 @@ def wave_cholesky(acc, T):
             for r in range(4):
                 new = mfma_16x16x4(Uinv[r], Q[r], new)
             acc[(kb, j)] = new
+        q = {j: split_tile(acc[(kb, j)]) for j in range(kb + 1, T)} if split_syrk else None
         for i in range(kb + 1, T):                 # SYRK: A_ij -= U_ki^T U_kj
             for j in range(i, T):
                 P, Q = acc[(kb, i)], acc[(kb, j)]
                 t = acc[(i, j)]
-                for r in range(4):
-                    t = mfma_16x16x4(-P[r], Q[r], t)
+                if split_syrk:
+                    nh, nl = -q[i][0], -q[i][1]
+                    t = mfma_16x16x16_f16(nh, q[j][0], t)
+                    t = mfma_16x16x16_f16(nh, q[j][1], t)
+                    t = mfma_16x16x16_f16(nl, q[j][0], t)
+                else:
+                    for r in range(4):
+                        t = mfma_16x16x4(-P[r], Q[r], t)
                 acc[(i, j)] = t
     return acc, minpiv
 
@@ -305,7 +351,12 @@ def wave_solve_row(Yg, vals, Gd, k, alpha=1.0, lam=0.1, reconstruct=False, loss_
     else:
         acc, bcol = wave_gram_rhs(np.asarray(Yg, np.float32).reshape(n_u, k), w, cb, k)
     acc = wave_add_base(acc, Gd, lam * alpha * n_u, k, use_g=not loss_ignores)
-    acc, minpiv = wave_cholesky(acc, T)
+    if split_f16 and T >= 2:                       # the split-precision kernel scales the row and splits the SYRK too
+        bcol, inv_s2 = row_scale(acc, bcol, T)
+        acc, minpiv = wave_cholesky(acc, T, split_syrk=True)
+        minpiv = minpiv * inv_s2
+    else:
+        acc, minpiv = wave_cholesky(acc, T)
     xcol = wave_solve(acc, bcol, T)
     x = np.zeros(16 * T, np.float32)
     for v in range(T):
