@@ -67,6 +67,7 @@ struct SideState {
   double* partials = nullptr;
   int64_t partial_waves = 0;
   bool G_valid = false;
+  uint64_t G_version = 0;  // bumped whenever G changes (cached operand scale of the split-precision gather)
 };
 
 struct PendingEvent {
@@ -82,6 +83,9 @@ struct mals_handle_s {
   int T = 0;
   bool split_f16 = false;  // cfg.gramian_mode resolved
   float* d_zscale = nullptr;  // {S, 1/S^2} of the split-precision gather (gather_scale_kernel)
+  int zs_side = -1;           // what d_zscale currently holds: solved side, version of the opposite G, value bound
+  uint64_t zs_version = 0;
+  float zs_bound = -1.f;
   unsigned* d_maxabs = nullptr;
   int n_cu = 256;
   SideState side[2];
@@ -1061,6 +1065,7 @@ int mals_gramian(mals_handle h, int side, double* host_G) {
   if (int rc = launch_gramian(h, s, s.F, s.n_total, s.G, s.Gf)) return rc;
   if (int rc = end_timed(h, pe)) return rc;
   s.G_valid = true;
+  ++s.G_version;
   if (host_G) {
     const int k = h->cfg.features;
     HIPCHK(h, hipMemcpyAsync(host_G, s.G, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, h->stream));
@@ -1095,6 +1100,7 @@ int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) {
   HIPCHK(h, hipGetLastError());
   if (mem_kind != MALS_MEM_DEVICE) HIPCHK(h, hipStreamSynchronize(h->stream));
   s.G_valid = true;
+  ++s.G_version;
   return MALS_OK;
 }
 
@@ -1132,11 +1138,15 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);  // ALS:435
   p.sing_threshold = (float)h->cfg.singularity_threshold;
   p.zscale = h->d_zscale;
-  if (h->split_f16) {
+  if (h->split_f16 && (h->zs_side != side || h->zs_version != o.G_version || h->zs_bound != s.max_abs_val)) {
+    // once per half-iteration, not per chunk: the scale only depends on G and on the value bound
     const double base_w = (h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) ? 1.0 : 0.0;
     const double w_max = base_w + ((h->cfg.flags & MALS_FLAG_RECONSTRUCT_R) ? 0.0 : std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
     hipLaunchKernelGGL(gather_scale_kernel, dim3(1), dim3(64), 0, h->stream, o.G, k, (float)std::sqrt(w_max), h->d_zscale);
     HIPCHK(h, hipGetLastError());
+    h->zs_side = side;
+    h->zs_version = o.G_version;
+    h->zs_bound = s.max_abs_val;
   }
   for (int c = chunk_begin; c < chunk_end; ++c) {
     if (int rc = launch_solve(h, s, p, c)) return rc;
