@@ -83,9 +83,7 @@ typedef struct mals_config {
                                    matrix-pipe time, rounding error on a par with FP32 (measured
                                    2-4e-7 vs the fp64 reference for both);
                                    MALS_GRAMIAN_AUTO (default): FP32 for features <= 32 (where the
-                                   products are not the bottleneck), SPLIT_F16 above -- except
-                                   for features > 112 on matrices with fewer than ~112 entries
-                                   per row, where the factorization dominates                  */
+                                   products are not the bottleneck), SPLIT_F16 above            */
   int32_t reserved0;
 } mals_config;
 

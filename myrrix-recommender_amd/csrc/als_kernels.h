@@ -28,7 +28,7 @@ namespace mals {
 #define MALS_WAVES(T, MODE) ((T) <= 4 ? 4 : ((T) == 5 ? 3 : 2))
 #endif
 #ifndef MALS_WAVES_H
-#define MALS_WAVES_H(T, MODE) ((T) <= 4 ? 3 : ((T) == 8 && (MODE) == 0 ? 1 : 2))
+#define MALS_WAVES_H(T, MODE) ((T) <= 4 ? 3 : 2)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -792,9 +792,7 @@ __device__ __forceinline__ WorkItem load_item(const SolveParams& p, int64_t it) 
 
 // Lists A (MODE 0: rows no longer than segment_nnz, fused K2+K3) and B (MODE 1: segments of long
 // rows, K2 only, partial tiles + RHS to scratch).  Persistent waves, see the K2 header comment.
-// KS: the factorization's rank-16 updates on the f16 matrix pipe (cholesky_tiles<T, true>) although the
-// gather is fp32 -- what AUTO uses for short rows at k > 112, where the factorization dominates.
-template <int T, int D, int MODE, bool FULL, bool KS = false>
+template <int T, int D, int MODE, bool FULL>
 __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kernel(SolveParams p) {
   __shared__ f32x4 sG[MODE == 0 ? tri(T) * 64 : 1];
   const int lane = threadIdx.x & 63;
@@ -866,13 +864,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
       } else
 #endif
       {
-        if constexpr (KS) {
-          const float inv_s2row = row_scale<T>(acc, bcol, lane);
-          cholesky_tiles<T, true>(acc, lane, minpiv);
-          minpiv *= inv_s2row;
-        } else {
-          cholesky_tiles<T>(acc, lane, minpiv);
-        }
+        cholesky_tiles<T>(acc, lane, minpiv);
 #ifdef MALS_PROFILING
         if (tr) t2 = __builtin_readcyclecounter();
 #endif

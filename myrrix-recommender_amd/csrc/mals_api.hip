@@ -410,21 +410,8 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, KA rows_
 
 template <int T, int D, bool FULL>
 int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk) {
-  bool split = h->split_f16;
-  if (split && T == 8 && h->cfg.gramian_mode == MALS_GRAMIAN_AUTO) {
-    // k > 112: the split-precision rows kernel only fits one wave per SIMD, which slows the 128 x 128
-    // factorization down by ~16K SIMD-cycles per row while the cheaper Gramian saves ~160 per entry
-    // (measured, bench.py workloads c5shard8 / k128long): it pays from ~100 entries per row on
-    const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
-    const double rows = (double)std::max<int64_t>(1, cr.nA + cr.nC);
-    if ((double)(cr.nnzA + cr.nnzB) / rows < 112.0) split = false;
-  }
-  if (split)
+  if (h->split_f16)
     return launch_lists(h, s, p, chunk, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>, als_finish_kernel<T>);
-  if constexpr (T == 8) {
-    if (h->split_f16)  // AUTO fell back to the fp32 gather: the factorization still takes its rank-16 updates on the f16 pipe
-      return launch_lists(h, s, p, chunk, als_persistent_kernel<T, D, 0, FULL, true>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
-  }
   return launch_lists(h, s, p, chunk, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
 }
 
