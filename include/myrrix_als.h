@@ -48,7 +48,8 @@ enum {
   MALS_COMM_ERROR = 4,
   MALS_CANCELLED = 5,
   MALS_OOM = 6,
-  MALS_ILL_CONDITIONED = 7 /* IllConditionedSolverException (Generation.java:150-153) */
+  MALS_ILL_CONDITIONED = 7, /* IllConditionedSolverException (Generation.java:150-153) */
+  MALS_IO_ERROR = 8         /* java.io.IOException (unreadable / corrupt / truncated model file) */
 };
 
 enum { MALS_SIDE_X = 0, MALS_SIDE_Y = 1 };
@@ -298,6 +299,65 @@ int mals_ingest_install(mals_ingest g, mals_handle h);
  * workspace (52 bytes per record, kept for later finishes; hipMalloc of tens of GB is slow), algorithmic
  * bytes read+written by all passes, radix passes run */
 int mals_ingest_stats(mals_ingest g, double* finish_ms, double* workspace_ms, double* bytes_moved, int32_t* radix_passes);
+
+/* ---- model.bin.gz, the file through which the factors leave and re-enter
+ * the unmodified Java server.  Replaces GenerationSerializer.writeGeneration / readGeneration
+ * (online-local/src/net/myrrix/online/generation/GenerationSerializer.java:84-95; body :96-262) and
+ * IOUtils.writeObjectToFile / readObjectFromFile (common/src/net/myrrix/common/io/IOUtils.java:259-283):
+ * a gzip member holding a Java Object Serialization stream (protocol version 2) with ONE object of
+ * class net.myrrix.online.generation.GenerationSerializer (serialVersionUID 1, GS:51) whose custom
+ * writeObject data (GS:96-105) is, big-endian, in 1024-byte block-data records:
+ *   knownItemIDs  int count | -1 for null, then per user: long id, int n, n x long      GS:129-165
+ *   X, Y          int count, then per row: long id, int length, length x float          GS:167-201
+ *   itemTagIDs, userTagIDs   int count, count x long                                    GS:203-222
+ *   userClusters, itemClusters  int count, per cluster: int n, n x long members,
+ *                               int length, length x float centroid                     GS:224-262
+ * Host only (no GPU, no handle).  Rows are written in the order given (the reference's order is the
+ * hash order of its maps, which its reader does not depend on).  A non-finite factor is rejected on
+ * both sides like Preconditions.checkState(LangUtils.isFinite(f)) (GS:167-201): MALS_INVALID_ARG.
+ * Rows of X and Y must share one length ("features"); a file with ragged rows is MALS_INVALID_ARG.
+ * Parity note: no JVM exists in the build image, so interoperability is pinned to the published
+ * stream grammar (Java Object Serialization Specification, section 6.4) and to an independent
+ * restatement in oracle/model_oracle.py -- not to a file written by the reference itself. */
+typedef struct mals_model_view {
+  int32_t struct_size; /* sizeof(mals_model_view) */
+  int32_t features;
+  int64_t n_users;
+  const int64_t* user_ids;
+  const float* X; /* n_users x features, row-major */
+  int64_t n_items;
+  const int64_t* item_ids;
+  const float* Y;
+  int64_t n_known; /* users with a known-item set; -1 = knownItemIDs is null (GS:131-133,148-149) */
+  const int64_t* known_user_ids;
+  const int64_t* known_ptr; /* n_known + 1 offsets into known_item_ids */
+  const int64_t* known_item_ids;
+  int64_t n_item_tags;
+  const int64_t* item_tag_ids;
+  int64_t n_user_tags;
+  const int64_t* user_tag_ids;
+  /* clusters: members of cluster c = members[member_ptr[c] .. member_ptr[c+1]), its centroid =
+   * centroids[centroid_ptr[c] .. centroid_ptr[c+1]) */
+  int64_t n_user_clusters;
+  const int64_t* user_cluster_member_ptr;
+  const int64_t* user_cluster_members;
+  const int64_t* user_cluster_centroid_ptr;
+  const float* user_cluster_centroids;
+  int64_t n_item_clusters;
+  const int64_t* item_cluster_member_ptr;
+  const int64_t* item_cluster_members;
+  const int64_t* item_cluster_centroid_ptr;
+  const float* item_cluster_centroids;
+} mals_model_view;
+typedef struct mals_model_s* mals_model;
+/* path must end in ".gz" (IOUtils.java:276) */
+int mals_model_write(const char* path, const mals_model_view* model);
+int mals_model_read(const char* path, mals_model* out);
+/* the arrays of a model that was read; the pointers stay valid until mals_model_destroy */
+int mals_model_get(mals_model m, mals_model_view* out);
+int mals_model_destroy(mals_model m);
+/* message of the last failed mals_model_* call of this thread */
+const char* mals_model_last_error(void);
 
 int mals_enable_timing(mals_handle h, int32_t on);
 int mals_reset_stats(mals_handle h);

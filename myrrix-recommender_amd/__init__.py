@@ -6,6 +6,7 @@ MatrixFactorizer / AlternatingLeastSquares surface.
   core.ALSCore                  one handle = one GPU (plumbing over the C-ABI)
   factorizer                    host mirror of the reference interface (same names / errors)
   generation                    host mirror of Generation.recomputeSolver + Solver (8(f) row 1)
+  serializer                    model.bin.gz reader / writer, mirror of GenerationSerializer (8(f) row 5)
   ingest                        records -> CSR on the device, mirror of InputFilesReader's record loop (8(f) row 2)
   sharded.ShardedALS            one process per GPU, torch.distributed (RCCL) all-gather between
                                 half-iterations
@@ -21,9 +22,10 @@ from .factorizer import (AlternatingLeastSquares, ExecutionException, Interrupte
                          SolverException, System)
 from .generation import Generation, IllConditionedSolverException, Solver
 from .ingest import Ingest, readInputRecords
+from .serializer import GenerationSerializer, SerializedGeneration
 from ._lib import (FLAG_LOSS_IGNORES_UNSPECIFIED, FLAG_RECONSTRUCT_R, SIDE_X, SIDE_Y)
 
-__all__ = ["ALSCore", "HostSolver", "IllConditioned", "Generation", "Solver", "Ingest", "readInputRecords",
+__all__ = ["GenerationSerializer", "SerializedGeneration", "ALSCore", "HostSolver", "IllConditioned", "Generation", "Solver", "Ingest", "readInputRecords",
            "IllConditionedSolverException", "MalsError", "SingularSystem", "Cancelled", "AlternatingLeastSquares",
            "MatrixFactorizer", "MatrixUtils", "System", "ExecutionException",
            "InterruptedException", "SolverException", "SingularMatrixSolverException",

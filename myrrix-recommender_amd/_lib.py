@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MALS_LIB") or os.path.join(_HERE, "csrc", "libmyrrix_als.so")  # MALS_LIB: A/B builds
 
-OK, SINGULAR, INVALID_ARG, HIP_ERROR, COMM_ERROR, CANCELLED, OOM, ILL_CONDITIONED = range(8)
+OK, SINGULAR, INVALID_ARG, HIP_ERROR, COMM_ERROR, CANCELLED, OOM, ILL_CONDITIONED, IO_ERROR = range(9)
 SIDE_X, SIDE_Y = 0, 1
 FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -16,7 +16,7 @@ GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
                 COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM",
-                ILL_CONDITIONED: "ILL_CONDITIONED"}
+                ILL_CONDITIONED: "ILL_CONDITIONED", IO_ERROR: "IO_ERROR"}
 
 
 class Config(ctypes.Structure):
@@ -37,6 +37,23 @@ class Stats(ctypes.Structure):
                 ("rows_bytes", ctypes.c_double), ("segments_bytes", ctypes.c_double),
                 ("finish_bytes", ctypes.c_double), ("gramian_bytes", ctypes.c_double),
                 ("rows_solved", ctypes.c_int64), ("nnz_gathered", ctypes.c_int64)]
+
+
+class ModelView(ctypes.Structure):
+    """mals_model_view"""
+    _fields_ = [("struct_size", ctypes.c_int32), ("features", ctypes.c_int32),
+                ("n_users", ctypes.c_int64), ("user_ids", ctypes.c_void_p), ("X", ctypes.c_void_p),
+                ("n_items", ctypes.c_int64), ("item_ids", ctypes.c_void_p), ("Y", ctypes.c_void_p),
+                ("n_known", ctypes.c_int64), ("known_user_ids", ctypes.c_void_p),
+                ("known_ptr", ctypes.c_void_p), ("known_item_ids", ctypes.c_void_p),
+                ("n_item_tags", ctypes.c_int64), ("item_tag_ids", ctypes.c_void_p),
+                ("n_user_tags", ctypes.c_int64), ("user_tag_ids", ctypes.c_void_p),
+                ("n_user_clusters", ctypes.c_int64), ("user_cluster_member_ptr", ctypes.c_void_p),
+                ("user_cluster_members", ctypes.c_void_p), ("user_cluster_centroid_ptr", ctypes.c_void_p),
+                ("user_cluster_centroids", ctypes.c_void_p),
+                ("n_item_clusters", ctypes.c_int64), ("item_cluster_member_ptr", ctypes.c_void_p),
+                ("item_cluster_members", ctypes.c_void_p), ("item_cluster_centroid_ptr", ctypes.c_void_p),
+                ("item_cluster_centroids", ctypes.c_void_p)]
 
 
 # every symbol include/myrrix_als.h declares: name -> (restype, argtypes)
@@ -97,6 +114,11 @@ SYMBOLS = {
     "mals_ingest_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I32)]),
     "mals_enable_timing": (ctypes.c_int, [_H, _I32]),
+    "mals_model_write": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ModelView)]),
+    "mals_model_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_H)]),
+    "mals_model_get": (ctypes.c_int, [_H, ctypes.POINTER(ModelView)]),
+    "mals_model_destroy": (ctypes.c_int, [_H]),
+    "mals_model_last_error": (ctypes.c_char_p, []),
     "mals_reset_stats": (ctypes.c_int, [_H]),
     "mals_get_stats": (ctypes.c_int, [_H, ctypes.POINTER(Stats)]),
 }

@@ -66,3 +66,37 @@ def test_records_to_recommendations():
             oidx, osc = to.recommend(Y, X[uu], 10, known)
             assert np.allclose(sc[q], osc, rtol=3e-7, atol=1e-12)
             assert len(set(idx[q].tolist()) ^ set(oidx.tolist())) <= 2   # only near-ties may differ
+
+
+def test_model_file_warm_start(tmp_path):
+    """Row 5 on the path: a finished build is saved as model.bin.gz (DGM:270-289), the next build reads
+    it back and seeds Y from it (DGM:412-427 -> setPreviousY -> ALS:172-174,304-308): same factors in,
+    bit for bit, and the warm build needs fewer iterations than the cold one."""
+    from myrrix_recommender_amd import AlternatingLeastSquares, GenerationSerializer, SerializedGeneration
+    rng = np.random.default_rng(5)
+    n_users, n_items, k = 400, 150, 10
+    pu, pi = rng.standard_normal((n_users, 3)), rng.standard_normal((n_items, 3))
+    RbyRow, RbyColumn = {}, {}
+    for u in range(n_users):
+        for i in np.argsort(-(pi @ pu[u]))[:12]:
+            RbyRow.setdefault(int(u) + 10_000_000_000, {})[int(i) * 5 - 40] = 1.0 + float(rng.integers(0, 3))
+    for u, row in RbyRow.items():
+        for i, v in row.items():
+            RbyColumn.setdefault(i, {})[u] = v
+    cold = AlternatingLeastSquares(RbyRow, RbyColumn, k, 0.001, 40)
+    cold.call()
+    uid, iid = np.array(list(cold.getX().keys())), np.array(list(cold.getY().keys()))
+    ptr = np.concatenate([[0], np.cumsum([len(RbyRow[u]) for u in uid.tolist()])])
+    items = np.array([i for u in uid.tolist() for i in RbyRow[u]], np.int64)
+    g = SerializedGeneration(userIDs=uid, X=np.stack(list(cold.getX().values())), itemIDs=iid,
+                             Y=np.stack(list(cold.getY().values())), knownItemIDs=(uid, ptr, items))
+    GenerationSerializer.writeGeneration(g, tmp_path / "model.bin.gz")
+    back = GenerationSerializer.readGeneration(tmp_path / "model.bin.gz")
+    assert np.array_equal(back.Y, g.Y) and np.array_equal(back.X, g.X) and np.array_equal(back.itemIDs, iid)
+    assert {u: set(v.tolist()) for u, v in back.getKnownItemIDs().items()} == {u: set(r) for u, r in RbyRow.items()}
+    warm = AlternatingLeastSquares(RbyRow, RbyColumn, k, 0.001, 40)
+    warm.setPreviousY(back.getY())
+    warm.call()
+    assert 1 <= warm.iterations < cold.iterations
+    Yc, Yw = np.stack([cold.getY()[i] for i in iid.tolist()]), np.stack([warm.getY()[i] for i in iid.tolist()])
+    assert np.linalg.norm(Yw - Yc) / np.linalg.norm(Yc) < 0.05
