@@ -68,6 +68,7 @@ struct SolveParams {
   float sing_threshold;
   const float* zscale;      // split-precision gather only: {S, 1/S^2}, written by gather_scale_kernel
   unsigned long long* trace;  // profiling only (MALS_DEBUG_TRACE): per-phase s_memtime stamps
+  int trace_start;            // first traced row of a wave's list (MALS_DEBUG_TRACE=<n>)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -132,30 +133,44 @@ __device__ __forceinline__ f32x4 tile_neg_ptq(const f32x4& P, const f32x4& Q, f3
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3a: in-register Cholesky of one full symmetric 16x16 tile D (acc layout).  Returns
-// Uinv = U^{-1} (acc layout) where U^T U = D, by running the elimination on [D | I]: the row
-// operations turn I into L^{-1} = U^{-T}, which is then transposed across lanes.
+// K3a: in-register factorization of one full symmetric 16x16 tile D (acc layout).  Returns
+// Uinv = U^{-1} (acc layout) where U^T U = D.  Read through the symmetry of D, lane (g,c) owns
+// ROW c of the tile, columns 4g..4g+3 (d[r] = D[c][4g+r]); it keeps the same part of row c of the
+// inverse factor next to it (e[r]).  The elimination runs LDL^T-style on [D | I] with unscaled rows:
+// step m subtracts l_cm = D[c][m] / D[m][m] times row m from every row c > m.  Row m at this lane's
+// columns sits in lane m of the same 16-lane group (a DPP row_newbcast operand of the FMA); only the
+// multiplier's numerator D[c][m] lives in another group (lane (m>>2, c)): ONE ds_bpermute per step.
+// At the end row c of [.. | L~^-1] is scaled by 1/sqrt(pivot c), which every lane holds for its own
+// row, and e[r] = L^-1[c][4g+r] = Uinv[4g+r][c] is already the acc layout of Uinv: no transposition.
+// (ds_bpermute is the scarce resource: tools/ubench/bperm_rate.hip measures one per 2.5 ns per CU,
+// shared by all waves, and it heads the dependency chain of every step.)
 // minpiv tracks the smallest pivot (a pivot <= singularity threshold flags a non-PD system).
 template <int M_>
-__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int g, float& minpiv) {
+__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, float& minpiv, float& mypiv) {
   constexpr int gm = M_ >> 2, rm = M_ & 3;
+  const int c = lane & 15;
   const float piv = readlane(D[rm], 16 * gm + M_);
   minpiv = fminf(minpiv, piv);
-  const float s = __builtin_amdgcn_rsqf(piv);
-  const int idx_row = ((16 * gm) | (lane & 15)) << 2;  // lane (gm, c)
-  const float urow = bperm(idx_row, D[rm]) * s;        // U[m][c]
-  const float erow = bperm(idx_row, E[rm]) * s;        // (L^-1)[m][c]
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    // U[m][4g+r] = D[4g+r][m] * s by symmetry of the Schur block; rows < m of D were zeroed when
-    // they were finalised, so finished rows of E are left alone; row m itself is rewritten below.
-    const float ucol = row_bcast<M_>(D[r]) * s;
-    D[r] = fmaf(-ucol, urow, D[r]);
-    E[r] = fmaf(-ucol, erow, E[r]);
-  }
-  const bool mine = g == gm;
-  D[rm] = mine ? 0.f : D[rm];
-  E[rm] = mine ? erow : E[rm];
+  const float rinv = __builtin_amdgcn_rcpf(piv);
+  const float num = bperm(((16 * gm) | c) << 2, D[rm]);  // D[c][m], from lane (gm, c)
+  float nl = -(num * rinv);
+  nl = c > M_ ? nl : 0.f;          // finished rows (and row m itself) stay put
+  mypiv = c == M_ ? piv : mypiv;
+  // d += row_newbcast(d) * nl as ONE instruction each (hipcc emits v_mov_b32_dpp + v_fma instead, and
+  // a DPP instruction costs two issue slots either way).  The s_nop covers the 2 wait states a DPP
+  // read needs after a VALU write of the same register, which the compiler does not track into asm.
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %0, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %1, %1, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %2, %2, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %3, %3, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %4, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %5, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %6, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f32_dpp %7, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+      : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
+      : "v"(nl), "n"(M_));
 }
 
 __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
@@ -163,32 +178,27 @@ __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   f32x4 E;
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] = (4 * g + r == c) ? 1.f : 0.f;
-  diag_step<0>(D, E, lane, g, minpiv);
-  diag_step<1>(D, E, lane, g, minpiv);
-  diag_step<2>(D, E, lane, g, minpiv);
-  diag_step<3>(D, E, lane, g, minpiv);
-  diag_step<4>(D, E, lane, g, minpiv);
-  diag_step<5>(D, E, lane, g, minpiv);
-  diag_step<6>(D, E, lane, g, minpiv);
-  diag_step<7>(D, E, lane, g, minpiv);
-  diag_step<8>(D, E, lane, g, minpiv);
-  diag_step<9>(D, E, lane, g, minpiv);
-  diag_step<10>(D, E, lane, g, minpiv);
-  diag_step<11>(D, E, lane, g, minpiv);
-  diag_step<12>(D, E, lane, g, minpiv);
-  diag_step<13>(D, E, lane, g, minpiv);
-  diag_step<14>(D, E, lane, g, minpiv);
-  diag_step<15>(D, E, lane, g, minpiv);
-  // Uinv = E^T : Uinv.reg[r](g,c) = E[c][4g+r] = E.reg[c&3] held by lane (c>>2, 4g+r)
-  f32x4 Uinv;
-  const int cq = c & 3;
+  float mypiv = 1.f;
+  diag_step<0>(D, E, lane, minpiv, mypiv);
+  diag_step<1>(D, E, lane, minpiv, mypiv);
+  diag_step<2>(D, E, lane, minpiv, mypiv);
+  diag_step<3>(D, E, lane, minpiv, mypiv);
+  diag_step<4>(D, E, lane, minpiv, mypiv);
+  diag_step<5>(D, E, lane, minpiv, mypiv);
+  diag_step<6>(D, E, lane, minpiv, mypiv);
+  diag_step<7>(D, E, lane, minpiv, mypiv);
+  diag_step<8>(D, E, lane, minpiv, mypiv);
+  diag_step<9>(D, E, lane, minpiv, mypiv);
+  diag_step<10>(D, E, lane, minpiv, mypiv);
+  diag_step<11>(D, E, lane, minpiv, mypiv);
+  diag_step<12>(D, E, lane, minpiv, mypiv);
+  diag_step<13>(D, E, lane, minpiv, mypiv);
+  diag_step<14>(D, E, lane, minpiv, mypiv);
+  diag_step<15>(D, E, lane, minpiv, mypiv);
+  const float s = __builtin_amdgcn_rsqf(mypiv);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int src = (16 * (c >> 2) + 4 * g + r) << 2;
-    const float t0 = bperm(src, E[0]), t1 = bperm(src, E[1]), t2 = bperm(src, E[2]), t3 = bperm(src, E[3]);
-    Uinv[r] = select4(cq, t0, t1, t2, t3);
-  }
-  return Uinv;
+  for (int r = 0; r < 4; ++r) E[r] *= s;
+  return E;
 }
 
 // ---- split-precision tile products for the rank-16 updates of the factorization (SYRK) ------------
@@ -834,7 +844,8 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
 #pragma unroll
     for (int v = 0; v < T; ++v) bpart[v] = 0.f;
 #ifdef MALS_PROFILING  // per-phase cycle stamps + ablation switches; not compiled into the product library
-    const bool tr = MODE == 0 && p.trace && wave < 64 && it < 64 * n_waves;
+    const int64_t trow = it / n_waves - p.trace_start;
+    const bool tr = MODE == 0 && p.trace && wave < 64 && trow >= 0 && trow < 64;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     if (tr) t0 = __builtin_readcyclecounter();
     if (!(p.flags & 0x200)) gather_row<T, D, FULL>(p, cur.begin, cur.len, lane, pp, acc, bpart);
@@ -879,8 +890,8 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
       if (tr) {
         t3 = __builtin_readcyclecounter();
         if (lane == 0) {
-          unsigned long long* o = p.trace + ((it / n_waves) * 64 + wave) * 5;
-          o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = (unsigned long long)cur.len;
+          unsigned long long* o = p.trace + (trow * 64 + wave) * 6;
+          o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = (unsigned long long)cur.len; o[5] = wall_clock64();
         }
       }
 #endif
@@ -949,7 +960,16 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
       float bpart[T];
 #pragma unroll
       for (int v = 0; v < T; ++v) bpart[v] = 0.f;
+#ifdef MALS_PROFILING
+      const int64_t trow = it / n_waves - p.trace_start;
+      const bool tr = MODE == 0 && p.trace && wave < 64 && trow >= 0 && trow < 64;
+      unsigned long long t0 = 0, t1 = 0, t2 = 0;
+      if (tr) t0 = __builtin_readcyclecounter();
+#endif
       gather_row_h<T, E, FULL>(p, cur.begin, cur.len, lane, zscale, ch, nch.col, raw, acc, bpart);
+#ifdef MALS_PROFILING
+      if (tr) t1 = __builtin_readcyclecounter();
+#endif
       float bcol[T];
 #pragma unroll
       for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);
@@ -973,8 +993,20 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
         } else {
           cholesky_tiles<T>(acc, lane, minpiv);
         }
+#ifdef MALS_PROFILING
+        if (tr) t2 = __builtin_readcyclecounter();
+#endif
         solve_tiles<T>(acc, bcol, xcol, lane);
         store_row<T>(p, xcol, minpiv, cur.id, lane);
+#ifdef MALS_PROFILING
+        if (tr) {
+          const unsigned long long t3 = __builtin_readcyclecounter();
+          if (lane == 0) {
+            unsigned long long* o = p.trace + (trow * 64 + wave) * 6;
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = (unsigned long long)cur.len; o[5] = wall_clock64();
+          }
+        }
+#endif
       } else {
         float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64) + lane;
 #pragma unroll

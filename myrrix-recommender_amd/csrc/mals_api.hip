@@ -762,8 +762,8 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   }
 #ifdef MALS_PROFILING
   if (std::getenv("MALS_DEBUG_TRACE")) {
-    (void)hipMalloc(&h->d_trace, 64 * 64 * 5 * sizeof(unsigned long long));
-    (void)hipMemset(h->d_trace, 0, 64 * 64 * 5 * sizeof(unsigned long long));
+    (void)hipMalloc(&h->d_trace, 64 * 64 * 6 * sizeof(unsigned long long));
+    (void)hipMemset(h->d_trace, 0, 64 * 64 * 6 * sizeof(unsigned long long));
   }
 #endif
   *out = h;
@@ -775,14 +775,19 @@ int mals_destroy(mals_handle h) {
   (void)hipSetDevice(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
   if (h->d_trace) {  // dump the last launch's per-phase cycle stamps (profiling aid)
-    std::vector<unsigned long long> t(64 * 64 * 5);
+    std::vector<unsigned long long> t(64 * 64 * 6);
     (void)hipMemcpy(t.data(), h->d_trace, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    for (int r = 0; r < 64; r += 9)
-      for (int w = 0; w < 8; w += 1) {
-        const unsigned long long* o = &t[(size_t)(r * 64 + w) * 5];
+    for (int r = 0; r < 64; r += 21)
+      for (int w = 0; w < 4; w += 1) {
+        const unsigned long long* o = &t[(size_t)(r * 64 + w) * 6];
         std::fprintf(stderr, "[trace] iter %2d wave %2d len %5llu gather %7llu chol %7llu solve+store %7llu gap_to_prev_end %lld\n", r, w, o[4],
-                     o[1] - o[0], o[2] - o[1], o[3] - o[2], r ? (long long)(o[0] - t[(size_t)((r - 1) * 64 + w) * 5 + 3]) : 0ll);
+                     o[1] - o[0], o[2] - o[1], o[3] - o[2], r ? (long long)(o[0] - t[(size_t)((r - 1) * 64 + w) * 6 + 3]) : 0ll);
       }
+    for (int w = 0; w < 4; ++w) {  // shader clock: s_memtime ticks per 100 MHz wall tick over 63 traced rows
+      const unsigned long long* a = &t[(size_t)w * 6];
+      const unsigned long long* b = &t[(size_t)(63 * 64 + w) * 6];
+      if (b[5] > a[5]) std::fprintf(stderr, "[trace] wave %d: %llu cycles in %llu wall ticks (100 MHz) = %.0f MHz; %.0f cycles per row\n", w, b[3] - a[3], b[5] - a[5], 100.0 * (double)(b[3] - a[3]) / (double)(b[5] - a[5]), (double)(b[3] - a[3]) / 63.0);
+    }
     free_dev(h->d_trace);
   }
   for (PendingEvent& pe : h->pending) {
@@ -1118,6 +1123,8 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.bad_row = h->d_bad + side;
   p.n_work = 0;
   p.trace = h->d_trace;
+  p.trace_start = 0;
+  if (const char* ts = std::getenv("MALS_DEBUG_TRACE")) p.trace_start = std::atoi(ts);
   if (const char* ts = std::getenv("MALS_DEBUG_TRACE_SIDE")) if (std::atoi(ts) != side) p.trace = nullptr;
   p.k = k;
   p.flags = h->cfg.flags;

@@ -190,34 +190,28 @@ def row_bcast(x, lane_in_row):
 
 
 def wave_factor_diag(D):
-    """In-tile Cholesky of a full symmetric 16x16 tile D (acc layout) by elimination on [D | I].
+    """In-tile factorization of a full symmetric 16x16 tile D (acc layout) by LDL^T-style elimination
+    on [D | I]: lane (g,c) owns row c, columns 4g..4g+3 of both halves (D read through its symmetry).
     Returns (Uinv, minpiv): Uinv = U^{-1} in acc layout, where U^T U = D."""
     D = D.copy()
     E = np.zeros((4, 64), np.float32)
     for r in range(4):
         E[r] = np.where((4 * G_ + r) == C_, 1.0, 0.0)
     minpiv = np.inf
+    mypiv = np.ones(64, np.float32)
     for m in range(16):
         gm, rm = m >> 2, m & 3
         piv = D[rm][16 * gm + m]                   # v_readlane (static lane)
         minpiv = min(minpiv, piv)
-        s = np.float32(1.0) / np.sqrt(np.float32(piv))
-        urow = (shfl(D[rm], 16 * gm + C_) * s).astype(np.float32)
-        erow = (shfl(E[rm], 16 * gm + C_) * s).astype(np.float32)
+        rinv = np.float32(1.0) / np.float32(piv)
+        num = shfl(D[rm], 16 * gm + C_)            # D[c][m]: the one cross-group move of the step
+        nl = np.where(C_ > m, -(num * rinv).astype(np.float32), np.float32(0))
+        mypiv = np.where(C_ == m, np.float32(piv), mypiv)
         for r in range(4):
-            # D[4g+r][m]*s = U[m][4g+r] (symmetry); finished rows of D are zero, so they stay put
-            ucol = (row_bcast(D[r], m) * s).astype(np.float32)
-            D[r] = (D[r] - ucol * urow).astype(np.float32)
-            E[r] = (E[r] - ucol * erow).astype(np.float32)
-        D[rm] = np.where(G_ == gm, np.float32(0), D[rm])
-        E[rm] = np.where(G_ == gm, erow, E[rm])
-    # Uinv = E^T: Uinv.reg[r](g,c) = E[c][4g+r] = E.reg[c&3] at lane (c>>2, 4g+r)
-    Uinv = np.zeros((4, 64), np.float32)
-    for r in range(4):
-        src = 16 * (C_ >> 2) + 4 * G_ + r
-        t = [shfl(E[q], src) for q in range(4)]
-        Uinv[r] = np.select([(C_ & 3) == q for q in range(4)], t)
-    return Uinv, minpiv
+            D[r] = (D[r] + row_bcast(D[r], m) * nl).astype(np.float32)
+            E[r] = (E[r] + row_bcast(E[r], m) * nl).astype(np.float32)
+    s = (np.float32(1.0) / np.sqrt(mypiv)).astype(np.float32)
+    return (E * s).astype(np.float32), minpiv
 
 
 def mfma_16x16x16_f16(a, b, acc):
