@@ -286,17 +286,33 @@ __device__ __forceinline__ f32x4 col_to_row(float vcol, int lane) {
   for (int r = 0; r < 4; ++r) o[r] = bperm(((lane & 48) | (4 * g + r)) << 2, vcol);
   return o;
 }
-__device__ __forceinline__ float row_to_col(const f32x4& vrow, int lane) {
-  const int c = lane & 15, cq = c & 3;
-  const int src = (16 * (c >> 2)) << 2;
-  const float t0 = bperm(src, vrow[0]), t1 = bperm(src, vrow[1]), t2 = bperm(src, vrow[2]), t3 = bperm(src, vrow[3]);
-  return select4(cq, t0, t1, t2, t3);
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {  // DPP quad_perm, CTRL = a | b<<2 | c<<4 | d<<6
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// Sum each of the four registers over the 16 lanes of a row; lane c ends up with the total of register
+// c & 3.  A butterfly that halves the live data per stage: 5 DPP adds instead of the 16 of four
+// reduce_row16, and the result is spread over the lanes the way the next cross-group move wants it.
+__device__ __forceinline__ float reduce4_row16(const f32x4& v, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  const float a0 = (b0 ? v[1] : v[0]) + quad_perm<0xB1>(b0 ? v[0] : v[1]);  // lanes ^1: registers with (r & 1) == b0
+  const float a1 = (b0 ? v[3] : v[2]) + quad_perm<0xB1>(b0 ? v[2] : v[3]);
+  float t = (b1 ? a1 : a0) + quad_perm<0x4E>(b1 ? a0 : a1);                  // lanes ^2: register 2*b1 + b0
+  t += row_ror<4>(t);
+  t += row_ror<8>(t);
+  return t;
+}
+// row-layout vector spread as reduce4_row16 leaves it (lane (g,c): element 4g + (c&3)) -> col layout
+__device__ __forceinline__ float spread_to_col(float v, int lane) {
+  const int c = lane & 15;
+  return bperm(((16 * (c >> 2)) | c) << 2, v);
 }
 
 // K3c: x = W^{-1} b using the factor tiles (forward z = U^{-T} b, backward x = U^{-1} z).
 template <int T>
 __device__ __forceinline__ void solve_tiles(const f32x4 (&acc)[tri(T)], const float (&bcol)[T], float (&xcol)[T], int lane) {
   f32x4 zrow[T];
+  float zcol[T];
 #pragma unroll
   for (int kb = 0; kb < T; ++kb) {
     float t = 0.f;
@@ -316,11 +332,14 @@ __device__ __forceinline__ void solve_tiles(const f32x4 (&acc)[tri(T)], const fl
     zt = fmaf(Ui[1], rr[1], zt);
     zt = fmaf(Ui[2], rr[2], zt);
     zt = fmaf(Ui[3], rr[3], zt);
-    zrow[kb] = col_to_row(reduce_groups(zt, lane), lane);
+    zcol[kb] = reduce_groups(zt, lane);
+    if (kb < T - 1) zrow[kb] = col_to_row(zcol[kb], lane);
   }
+  // backward: contractions over the columns = over the 16 lanes of a row (DPP); one cross-group move
+  // per product brings the row-indexed result back to the col layout the next product wants
 #pragma unroll
   for (int kb = T - 1; kb >= 0; --kb) {
-    f32x4 rhs_row = zrow[kb];
+    float rhs_col = zcol[kb];
     if (kb < T - 1) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -329,15 +348,13 @@ __device__ __forceinline__ void solve_tiles(const f32x4 (&acc)[tri(T)], const fl
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = fmaf(U[r], xcol[j], t[r]);
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rhs_row[r] -= reduce_row16(t[r]);
+      rhs_col -= spread_to_col(reduce4_row16(t, lane), lane);
     }
-    const float rhs_col = row_to_col(rhs_row, lane);
     const f32x4& Ui = acc[tidx(T, kb, kb)];
     f32x4 xr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xr[r] = reduce_row16(Ui[r] * rhs_col);
-    xcol[kb] = row_to_col(xr, lane);
+    for (int r = 0; r < 4; ++r) xr[r] = Ui[r] * rhs_col;
+    xcol[kb] = spread_to_col(reduce4_row16(xr, lane), lane);
   }
 }
 

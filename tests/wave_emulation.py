@@ -296,9 +296,35 @@ def row_to_col(vrow):
     return np.select([(C_ & 3) == q for q in range(4)], t)
 
 
+def quad_perm(x, perm):
+    """DPP quad_perm: lane 4q+i reads lane 4q+perm[i]."""
+    return x[(L & ~3) | np.asarray(perm)[L & 3]]
+
+
+def row_ror(x, n):
+    """DPP row_ror: lane c of a 16-lane row reads lane (c + n) % 16 of the row."""
+    return x[(L & 48) | ((L + n) & 15)]
+
+
+def reduce4_row16(v):
+    """Sum each of four registers over the 16 lanes of a row; lane c ends with the total of register c & 3."""
+    b0, b1 = (L & 1) != 0, (L & 2) != 0
+    a0 = (np.where(b0, v[1], v[0]) + quad_perm(np.where(b0, v[0], v[1]), [1, 0, 3, 2])).astype(np.float32)
+    a1 = (np.where(b0, v[3], v[2]) + quad_perm(np.where(b0, v[2], v[3]), [1, 0, 3, 2])).astype(np.float32)
+    t = (np.where(b1, a1, a0) + quad_perm(np.where(b1, a0, a1), [2, 3, 0, 1])).astype(np.float32)
+    t = (t + row_ror(t, 4)).astype(np.float32)
+    t = (t + row_ror(t, 8)).astype(np.float32)
+    return t
+
+
+def spread_to_col(v):
+    """lane (g,c) holds element 4g + (c&3) of a row-indexed vector -> col layout (lane (g,c): element c)."""
+    return shfl(v, 16 * (C_ >> 2) + C_)
+
+
 def wave_solve(acc, bcol, T):
     """x = W^{-1} b with W = U^T U; acc as returned by wave_cholesky.  Returns xcol[v]."""
-    zrow = []
+    zrow, zcol = [], []
     for kb in range(T):                            # forward: z = U^{-T} b
         t = np.zeros(64, np.float32)
         for i in range(kb):
@@ -309,18 +335,19 @@ def wave_solve(acc, bcol, T):
         zt = np.zeros(64, np.float32)
         for r in range(4):
             zt = (zt + acc[(kb, kb)][r] * rr[r]).astype(np.float32)
-        zrow.append(col_to_row(reduce_groups(zt)))
+        zcol.append(reduce_groups(zt))
+        zrow.append(col_to_row(zcol[kb]))
     xcol = [None] * T
     for kb in range(T - 1, -1, -1):                # backward: x = U^{-1} z
-        rhs_row = []
-        for r in range(4):
-            t = np.zeros(64, np.float32)
-            for j in range(kb + 1, T):
-                t = (t + acc[(kb, j)][r] * xcol[j]).astype(np.float32)
-            rhs_row.append((zrow[kb][r] - reduce_row16(t)).astype(np.float32))
-        rhs_col = row_to_col(rhs_row)
-        xr = [reduce_row16((acc[(kb, kb)][r] * rhs_col).astype(np.float32)) for r in range(4)]
-        xcol[kb] = row_to_col(xr)
+        rhs_col = zcol[kb]
+        if kb < T - 1:
+            t = [np.zeros(64, np.float32) for _ in range(4)]
+            for r in range(4):
+                for j in range(kb + 1, T):
+                    t[r] = (t[r] + acc[(kb, j)][r] * xcol[j]).astype(np.float32)
+            rhs_col = (rhs_col - spread_to_col(reduce4_row16(t))).astype(np.float32)
+        xr = [(acc[(kb, kb)][r] * rhs_col).astype(np.float32) for r in range(4)]
+        xcol[kb] = spread_to_col(reduce4_row16(xr))
     return xcol
 
 
