@@ -145,56 +145,60 @@ __device__ __forceinline__ f32x4 tile_neg_ptq(const f32x4& P, const f32x4& Q, f3
 // (ds_bpermute is the scarce resource: tools/ubench/bperm_rate.hip measures one per 2.5 ns per CU,
 // shared by all waves, and it heads the dependency chain of every step.)
 // minpiv tracks the smallest pivot (a pivot <= singularity threshold flags a non-PD system).
-template <int M_>
-__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, float& minpiv, float& mypiv) {
-  constexpr int gm = M_ >> 2, rm = M_ & 3;
+// Pivot order: step t eliminates index p = 4*(t&3) + (t>>2), i.e. register t>>2 of lane group t&3 --
+// register by register instead of 0..15.  Any symmetric pivot order factors an SPD tile (U is then a
+// row permutation of a triangle, which neither the TRSM, the SYRK nor the solves care about: they only
+// use U_kk^-1), and with this one whole registers drop out of the work: register r of the D half is
+// finished after step 4r+3, register r of the inverse half is still zero before step 4r.  76 DPP FMAs
+// per tile instead of 128 (a DPP instruction costs two issue slots).
+template <int T_>
+__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos, float& minpiv, float& mypiv) {
+  constexpr int gm = T_ & 3, rm = T_ >> 2, P = 4 * gm + rm;
   const int c = lane & 15;
-  const float piv = readlane(D[rm], 16 * gm + M_);
+  const float piv = readlane(D[rm], 16 * gm + P);
   minpiv = fminf(minpiv, piv);
   const float rinv = __builtin_amdgcn_rcpf(piv);
-  const float num = bperm(((16 * gm) | c) << 2, D[rm]);  // D[c][m], from lane (gm, c)
+  const float num = bperm(((16 * gm) | c) << 2, D[rm]);  // D[c][p], from lane (gm, c)
   float nl = -(num * rinv);
-  nl = c > M_ ? nl : 0.f;          // finished rows (and row m itself) stay put
-  mypiv = c == M_ ? piv : mypiv;
-  // d += row_newbcast(d) * nl as ONE instruction each (hipcc emits v_mov_b32_dpp + v_fma instead, and
-  // a DPP instruction costs two issue slots either way).  The s_nop covers the 2 wait states a DPP
-  // read needs after a VALU write of the same register, which the compiler does not track into asm.
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f32_dpp %0, %0, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f32_dpp %1, %1, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f32_dpp %2, %2, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f32_dpp %3, %3, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f32_dpp %4, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f32_dpp %5, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f32_dpp %6, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-      "v_fmac_f32_dpp %7, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
-      : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
-      : "v"(nl), "n"(M_));
+  nl = pos > T_ ? nl : 0.f;        // finished rows (and row p itself) stay put
+  mypiv = pos == T_ ? piv : mypiv;
+  // d += row_newbcast(d) * nl as ONE instruction each (hipcc emits v_mov_b32_dpp + v_fma instead).  The
+  // s_nop covers the 2 wait states a DPP read needs after a VALU write of the same register, which the
+  // compiler does not track into asm.
+  // One block per step (the assembler's .if drops the finished / still-zero registers): a statement
+  // per FMA would let the compiler put a register copy right in front of a DPP read.
+#define MALS_FMAC_BCAST(n, cond) ".if " cond "\n\tv_fmac_f32_dpp %" #n ", %" #n ", %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t.endif\n\t"
+  asm volatile("s_nop 1\n\t"
+               MALS_FMAC_BCAST(0, "3 > %10") MALS_FMAC_BCAST(1, "7 > %10") MALS_FMAC_BCAST(2, "11 > %10") MALS_FMAC_BCAST(3, "15 > %10")
+               MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
+               : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
+               : "v"(nl), "n"(P), "n"(T_));
+#undef MALS_FMAC_BCAST
 }
 
 __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   const int g = lane >> 4, c = lane & 15;
+  const int pos = 4 * (c & 3) + (c >> 2);  // the step at which row c is the pivot row
   f32x4 E;
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] = (4 * g + r == c) ? 1.f : 0.f;
   float mypiv = 1.f;
-  diag_step<0>(D, E, lane, minpiv, mypiv);
-  diag_step<1>(D, E, lane, minpiv, mypiv);
-  diag_step<2>(D, E, lane, minpiv, mypiv);
-  diag_step<3>(D, E, lane, minpiv, mypiv);
-  diag_step<4>(D, E, lane, minpiv, mypiv);
-  diag_step<5>(D, E, lane, minpiv, mypiv);
-  diag_step<6>(D, E, lane, minpiv, mypiv);
-  diag_step<7>(D, E, lane, minpiv, mypiv);
-  diag_step<8>(D, E, lane, minpiv, mypiv);
-  diag_step<9>(D, E, lane, minpiv, mypiv);
-  diag_step<10>(D, E, lane, minpiv, mypiv);
-  diag_step<11>(D, E, lane, minpiv, mypiv);
-  diag_step<12>(D, E, lane, minpiv, mypiv);
-  diag_step<13>(D, E, lane, minpiv, mypiv);
-  diag_step<14>(D, E, lane, minpiv, mypiv);
-  diag_step<15>(D, E, lane, minpiv, mypiv);
+  diag_step<0>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<1>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<2>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<3>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<4>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<5>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<6>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<7>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<8>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<9>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<10>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<11>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<12>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<13>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<14>(D, E, lane, pos, minpiv, mypiv);
+  diag_step<15>(D, E, lane, pos, minpiv, mypiv);
   const float s = __builtin_amdgcn_rsqf(mypiv);
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] *= s;

@@ -199,17 +199,21 @@ def wave_factor_diag(D):
         E[r] = np.where((4 * G_ + r) == C_, 1.0, 0.0)
     minpiv = np.inf
     mypiv = np.ones(64, np.float32)
-    for m in range(16):
-        gm, rm = m >> 2, m & 3
+    pos = 4 * (C_ & 3) + (C_ >> 2)                 # the step at which row c is the pivot row
+    for t in range(16):                            # pivot order: register by register (see diag_step)
+        gm, rm = t & 3, t >> 2
+        m = 4 * gm + rm
         piv = D[rm][16 * gm + m]                   # v_readlane (static lane)
         minpiv = min(minpiv, piv)
         rinv = np.float32(1.0) / np.float32(piv)
         num = shfl(D[rm], 16 * gm + C_)            # D[c][m]: the one cross-group move of the step
-        nl = np.where(C_ > m, -(num * rinv).astype(np.float32), np.float32(0))
-        mypiv = np.where(C_ == m, np.float32(piv), mypiv)
+        nl = np.where(pos > t, -(num * rinv).astype(np.float32), np.float32(0))
+        mypiv = np.where(pos == t, np.float32(piv), mypiv)
         for r in range(4):
-            D[r] = (D[r] + row_bcast(D[r], m) * nl).astype(np.float32)
-            E[r] = (E[r] + row_bcast(E[r], m) * nl).astype(np.float32)
+            if 4 * r + 3 > t:                      # register r of the D half is finished after step 4r+3
+                D[r] = (D[r] + row_bcast(D[r], m) * nl).astype(np.float32)
+            if 4 * r <= t:                         # register r of the inverse half is zero before step 4r
+                E[r] = (E[r] + row_bcast(E[r], m) * nl).astype(np.float32)
     s = (np.float32(1.0) / np.sqrt(mypiv)).astype(np.float32)
     return (E * s).astype(np.float32), minpiv
 
