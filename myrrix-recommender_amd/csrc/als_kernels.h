@@ -151,31 +151,60 @@ __device__ __forceinline__ f32x4 tile_neg_ptq(const f32x4& P, const f32x4& Q, f3
 // use U_kk^-1), and with this one whole registers drop out of the work: register r of the D half is
 // finished after step 4r+3, register r of the inverse half is still zero before step 4r.  76 DPP FMAs
 // per tile instead of 128 (a DPP instruction costs two issue slots).
-template <int T_>
-__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos, float& minpiv, float& mypiv) {
+template <int T_, bool PIPE>
+__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos, float& minpiv, float& mypiv, float& piv, float& num) {
   constexpr int gm = T_ & 3, rm = T_ >> 2, P = 4 * gm + rm;
+  constexpr int gn = (T_ + 1) & 3, rn = ((T_ + 1) >> 2) & 3, PN = 4 * gn + rn;  // the next step's pivot
   const int c = lane & 15;
-  const float piv = readlane(D[rm], 16 * gm + P);
   minpiv = fminf(minpiv, piv);
   const float rinv = __builtin_amdgcn_rcpf(piv);
-  const float num = bperm(((16 * gm) | c) << 2, D[rm]);  // D[c][p], from lane (gm, c)
-  float nl = -(num * rinv);
+  float nl = -(num * rinv);        // num = D[c][p] (from lane (gm, c)), piv = D[p][p]: fetched a step ahead
   nl = pos > T_ ? nl : 0.f;        // finished rows (and row p itself) stay put
   mypiv = pos == T_ ? piv : mypiv;
   // d += row_newbcast(d) * nl as ONE instruction each (hipcc emits v_mov_b32_dpp + v_fma instead).  The
   // s_nop covers the 2 wait states a DPP read needs after a VALU write of the same register, which the
-  // compiler does not track into asm.
-  // One block per step (the assembler's .if drops the finished / still-zero registers): a statement
-  // per FMA would let the compiler put a register copy right in front of a DPP read.
+  // compiler does not track into asm.  One block per step (the assembler's .if drops the finished /
+  // still-zero registers): a statement per FMA would let the compiler put a register copy right in
+  // front of a DPP read.  PIPE: the register of the next pivot goes first, so that the next step's pivot
+  // and multipliers (the ds_bpermute heads the step's dependency chain) are fetched under the other
+  // FMAs -- pays at two waves per SIMD (k > 64: k=128 X-half 40.7 -> 39.7 ms), costs at three (k = 64:
+  // 52.5 -> 53.1 ms, issue-bound: the second s_nop), hence the switch.
 #define MALS_FMAC_BCAST(n, cond) ".if " cond "\n\tv_fmac_f32_dpp %" #n ", %" #n ", %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t.endif\n\t"
-  asm volatile("s_nop 1\n\t"
-               MALS_FMAC_BCAST(0, "3 > %10") MALS_FMAC_BCAST(1, "7 > %10") MALS_FMAC_BCAST(2, "11 > %10") MALS_FMAC_BCAST(3, "15 > %10")
-               MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
-               : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
-               : "v"(nl), "n"(P), "n"(T_));
+  if constexpr (!PIPE) {
+    asm volatile("s_nop 1\n\t"
+                 MALS_FMAC_BCAST(0, "3 > %10") MALS_FMAC_BCAST(1, "7 > %10") MALS_FMAC_BCAST(2, "11 > %10") MALS_FMAC_BCAST(3, "15 > %10")
+                 MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
+                 : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
+                 : "v"(nl), "n"(P), "n"(T_));
+    if constexpr (T_ < 15) {
+      num = bperm(((16 * gn) | c) << 2, D[rn]);
+      piv = readlane(D[rn], 16 * gn + PN);
+    }
+  } else if constexpr (T_ < 15) {
+    asm volatile("s_nop 1\n\t"
+                 MALS_FMAC_BCAST(0, "%11 == 0") MALS_FMAC_BCAST(1, "%11 == 1") MALS_FMAC_BCAST(2, "%11 == 2") MALS_FMAC_BCAST(3, "%11 == 3")
+                 : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
+                 : "v"(nl), "n"(P), "n"(T_), "n"(rn));
+    __builtin_amdgcn_sched_barrier(0);
+    num = bperm(((16 * gn) | c) << 2, D[rn]);
+    piv = readlane(D[rn], 16 * gn + PN);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1\n\t"
+                 MALS_FMAC_BCAST(0, "(3 > %10) && (%11 != 0)") MALS_FMAC_BCAST(1, "(7 > %10) && (%11 != 1)")
+                 MALS_FMAC_BCAST(2, "(11 > %10) && (%11 != 2)") MALS_FMAC_BCAST(3, "(15 > %10) && (%11 != 3)")
+                 MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
+                 : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
+                 : "v"(nl), "n"(P), "n"(T_), "n"(rn));
+  } else {
+    asm volatile("s_nop 1\n\t"
+                 MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
+                 : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
+                 : "v"(nl), "n"(P), "n"(T_), "n"(rn));
+  }
 #undef MALS_FMAC_BCAST
 }
 
+template <bool PIPE>
 __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   const int g = lane >> 4, c = lane & 15;
   const int pos = 4 * (c & 3) + (c >> 2);  // the step at which row c is the pivot row
@@ -183,22 +212,24 @@ __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] = (4 * g + r == c) ? 1.f : 0.f;
   float mypiv = 1.f;
-  diag_step<0>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<1>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<2>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<3>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<4>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<5>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<6>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<7>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<8>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<9>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<10>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<11>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<12>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<13>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<14>(D, E, lane, pos, minpiv, mypiv);
-  diag_step<15>(D, E, lane, pos, minpiv, mypiv);
+  float num = bperm(c << 2, D[0]);   // step 0: pivot index 0 = register 0 of group 0
+  float piv = readlane(D[0], 0);
+  diag_step<0, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<1, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<2, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<3, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<4, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<5, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<6, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<7, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<8, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<9, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<10, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<11, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<12, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<13, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<14, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
+  diag_step<15, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
   const float s = __builtin_amdgcn_rsqf(mypiv);
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] *= s;
@@ -252,7 +283,7 @@ template <int T, bool SPLIT = false>
 __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
 #pragma unroll
   for (int kb = 0; kb < T; ++kb) {
-    const f32x4 Uinv = factor_diag(acc[tidx(T, kb, kb)], lane, minpiv);
+    const f32x4 Uinv = factor_diag<(T > 4)>(acc[tidx(T, kb, kb)], lane, minpiv);
     acc[tidx(T, kb, kb)] = Uinv;
 #pragma unroll
     for (int j = kb + 1; j < T; ++j) {  // U_kj = Uinv^T A_kj
