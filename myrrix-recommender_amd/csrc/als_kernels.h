@@ -249,14 +249,19 @@ struct TileH {
 };
 __device__ __forceinline__ int pk_rtz16(float a, float b) { return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(a, b)); }
 __device__ __forceinline__ TileH split_tile(const f32x4& t) {
-  float h[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) h[r] = __int_as_float(__float_as_int(t[r]) & 0xffffe000);
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  // top 11 significand bits (round toward zero straight into f16), then what is left (v_fma_mix_f32 /
+  // v_cvt_f32_f16 + v_sub).  Kept in scalars: with the halves read back out of the int2 vector hipcc
+  // (ROCm 7.2) subtracts the first pair from both (seen in the ISA, caught by the parity tests).
+  const int h01 = pk_rtz16(t[0], t[1]), h23 = pk_rtz16(t[2], t[3]);
+  const h2 a = __builtin_bit_cast(h2, h01), b = __builtin_bit_cast(h2, h23);
+  const int l01 = pk_rtz16(t[0] - (float)a[0], t[1] - (float)a[1]);
+  const int l23 = pk_rtz16(t[2] - (float)b[0], t[3] - (float)b[1]);
   TileH o;
-  o.h[0] = pk_rtz16(h[0], h[1]);
-  o.h[1] = pk_rtz16(h[2], h[3]);
-  o.l[0] = pk_rtz16(t[0] - h[0], t[1] - h[1]);
-  o.l[1] = pk_rtz16(t[2] - h[2], t[3] - h[3]);
+  o.h[0] = h01;
+  o.h[1] = h23;
+  o.l[0] = l01;
+  o.l[1] = l23;
   return o;
 }
 __device__ __forceinline__ TileH negate_tile(const TileH& t) {
@@ -577,6 +582,7 @@ __device__ __forceinline__ void gather_row(const SolveParams& p, int64_t begin, 
 // the factorization, like above.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
@@ -638,10 +644,13 @@ __device__ __forceinline__ void convert_pair_h(const Chunk& ch, int lane, const 
   for (int v = 0; v < T; ++v) {
     const float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
     const float z0 = y0 * s0, z1 = y1 * s1;
-    const float h0 = __int_as_float(__float_as_int(z0) & 0xffffe000);  // top 11 significand bits: exact in f16
-    const float h1 = __int_as_float(__float_as_int(z1) & 0xffffe000);
-    zh[v].r[E2] = pk_rtz(h0, h1);
-    zl[v].r[E2] = pk_rtz(z0 - h0, z1 - h1);
+    // zh = the top 11 significand bits (round toward zero straight into f16), zl = what is left: written
+    // as an FMA on the widened half so that hipcc emits one v_fma_mix_f32 per value (and folds the
+    // scaling in: zl is the residual of the exact product)
+    const int hp = pk_rtz(z0, z1);
+    const f16x2 hh = __builtin_bit_cast(f16x2, hp);
+    zh[v].r[E2] = hp;
+    zl[v].r[E2] = pk_rtz(fmaf((float)hh[0], -1.f, z0), fmaf((float)hh[1], -1.f, z1));
     bpart[v] = fmaf(c0, y0, bpart[v]);
     bpart[v] = fmaf(c1, y1, bpart[v]);
   }
