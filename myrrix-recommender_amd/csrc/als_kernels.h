@@ -151,19 +151,21 @@ __device__ __forceinline__ f32x4 tile_neg_ptq(const f32x4& P, const f32x4& Q, f3
 // use U_kk^-1), and with this one whole registers drop out of the work: register r of the D half is
 // finished after step 4r+3, register r of the inverse half is still zero before step 4r.  76 DPP FMAs
 // per tile instead of 128 (a DPP instruction costs two issue slots).
+__device__ __forceinline__ float spread_to_col(float v, int lane);
 template <int T_, bool PIPE>
-__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos, float& minpiv, float& mypiv, float& piv, float& num) {
+__device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos, float& minpiv, float& piv, float& num) {
   constexpr int gm = T_ & 3, rm = T_ >> 2, P = 4 * gm + rm;
   constexpr int gn = (T_ + 1) & 3, rn = ((T_ + 1) >> 2) & 3, PN = 4 * gn + rn;  // the next step's pivot
   const int c = lane & 15;
   minpiv = fminf(minpiv, piv);
   const float rinv = __builtin_amdgcn_rcpf(piv);
   float nl = -(num * rinv);        // num = D[c][p] (from lane (gm, c)), piv = D[p][p]: fetched a step ahead
-  nl = pos > T_ ? nl : 0.f;        // finished rows (and row p itself) stay put
-  mypiv = pos == T_ ? piv : mypiv;
-  // d += row_newbcast(d) * nl as ONE instruction each (hipcc emits v_mov_b32_dpp + v_fma instead).  The
-  // s_nop covers the 2 wait states a DPP read needs after a VALU write of the same register, which the
-  // compiler does not track into asm.  One block per step (the assembler's .if drops the finished /
+  nl = pos > T_ ? nl : 0.f;        // finished rows (and row p itself) stay put: D[p][p] keeps the pivot
+  // d += row_newbcast(d) * nl as ONE instruction each (hipcc emits v_mov_b32_dpp + v_fma instead).  A
+  // DPP read needs 2 wait states after a VALU write of the same register, which the compiler does not
+  // track into asm: step 0 (whose operands may just have been copied) opens with an s_nop; later the
+  // registers were last written by the previous step's block, 7+ instructions earlier
+  // (tools/check_dpp_hazards.py checks that on the generated ISA).  One block per step (the assembler's .if drops the finished /
   // still-zero registers): a statement per FMA would let the compiler put a register copy right in
   // front of a DPP read.  PIPE: the register of the next pivot goes first, so that the next step's pivot
   // and multipliers (the ds_bpermute heads the step's dependency chain) are fetched under the other
@@ -171,7 +173,7 @@ __device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos,
   // 52.5 -> 53.1 ms, issue-bound: the second s_nop), hence the switch.
 #define MALS_FMAC_BCAST(n, cond) ".if " cond "\n\tv_fmac_f32_dpp %" #n ", %" #n ", %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t.endif\n\t"
   if constexpr (!PIPE) {
-    asm volatile("s_nop 1\n\t"
+    asm volatile(".if %10 == 0\n\ts_nop 1\n\t.endif\n\t"
                  MALS_FMAC_BCAST(0, "3 > %10") MALS_FMAC_BCAST(1, "7 > %10") MALS_FMAC_BCAST(2, "11 > %10") MALS_FMAC_BCAST(3, "15 > %10")
                  MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
                  : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
@@ -211,26 +213,26 @@ __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   f32x4 E;
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] = (4 * g + r == c) ? 1.f : 0.f;
-  float mypiv = 1.f;
   float num = bperm(c << 2, D[0]);   // step 0: pivot index 0 = register 0 of group 0
   float piv = readlane(D[0], 0);
-  diag_step<0, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<1, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<2, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<3, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<4, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<5, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<6, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<7, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<8, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<9, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<10, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<11, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<12, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<13, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<14, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  diag_step<15, PIPE>(D, E, lane, pos, minpiv, mypiv, piv, num);
-  const float s = __builtin_amdgcn_rsqf(mypiv);
+  diag_step<0, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<1, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<2, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<3, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<4, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<5, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<6, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<7, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<8, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<9, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<10, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<11, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<12, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<13, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<14, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<15, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  // row c is scaled by 1/sqrt(its pivot), which lane (c>>2, c) still holds as D[c][c]
+  const float s = __builtin_amdgcn_rsqf(spread_to_col(select4(c & 3, D[0], D[1], D[2], D[3]), lane));
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] *= s;
   return E;
