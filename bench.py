@@ -37,7 +37,7 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, budget_rows=(20000, 2000)):
+def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, budget_rows=(100000, 10000)):
     """Reference's CPU path, restated (oracle = "port"), timed on this host's cores on a bounded
     random sample of rows and extrapolated by row count.  The Gramian (serial in the reference,
     ALS:342 -> MU:219-239) is timed on a row sample too."""
