@@ -92,9 +92,9 @@ int scan_u32(mals_ingest g, Scratch& s, const unsigned* in, unsigned* out, int64
     return MALS_OK;
   }
   const int64_t tiles = (n + SC_TILE - 1) / SC_TILE;
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3((unsigned)tiles), dim3(256), 0, g->stream, in, n, out, s.tile_sums);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)tiles), dim3(256), 0, g->stream, in, n, s.tile_sums);
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, g->stream, s.tile_sums, tiles, s.total);
-  hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)tiles), dim3(256), 0, g->stream, out, n, s.tile_sums);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)tiles), dim3(256), 0, g->stream, in, n, out, s.tile_sums);
   ICHK(g, hipGetLastError());
   g->bytes_moved += 12.0 * (double)n;
   if (host_total) {

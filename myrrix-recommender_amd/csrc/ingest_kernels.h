@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const uint64_t* __restr
   }
 }
 
-// ---- exclusive scan of uint32 (three kernels; block = 256 threads x 8 items) -----------------------
+// ---- exclusive scan of uint32 (reduce, scan of the tile sums, apply; block = 256 threads x 8 items):
+// the data is read twice and written once -----------------------------------------------------------
 constexpr int SC_TILE = 2048;
 __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* total) {  // v: per-thread value
   __shared__ unsigned ws[4];
@@ -194,23 +195,49 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* t
   __syncthreads();
   return pre + x - v;
 }
-__global__ __launch_bounds__(256) void scan_tiles_kernel(const unsigned* __restrict__ in, int64_t n, unsigned* __restrict__ out,
-                                                         unsigned* __restrict__ tile_sums) {
+// a thread's 8 consecutive items: two 16-byte loads where the whole group is inside the array
+__device__ __forceinline__ void scan_load8(const unsigned* __restrict__ in, int64_t b, int64_t n, unsigned (&v)[8]) {
+  if (b + 8 <= n) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(in + b), hi = *reinterpret_cast<const uint4*>(in + b + 4);
+    v[0] = lo.x, v[1] = lo.y, v[2] = lo.z, v[3] = lo.w, v[4] = hi.x, v[5] = hi.y, v[6] = hi.z, v[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = b + i < n ? in[b + i] : 0;
+  }
+}
+// pass 1: the sum of every tile (the input is only read)
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const unsigned* __restrict__ in, int64_t n, unsigned* __restrict__ tile_sums) {
   const int64_t b = (int64_t)blockIdx.x * SC_TILE + threadIdx.x * 8;
   unsigned v[8], s = 0;
+  scan_load8(in, b, n, v);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v[i] = b + i < n ? in[b + i] : 0;
-    s += v[i];
-  }
+  for (int i = 0; i < 8; ++i) s += v[i];
   unsigned total;
-  unsigned pre = block_exclusive_scan(s, &total);
+  block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+// pass 3: exclusive scan inside each tile on top of its (already scanned) tile offset; in may alias out
+__global__ __launch_bounds__(256) void scan_apply_kernel(const unsigned* in, int64_t n, unsigned* out, const unsigned* __restrict__ tile_offsets) {
+  const int64_t b = (int64_t)blockIdx.x * SC_TILE + threadIdx.x * 8;
+  unsigned v[8], s = 0;
+  scan_load8(in, b, n, v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v[i];
+  unsigned pre = tile_offsets[blockIdx.x] + block_exclusive_scan(s, nullptr);
+  unsigned o[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    if (b + i < n) out[b + i] = pre;
+    o[i] = pre;
     pre += v[i];
   }
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+  if (b + 8 <= n) {
+    *reinterpret_cast<uint4*>(out + b) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(out + b + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (b + i < n) out[b + i] = o[i];
+  }
 }
 // one block scans the tile sums in place (exclusive), carrying across chunks of 2048
 __global__ __launch_bounds__(256) void scan_sums_kernel(unsigned* __restrict__ sums, int64_t n_tiles, unsigned* __restrict__ grand_total) {
@@ -234,14 +261,6 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(unsigned* __restrict__ s
   }
   if (threadIdx.x == 0 && grand_total) *grand_total = carry;
 }
-__global__ __launch_bounds__(256) void scan_add_kernel(unsigned* __restrict__ out, int64_t n, const unsigned* __restrict__ tile_offsets) {
-  const int64_t b = (int64_t)blockIdx.x * SC_TILE + threadIdx.x * 8;
-  const unsigned o = tile_offsets[blockIdx.x];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (b + i < n) out[b + i] += o;
-}
-
 // ---- elementwise passes ------------------------------------------------------------------------------
 #define MALS_GRID_STRIDE(i, n) \
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
