@@ -32,3 +32,12 @@ def test_cpp_mirror_builds_and_has_no_cpu_fallback():
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0
     assert "no CPU fallback" in r.stdout
+
+
+def test_model_file_through_the_cpp_mirror(tmp_path):
+    """include/myrrix/serializer.hpp (GenerationSerializer) on the C-ABI: host code only."""
+    from tests.test_model_oracle import TINY_STREAM
+    subprocess.check_call(["make", "-C", CPP, "test_model_file"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(CPP, "test_model_file"), str(tmp_path), TINY_STREAM.hex()], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
