@@ -624,6 +624,12 @@ __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, 
   const int c = lane & 15;
   int col[2];
   bperm2_i<32 * E2, 32 * E2 + 16>(off, col_src, col[0], col[1]);
+#ifdef MALS_PROFILING
+  if (p.flags & 0x400) {  // ablation (MALS_DEBUG_FLAGS=4): every gather hits the cache
+    col[0] &= 0xfff;
+    col[1] &= 0xfff;
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = 2 * E2 + i;
