@@ -965,13 +965,12 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
       }
 #endif
     } else {
-      float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64) + lane;
+      // partial slot: tri(T) tiles as one float4 per lane (16-byte stores), then the T RHS blocks
+      float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64);
 #pragma unroll
-      for (int t = 0; t < tri(T); ++t)
+      for (int t = 0; t < tri(T); ++t) reinterpret_cast<f32x4*>(s)[t * 64 + lane] = acc[t];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r];
-#pragma unroll
-      for (int v = 0; v < T; ++v) s[(tri(T) * 4 + v) * 64] = bcol[v];
+      for (int v = 0; v < T; ++v) s[(tri(T) * 4 + v) * 64 + lane] = bcol[v];
       if (prime_next) {
         chunk_weights(p, pp.ch);
         prime_row<T, D, FULL>(p, lane, pp);
@@ -1077,13 +1076,11 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
         }
 #endif
       } else {
-        float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64) + lane;
+        float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64);
 #pragma unroll
-        for (int t = 0; t < tri(T); ++t)
+        for (int t = 0; t < tri(T); ++t) reinterpret_cast<f32x4*>(s)[t * 64 + lane] = acc[t] * inv_s2;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[(t * 4 + r) * 64] = acc[t][r] * inv_s2;
-#pragma unroll
-        for (int v = 0; v < T; ++v) s[(tri(T) * 4 + v) * 64] = bcol[v];
+        for (int v = 0; v < T; ++v) s[(tri(T) * 4 + v) * 64 + lane] = bcol[v];
       }
       cur = nxt;
       nxt = nx2;
@@ -1124,13 +1121,18 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
 #pragma unroll
   for (int v = 0; v < T; ++v) bcol[v] = 0.f;
   for (int sgi = 0; sgi < rc.nseg; ++sgi) {
-    const float* s = p.scratch + (rc.first_slot + sgi) * (int64_t)((tri(T) * 4 + T) * 64) + lane;
+    // all loads of a segment's slot first (16 bytes per lane and tile), then the adds
+    const float* s = p.scratch + (rc.first_slot + sgi) * (int64_t)((tri(T) * 4 + T) * 64);
+    f32x4 part[tri(T)];
+    float bp[T];
 #pragma unroll
-    for (int t = 0; t < tri(T); ++t)
+    for (int t = 0; t < tri(T); ++t) part[t] = reinterpret_cast<const f32x4*>(s)[t * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[t][r] += s[(t * 4 + r) * 64];
+    for (int v = 0; v < T; ++v) bp[v] = s[(tri(T) * 4 + v) * 64 + lane];
 #pragma unroll
-    for (int v = 0; v < T; ++v) bcol[v] += s[(tri(T) * 4 + v) * 64];
+    for (int t = 0; t < tri(T); ++t) acc[t] += part[t];
+#pragma unroll
+    for (int v = 0; v < T; ++v) bcol[v] += bp[v];
   }
   const int n_u = uniform((int)(p.row_ptr[rc.row + 1] - p.row_ptr[rc.row]));
   finish_row<T>(p, acc, bcol, n_u, rc.row, lane);
