@@ -781,16 +781,26 @@ __device__ __forceinline__ void init_acc(const SolveParams& p, f32x4 (&acc)[tri(
 }
 
 // W += lambda*alpha*n_u I (ALS:488-492); identity on the padding features
-template <int T>
+template <int T, bool FULL = false>
 __device__ __forceinline__ void add_ridge(const SolveParams& p, f32x4 (&acc)[tri(T)], int n_u, int lane) {
   const int g = lane >> 4, c = lane & 15;
   const float ridge = p.lambda_alpha * (float)n_u;
+  // whole blocks: the diagonal sits at register r of lane (g, 4g+r) in every diagonal tile, so the four
+  // selects are made once and the tiles get plain adds
+  float rd[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) rd[r] = (4 * g + r == c) ? ridge : 0.f;
 #pragma unroll
   for (int v = 0; v < T; ++v) {
-    const int feat = 16 * v + c;
+    if (FULL || v < T - 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (4 * g + r == c) acc[tidx(T, v, v)][r] = feat < p.k ? acc[tidx(T, v, v)][r] + ridge : 1.f;
+      for (int r = 0; r < 4; ++r) acc[tidx(T, v, v)][r] += rd[r];
+    } else {  // partial last block: 1 on the diagonal of the padding
+      const int feat = 16 * v + c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (4 * g + r == c) acc[tidx(T, v, v)][r] = feat < p.k ? acc[tidx(T, v, v)][r] + ridge : 1.f;
+      }
     }
   }
 }
@@ -800,21 +810,23 @@ __device__ __forceinline__ void add_ridge(const SolveParams& p, f32x4 (&acc)[tri
 // threshold * s^2 (the caller multiplies minpiv by the returned 1/s^2) -- x itself is unchanged.
 template <int T>
 __device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T], int lane) {
-  const int g = lane >> 4, c = lane & 15;
-  float m = 0.f;
+  // the largest diagonal element of an SPD matrix is its largest |entry|: no need to pick the diagonal
+  // out of the diagonal tiles.  Non-negative floats order like their bit patterns: integer max from here
+  // on (a float max of a DPP / bpermute result costs an extra canonicalising v_max).
+  float mf = 0.f;
 #pragma unroll
   for (int v = 0; v < T; ++v) {
     const f32x4& d = acc[tidx(T, v, v)];
-    m = fmaxf(m, select4(c & 3, d[0], d[1], d[2], d[3]));  // D[4g + (c&3)][c]: a diagonal element iff c>>2 == g
+    mf = fmaxf(mf, fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3]))));
   }
-  m = ((c >> 2) == g) ? m : 0.f;
-  m = fmaxf(m, row_ror<8>(m));
-  m = fmaxf(m, row_ror<4>(m));
-  m = fmaxf(m, row_ror<2>(m));
-  m = fmaxf(m, row_ror<1>(m));
-  m = fmaxf(m, bperm((lane ^ 16) << 2, m));
-  m = fmaxf(m, bperm((lane ^ 32) << 2, m));
-  const int e = ((__float_as_int(m) >> 23) & 255) - 126;  // m < 2^e
+  int m = __float_as_int(mf);
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x120 + 8, 0xf, 0xf, false));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x120 + 4, 0xf, 0xf, false));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x120 + 2, 0xf, 0xf, false));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x120 + 1, 0xf, 0xf, false));
+  m = max(m, bperm_i((lane ^ 16) << 2, m));
+  m = max(m, bperm_i((lane ^ 32) << 2, m));
+  const int e = ((m >> 23) & 255) - 126;  // largest entry < 2^e
   int p2 = 2 * (13 - ((e + 1) >> 1));
   p2 = p2 < -100 ? -100 : (p2 > 100 ? 100 : p2);
   const float s2 = __int_as_float((p2 + 127) << 23), inv_s2 = __int_as_float((127 - p2) << 23);
@@ -930,7 +942,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
     if (prime_next) pp.ch = chunk_issue(p, nxt.begin, nxt.len, 0, lane);
     const WorkItem nxt2 = load_item(p, it + 2 * n_waves);
     if (MODE == 0) {
-      add_ridge<T>(p, acc, cur.len, lane);
+      add_ridge<T, FULL>(p, acc, cur.len, lane);
       float minpiv = 3.0e38f;
       float xcol[T];
 #ifdef MALS_PROFILING
@@ -1051,7 +1063,7 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(acc[t][r], inv_s2, g4[r]);
         }
-        add_ridge<T>(p, acc, cur.len, lane);
+        add_ridge<T, FULL>(p, acc, cur.len, lane);
         float minpiv = 3.0e38f;
         float xcol[T];
         if constexpr (T >= 2) {  // the rank-16 updates of the factorization on the f16 pipe as well

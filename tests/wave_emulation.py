@@ -244,10 +244,11 @@ def split_tile(t):
 
 
 def row_scale(acc, bcol, T):
-    """row_scale: s^2 = 2^(2p) with s * sqrt(max diag) <= 2^13; returns 1/s^2."""
+    """row_scale: s^2 = 2^(2p) with s * sqrt(max diag) <= 2^13; returns 1/s^2.  The largest diagonal
+    element is taken as the largest |entry| of the diagonal tiles (equal for an SPD matrix)."""
     m = np.float32(0)
     for v in range(T):
-        m = max(m, np.float32(np.max(np.diag(tile_to_dense(acc[(v, v)])))))
+        m = max(m, np.float32(np.max(np.abs(acc[(v, v)]))))
     e = ((int(np.float32(m).view(np.uint32)) >> 23) & 255) - 126
     p2 = int(np.clip(2 * (13 - ((e + 1) >> 1)), -100, 100))
     s2, inv_s2 = np.float32(np.ldexp(1.0, p2)), np.float32(np.ldexp(1.0, -p2))
