@@ -30,6 +30,7 @@ WORKLOADS = {
     "c5shard8": (12_500_000, 10_000_000, 625_000_000, 128, "one rank's user rows of C5 at 8 GPUs (12.5M x 10M, 625M interactions requested), k=128"),
     "k128long": (1_000_000, 100_000, 400_000_000, 128, "k=128 with long rows (1M x 100K, 400M interactions requested)"),
     "k112": (2_000_000, 200_000, 200_000_000, 112, "k=112 (2M x 200K, 200M interactions requested)"),
+    "k30": (10_000_000, 1_000_000, 1_000_000_000, 30, "the reference's default feature count on the C4 shape (10M x 1M, 1e9 interactions requested, k=30)"),
     "mall400k": (400_000, 100_000, 400_000_000, 64, "cache probe: 400K x 100K, 400M interactions requested, k=64 (X = 102 MB)"),
     "mall2m": (2_000_000, 100_000, 400_000_000, 64, "cache probe: 2M x 100K, 400M interactions requested, k=64 (X = 512 MB)"),
     "small": (200_000, 50_000, 10_000_000, 64, "small smoke workload 200K x 50K, 10M interactions requested, k=64"),
