@@ -183,7 +183,7 @@ __device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos,
       piv = readlane(D[rn], 16 * gn + PN);
     }
   } else if constexpr (T_ < 15) {
-    asm volatile("s_nop 1\n\t"
+    asm volatile(".if %10 == 0\n\ts_nop 1\n\t.endif\n\t"
                  MALS_FMAC_BCAST(0, "%11 == 0") MALS_FMAC_BCAST(1, "%11 == 1") MALS_FMAC_BCAST(2, "%11 == 2") MALS_FMAC_BCAST(3, "%11 == 3")
                  : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
                  : "v"(nl), "n"(P), "n"(T_), "n"(rn));
@@ -191,15 +191,13 @@ __device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos,
     num = bperm(((16 * gn) | c) << 2, D[rn]);
     piv = readlane(D[rn], 16 * gn + PN);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 1\n\t"
-                 MALS_FMAC_BCAST(0, "(3 > %10) && (%11 != 0)") MALS_FMAC_BCAST(1, "(7 > %10) && (%11 != 1)")
+    asm volatile(MALS_FMAC_BCAST(0, "(3 > %10) && (%11 != 0)") MALS_FMAC_BCAST(1, "(7 > %10) && (%11 != 1)")
                  MALS_FMAC_BCAST(2, "(11 > %10) && (%11 != 2)") MALS_FMAC_BCAST(3, "(15 > %10) && (%11 != 3)")
                  MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
                  : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
                  : "v"(nl), "n"(P), "n"(T_), "n"(rn));
   } else {
-    asm volatile("s_nop 1\n\t"
-                 MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
+    asm volatile(MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
                  : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
                  : "v"(nl), "n"(P), "n"(T_), "n"(rn));
   }
