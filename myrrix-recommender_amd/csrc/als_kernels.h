@@ -152,7 +152,7 @@ __device__ __forceinline__ f32x4 tile_neg_ptq(const f32x4& P, const f32x4& Q, f3
 // finished after step 4r+3, register r of the inverse half is still zero before step 4r.  76 DPP FMAs
 // per tile instead of 128 (a DPP instruction costs two issue slots).
 __device__ __forceinline__ float spread_to_col(float v, int lane);
-template <int T_, bool PIPE>
+template <int T_>
 __device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos, float& minpiv, float& piv, float& num) {
   constexpr int gm = T_ & 3, rm = T_ >> 2, P = 4 * gm + rm;
   constexpr int gn = (T_ + 1) & 3, rn = ((T_ + 1) >> 2) & 3, PN = 4 * gn + rn;  // the next step's pivot
@@ -165,24 +165,12 @@ __device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos,
   // DPP read needs 2 wait states after a VALU write of the same register, which the compiler does not
   // track into asm: step 0 (whose operands may just have been copied) opens with an s_nop; later the
   // registers were last written by the previous step's block, 7+ instructions earlier
-  // (tools/check_dpp_hazards.py checks that on the generated ISA).  One block per step (the assembler's .if drops the finished /
-  // still-zero registers): a statement per FMA would let the compiler put a register copy right in
-  // front of a DPP read.  PIPE: the register of the next pivot goes first, so that the next step's pivot
-  // and multipliers (the ds_bpermute heads the step's dependency chain) are fetched under the other
-  // FMAs -- pays at two waves per SIMD (k > 64: k=128 X-half 40.7 -> 39.7 ms), costs at three (k = 64:
-  // 52.5 -> 53.1 ms, issue-bound: the second s_nop), hence the switch.
+  // (tools/check_dpp_hazards.py checks that on the generated ISA).  Blocks, not one statement per FMA
+  // (the assembler's .if drops the finished / still-zero registers): a statement per FMA would let the
+  // compiler put a register copy right in front of a DPP read.  The register of the next pivot goes first, so that the next step's pivot and
+  // multipliers (the ds_bpermute heads the step's dependency chain) are fetched under the other FMAs.
 #define MALS_FMAC_BCAST(n, cond) ".if " cond "\n\tv_fmac_f32_dpp %" #n ", %" #n ", %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t.endif\n\t"
-  if constexpr (!PIPE) {
-    asm volatile(".if %10 == 0\n\ts_nop 1\n\t.endif\n\t"
-                 MALS_FMAC_BCAST(0, "3 > %10") MALS_FMAC_BCAST(1, "7 > %10") MALS_FMAC_BCAST(2, "11 > %10") MALS_FMAC_BCAST(3, "15 > %10")
-                 MALS_FMAC_BCAST(4, "0 <= %10") MALS_FMAC_BCAST(5, "4 <= %10") MALS_FMAC_BCAST(6, "8 <= %10") MALS_FMAC_BCAST(7, "12 <= %10")
-                 : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
-                 : "v"(nl), "n"(P), "n"(T_));
-    if constexpr (T_ < 15) {
-      num = bperm(((16 * gn) | c) << 2, D[rn]);
-      piv = readlane(D[rn], 16 * gn + PN);
-    }
-  } else if constexpr (T_ < 15) {
+  if constexpr (T_ < 15) {
     asm volatile(".if %10 == 0\n\ts_nop 1\n\t.endif\n\t"
                  MALS_FMAC_BCAST(0, "%11 == 0") MALS_FMAC_BCAST(1, "%11 == 1") MALS_FMAC_BCAST(2, "%11 == 2") MALS_FMAC_BCAST(3, "%11 == 3")
                  : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3])
@@ -204,7 +192,6 @@ __device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos,
 #undef MALS_FMAC_BCAST
 }
 
-template <bool PIPE>
 __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   const int g = lane >> 4, c = lane & 15;
   const int pos = 4 * (c & 3) + (c >> 2);  // the step at which row c is the pivot row
@@ -213,22 +200,22 @@ __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   for (int r = 0; r < 4; ++r) E[r] = (4 * g + r == c) ? 1.f : 0.f;
   float num = bperm(c << 2, D[0]);   // step 0: pivot index 0 = register 0 of group 0
   float piv = readlane(D[0], 0);
-  diag_step<0, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<1, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<2, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<3, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<4, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<5, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<6, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<7, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<8, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<9, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<10, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<11, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<12, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<13, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<14, PIPE>(D, E, lane, pos, minpiv, piv, num);
-  diag_step<15, PIPE>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<0>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<1>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<2>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<3>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<4>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<5>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<6>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<7>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<8>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<9>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<10>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<11>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<12>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<13>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<14>(D, E, lane, pos, minpiv, piv, num);
+  diag_step<15>(D, E, lane, pos, minpiv, piv, num);
   // row c is scaled by 1/sqrt(its pivot), which lane (c>>2, c) still holds as D[c][c]
   const float s = __builtin_amdgcn_rsqf(spread_to_col(select4(c & 3, D[0], D[1], D[2], D[3]), lane));
 #pragma unroll
@@ -288,7 +275,7 @@ template <int T, bool SPLIT = false>
 __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
 #pragma unroll
   for (int kb = 0; kb < T; ++kb) {
-    const f32x4 Uinv = factor_diag<(T > 4)>(acc[tidx(T, kb, kb)], lane, minpiv);
+    const f32x4 Uinv = factor_diag(acc[tidx(T, kb, kb)], lane, minpiv);
     acc[tidx(T, kb, kb)] = Uinv;
 #pragma unroll
     for (int j = kb + 1; j < T; ++j) {  // U_kj = Uinv^T A_kj
