@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MALS_ABI_VERSION 1
+#define MALS_ABI_VERSION 2
 
 typedef struct mals_handle_s* mals_handle;
 
@@ -61,6 +61,8 @@ enum { MALS_MEM_HOST = 0, MALS_MEM_DEVICE = 1 };
 
 enum { MALS_GRAMIAN_AUTO = 0, MALS_GRAMIAN_FP32 = 1, MALS_GRAMIAN_SPLIT_F16 = 2 };
 
+enum { MALS_SOLVE_AUTO = 0, MALS_SOLVE_DIRECT = 1, MALS_SOLVE_DUAL = 2 };
+
 typedef struct mals_config {
   int32_t struct_size;          /* sizeof(mals_config), for ABI evolution                      */
   int32_t features;             /* k; ALS:134 "features must be positive"; 1..128 supported    */
@@ -85,7 +87,16 @@ typedef struct mals_config {
                                    2-4e-7 vs the fp64 reference for both);
                                    MALS_GRAMIAN_AUTO (default): FP32 for features <= 32 (where the
                                    products are not the bottleneck), SPLIT_F16 above            */
-  int32_t reserved0;
+  int32_t solve_mode;           /* how a row with FEWER ENTRIES THAN FEATURES is solved (ALS:447-494 is the
+                                   same k x k system either way):
+                                   MALS_SOLVE_DIRECT: the k x k system W x = b, whatever the row length;
+                                   MALS_SOLVE_DUAL: rows with n_u <= 16*floor(ceil(k/16)/2) entries through
+                                   the n_u x n_u system of the push-through identity in the eigenbasis of
+                                   the shared Gramian (csrc/dual_kernels.h: same x, 8x fewer factorization
+                                   flops at n_u <= k/2), the others directly; needs the reference's default
+                                   mode (flags = 0), alpha > 0 and min eig(G) + lambda*alpha >= 1e-4 and
+                                   otherwise falls back to DIRECT for that half-iteration;
+                                   MALS_SOLVE_AUTO (default): DUAL for features > 32, DIRECT below    */
 } mals_config;
 
 typedef struct mals_stats {
@@ -109,6 +120,15 @@ typedef struct mals_stats {
   double gramian_bytes;     /* rows*4k read                                                        */
   int64_t rows_solved;
   int64_t nnz_gathered;
+  /* appended in ABI version 2 */
+  double dual_ms;           /* als_dual_kernel: short rows through the n_u x n_u system               */
+  double rotate_ms;         /* rotate_rows_kernel: M Q before, x = Q x' after the dual kernels        */
+  int64_t dual_launches;
+  int64_t rotate_launches;
+  double dual_bytes;        /* entries*(4k+8) + rows*(4k+8), like rows_bytes                          */
+  double rotate_bytes;      /* rows*(4k + 64*ceil(k/16)) forward, rows*8k in place                    */
+  int64_t rows_dual;        /* rows solved by the dual kernels (included in rows_solved)              */
+  double eigen_host_ms;     /* host time of the k x k eigendecompositions (overlapped with kernels)   */
 } mals_stats;
 
 int mals_abi_version(void);

@@ -13,6 +13,8 @@ SIDE_X, SIDE_Y = 0, 1
 FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
+SOLVE_AUTO, SOLVE_DIRECT, SOLVE_DUAL = 0, 1, 2
+ABI_VERSION = 2
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
                 COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM",
@@ -25,7 +27,7 @@ class Config(ctypes.Structure):
                 ("singularity_threshold", ctypes.c_double), ("flags", ctypes.c_int32),
                 ("device", ctypes.c_int32), ("segment_nnz", ctypes.c_int32),
                 ("chunk_rows", ctypes.c_int32), ("gramian_mode", ctypes.c_int32),
-                ("reserved0", ctypes.c_int32)]
+                ("solve_mode", ctypes.c_int32)]
 
 
 class Stats(ctypes.Structure):
@@ -36,7 +38,11 @@ class Stats(ctypes.Structure):
                 ("finish_launches", ctypes.c_int64), ("gramian_launches", ctypes.c_int64),
                 ("rows_bytes", ctypes.c_double), ("segments_bytes", ctypes.c_double),
                 ("finish_bytes", ctypes.c_double), ("gramian_bytes", ctypes.c_double),
-                ("rows_solved", ctypes.c_int64), ("nnz_gathered", ctypes.c_int64)]
+                ("rows_solved", ctypes.c_int64), ("nnz_gathered", ctypes.c_int64),
+                ("dual_ms", ctypes.c_double), ("rotate_ms", ctypes.c_double),
+                ("dual_launches", ctypes.c_int64), ("rotate_launches", ctypes.c_int64),
+                ("dual_bytes", ctypes.c_double), ("rotate_bytes", ctypes.c_double),
+                ("rows_dual", ctypes.c_int64), ("eigen_host_ms", ctypes.c_double)]
 
 
 class ModelView(ctypes.Structure):
@@ -148,7 +154,7 @@ def load():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
-        if L.mals_abi_version() != 1:
+        if L.mals_abi_version() != ABI_VERSION:
             raise ImportError("libmyrrix_als.so ABI version mismatch")
         _lib = L
     return _lib

@@ -101,7 +101,7 @@ def _host(a, dtype):
 
 class ALSCore:
     def __init__(self, features, alpha=1.0, lam=0.1, flags=0, device=0, segment_nnz=0,
-                 singularity_threshold=1e-5, chunk_rows=0, gramian_mode=0):
+                 singularity_threshold=1e-5, chunk_rows=0, gramian_mode=0, solve_mode=0):
         self._L = _lib.load()
         cfg = _lib.Config()
         self._L.mals_default_config(ctypes.byref(cfg))
@@ -113,6 +113,7 @@ class ALSCore:
         cfg.segment_nnz = int(segment_nnz)
         cfg.chunk_rows = int(chunk_rows)
         cfg.gramian_mode = int(gramian_mode)
+        cfg.solve_mode = int(solve_mode)
         self.chunk_rows = max(0, int(chunk_rows))
         cfg.singularity_threshold = float(singularity_threshold)
         self.features = int(features)

@@ -1259,6 +1259,24 @@ __global__ void max_abs_kernel(const float* __restrict__ v, int64_t n, unsigned*
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// {min, max} over a column-index array (matrix upload: indices must stay inside the opposite replica)
+__global__ void col_range_kernel(const int32_t* __restrict__ col, int64_t n, int* __restrict__ out) {
+  int lo = 0x7fffffff, hi = (int)0x80000000;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = col[i];
+    lo = min(lo, c);
+    hi = max(hi, c);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = min(lo, __shfl_xor(lo, off));
+    hi = max(hi, __shfl_xor(hi, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(out, lo);
+    atomicMax(out + 1, hi);
+  }
+}
+
 // Reconstruction error over the stored entries of the local rows of R:
 // sum over (u,i) of max(0, 1 - x_u . y_i), the quantity ReconstructionEvaluator averages
 // (online/src/net/myrrix/online/eval/ReconstructionEvaluator.java:91-102), with the reference's dot

@@ -1,0 +1,354 @@
+// dual_kernels.h -- the "short row" solve path of the ALS half-iteration (gfx950, wave64).
+//
+// AlternatingLeastSquares.Worker.call (ALS:447-494) solves, per row u with n_u entries,
+//     W_u x_u = b_u,   W_u = G + sum_i w_i y_i y_i^T + rho_u I,   b_u = sum_i cb_i y_i,
+//     w_i = alpha |r_ui|,  cb_i = [r_ui > 0] (1 + w_i),  rho_u = lambda alpha n_u,  G = Y^T Y.
+// W_u is k x k however short the row is.  With the eigendecomposition G = Q diag(L) Q^T (host fp64,
+// host_eigen.h, once per half-iteration) and y' = Q^T y,  A_u = G + rho_u I = Q diag(L + rho_u) Q^T is
+// diagonal in the rotated coordinates, W_u = A_u + V^T C V (V = the n_u gathered rows, C = diag(w)) is
+// a rank-n_u update of it, and the push-through identity gives
+//     x_u = W_u^-1 V^T cb = A_u^-1 V^T C^1/2 (I + C^1/2 V A_u^-1 V^T C^1/2)^-1 C^-1/2 cb
+//         = Q D^1/2 Z^T S^-1 q,       D = diag(1 / (L + rho_u)),  Z = C^1/2 V' D^1/2  (n_u x k),
+//                                     S = I + Z Z^T  (n_u x n_u, SPD, eigenvalues >= 1),  q_i = cb_i / sqrt(w_i)
+// -- the SAME x_u (not an approximation), from an n_u x n_u Cholesky instead of a k x k one.  For
+// n_u <= k/2 that is 8x fewer factorization flops and a 4x smaller per-row Gramian (Z Z^T contracts
+// over k, n_u^2 k / 2 products instead of n_u k^2 / 2).  Measured error against the fp64 oracle is on a
+// par with the direct path (tests/test_gpu_dual.py, tools/dual_numerics.py: 2-5e-7 relative, also
+// with cond(G) = 1e6 and lambda = 0).
+//
+// Pieces (all launched by mals_api.hip on the handle's stream):
+//   rotate_rows_kernel<T,false>  Mr = M Q, row stride padded to 16T floats (fp32 matrix cores), plus the
+//                                bound max |y'_f| / sqrt(L_f + rho_1) for the f16 operand scale
+//   als_dual_kernel<T,TN>        one wave per row with 16(TN-1) < n_u <= 16 TN: gather the rotated rows
+//                                with lane <-> entry (the MFMA operand layout of Z, no cross-lane moves),
+//                                S on v_mfma_f32_16x16x32_f16 with split-f16 operands (as gather_row_h),
+//                                in-register Cholesky + solves on the TN x TN tiles (als_kernels.h),
+//                                x' = D^1/2 Z^T v through an MFMA transposition of Z
+//   rotate_rows_kernel<T,true>   x = Q x' in place over the rows of the dual work lists
+// The path is only taken in the reference's default mode (no reconstructR / lossIgnoresUnspecified),
+// alpha > 0, and min_f L_f + lambda alpha >= 1e-4 (A_u safely positive definite: the direct path could
+// not flag such a row as singular either); otherwise the same lists run through the direct kernels.
+#pragma once
+#include "als_kernels.h"
+
+namespace mals {
+
+struct DualParams {
+  const int32_t* col;
+  const float* val;
+  const float* Mr;          // rotated opposing factors, row stride 16T floats, zero padded
+  const float* lam;         // eigenvalues L_f of G, 16T floats (0 for the padding features)
+  const unsigned* zbound;   // bit pattern of max_{rows,f} |y'_f| / sqrt(L_f + rho_1)  (rotate_rows_kernel)
+  float* out;               // this side's factor replica + row_offset*k: x' is written here
+  const WorkItem* items;
+  unsigned long long* bad_row;
+  int64_t n_work;
+  int32_t k;
+  float alpha;
+  float lambda_alpha;
+  float sqrt_w_max;         // sqrt(alpha * max |r|): bound of C^1/2
+};
+
+struct RotateParams {
+  const float* src;
+  float* dst;
+  const float* B;           // k x 16T row-major: forward Q (zero padded columns), listed Q^T
+  const WorkItem* items;    // LISTED: the rows are items[i].id
+  const float* dmax;        // forward: 1 / sqrt(L_f + rho_1) per output column (16T floats)
+  unsigned* zbound;
+  int64_t n_rows;           // rows (forward) or list length (LISTED)
+  int32_t k;
+  int32_t src_stride, dst_stride, dst_cols;
+};
+
+__host__ __device__ constexpr int dual_max_blocks(int T) { return T / 2; }
+__host__ __device__ constexpr int dual_waves(int T, int TN) {
+  const int regs = 4 * T * TN + 4 * tri(TN) + 72;
+  return regs > 168 ? 2 : (regs > 128 ? 3 : (regs > 102 ? 4 : 5));
+}
+
+// dst rows = src rows x B on v_mfma_f32_16x16x4_f32: one wave per 16 rows, B (<= 64 KB) staged in LDS
+// once per workgroup with its columns rotated by 16 (f & 3) so that the four lane groups of a read hit
+// different banks.
+template <int T, bool LISTED>
+__global__ __launch_bounds__(256, 2) void rotate_rows_kernel(RotateParams p) {
+  constexpr int KP = 16 * T;
+  __shared__ float sB[KP * KP];
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  for (int e = threadIdx.x; e < KP * KP; e += 256) {
+    const int f = e / KP, j = e - f * KP;
+    const float v = f < p.k ? p.B[(int64_t)f * KP + j] : 0.f;
+    sB[f * KP + 16 * (((j >> 4) + (f & 3)) % T) + (j & 15)] = v;
+  }
+  __syncthreads();
+  const int64_t n_tiles = (p.n_rows + 15) >> 4;
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  int offs[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) offs[t] = 16 * ((t + g) % T) + c;
+  float dmaxcol[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) dmaxcol[t] = (!LISTED && p.dmax) ? p.dmax[16 * t + c] : 0.f;
+  float zmax = 0.f;
+  const int n_steps = (p.k + 3) >> 2;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
+    const int64_t rc = tile * 16 + c;
+    const bool okc = rc < p.n_rows;
+    const int64_t row_c = LISTED ? (int64_t)p.items[okc ? rc : p.n_rows - 1].id : rc;
+    const float* sp = p.src + row_c * (int64_t)p.src_stride + g;
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < n_steps; s0 += 4) {
+      float a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = 4 * (s0 + u) + g;
+        a[u] = (okc && f < p.k) ? sp[4 * (s0 + u)] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int f = 4 * (s0 + u) + g;
+        const float* bp = sB + (f < KP ? f : KP - 1) * KP;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = mfma4(a[u], bp[offs[t]], acc[t]);
+      }
+    }
+    // acc[t][r] = out[row 4g+r][16t+c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t rr = tile * 16 + 4 * g + r;
+      if (rr < p.n_rows) {
+        const int64_t row = LISTED ? (int64_t)p.items[rr].id : rr;
+        float* o = p.dst + row * (int64_t)p.dst_stride;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          if (16 * t + c < p.dst_cols) o[16 * t + c] = acc[t][r];
+          if (!LISTED) zmax = fmaxf(zmax, fabsf(acc[t][r]) * dmaxcol[t]);
+        }
+      }
+    }
+  }
+  if (!LISTED && p.zbound) {
+    for (int off = 32; off > 0; off >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off));
+    if (lane == 0) atomicMax(p.zbound, __float_as_uint(zmax));
+  }
+}
+
+// rows outside every work list that need no arithmetic: x = 0 (empty rows: b = 0)
+__global__ void zero_rows_kernel(const WorkItem* __restrict__ items, int64_t n, int k, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * k) return;
+  const int64_t i = e / k;
+  out[(int64_t)items[i].id * k + (e - i * k)] = 0.f;
+}
+
+template <int TN>
+struct DualEntries {
+  int col[TN];
+  float r[TN];
+};
+
+template <int TN>
+__device__ __forceinline__ DualEntries<TN> dual_load_entries(const DualParams& p, const WorkItem& w, int c) {
+  DualEntries<TN> e;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = 16 * b + c;
+    const int nn = n < w.len ? n : w.len - 1;
+    e.col[b] = __builtin_nontemporal_load(p.col + w.begin + nn);
+    e.r[b] = __builtin_nontemporal_load(p.val + w.begin + nn);
+  }
+  return e;
+}
+
+__device__ __forceinline__ WorkItem dual_load_item(const DualParams& p, int64_t it) {
+  WorkItem w;
+  if (it < p.n_work) {
+    w = p.items[it];
+  } else {
+    w.begin = 0;
+    w.len = -1;
+    w.id = 0;
+  }
+  return w;
+}
+
+template <int T, int TN>
+__global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualParams p) {
+  constexpr int KP = 16 * T, KC = (T + 1) / 2, NMAX = 16 * TN;
+  __shared__ float sD[NMAX * KP];  // sD[n-1][f] = 1 / sqrt(L_f + lambda alpha n)
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  for (int e = threadIdx.x; e < NMAX * KP; e += 256) {
+    const int n = e / KP + 1, f = e - (n - 1) * KP;
+    sD[e] = 1.0f / sqrtf(p.lam[f] + p.lambda_alpha * (float)n);
+  }
+  __syncthreads();
+  const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  int64_t it = wave;
+  if (it >= p.n_work) return;
+  // operand scale: |z| <= sqrt_w_max * zbound;  Sc = 2^pw with |z| Sc <= 2^14 (f16 cannot overflow)
+  float sc, inv_sc, inv_sc2;
+  {
+    const float bound = __uint_as_float(uniform((int)*p.zbound)) * p.sqrt_w_max;
+    int e = ((__float_as_int(bound) >> 23) & 255) - 126;  // bound < 2^e
+    int pw = 14 - e;
+    pw = pw < -60 ? -60 : (pw > 60 ? 60 : pw);
+    if (!(bound > 0.f)) pw = 0;
+    sc = __int_as_float((pw + 127) << 23);
+    inv_sc = __int_as_float((127 - pw) << 23);
+    inv_sc2 = __int_as_float((127 - 2 * pw) << 23);
+  }
+  // identity operand of the transposition MFMA (v_mfma_f32_16x16x16_f16): B[k = 4g+s][j = c] = [k == j]
+  i32x2h ident;
+  {
+    const int s = c - 4 * g;
+    ident[0] = s == 0 ? 0x3c00 : (s == 1 ? 0x3c000000 : 0);
+    ident[1] = s == 2 ? 0x3c00 : (s == 3 ? 0x3c000000 : 0);
+  }
+  float idn[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) idn[r] = (4 * g + r == c) ? 1.f : 0.f;
+
+  WorkItem cur = dual_load_item(p, it);
+  WorkItem nxt = dual_load_item(p, it + n_waves);
+  DualEntries<TN> en = dual_load_entries<TN>(p, cur, c);
+  for (;;) {
+    const int n = cur.len;
+    // (1) all gathers of the row: lane (g,c) reads, for entry c of every 16-entry block, 16 bytes at
+    // float offset 16 j + 4 g of the rotated row -- 64 contiguous bytes per entry and instruction
+    f32x4 raw[TN][T];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      if (16 * b < n) {
+        const float* ptr = p.Mr + ((uint64_t)(uint32_t)en.col[b] * (uint32_t)KP + (uint32_t)(4 * g));
+#pragma unroll
+        for (int j = 0; j < T; ++j) raw[b][j] = *reinterpret_cast<const f32x4*>(ptr + 16 * j);
+      } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j) raw[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    // weights of this lane's entries (ALS:471-482)
+    float ws[TN], qcol[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const bool ok = 16 * b + c < n;
+      const float r = en.r[b];
+      const float ar = p.alpha * fabsf(r);
+      const float w = ok ? __builtin_sqrtf(ar) : 0.f;
+      const float cb = (ok && r > 0.f) ? 1.f + ar : 0.f;
+      qcol[b] = w > 0.f ? cb / w : 0.f;
+      ws[b] = w * sc;
+    }
+    // next row's entries and the item after it land during this row's arithmetic
+    if (nxt.len > 0) en = dual_load_entries<TN>(p, nxt, c);
+    const WorkItem nx2 = dual_load_item(p, it + 2 * n_waves);
+    __builtin_amdgcn_sched_barrier(0);
+    // (2) z = sqrt(w) Sc d y', split into two f16 halves (22 significand bits, as gather_row_h)
+    ZOp<8> zh[TN][KC], zl[TN][KC];
+    const float* dn = sD + (n - 1) * KP + 4 * g;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+#pragma unroll
+      for (int j = 0; j < 2 * KC; ++j) {
+        if (j < T) {
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(dn + 16 * j);
+          const f32x4 y = raw[b][j];
+          const float z0 = y[0] * d4[0] * ws[b], z1 = y[1] * d4[1] * ws[b];
+          const float z2 = y[2] * d4[2] * ws[b], z3 = y[3] * d4[3] * ws[b];
+          const int h01 = pk_rtz(z0, z1), h23 = pk_rtz(z2, z3);
+          const f16x2 a = __builtin_bit_cast(f16x2, h01), bb = __builtin_bit_cast(f16x2, h23);
+          zh[b][j >> 1].r[2 * (j & 1)] = h01;
+          zh[b][j >> 1].r[2 * (j & 1) + 1] = h23;
+          zl[b][j >> 1].r[2 * (j & 1)] = pk_rtz(fmaf((float)a[0], -1.f, z0), fmaf((float)a[1], -1.f, z1));
+          zl[b][j >> 1].r[2 * (j & 1) + 1] = pk_rtz(fmaf((float)bb[0], -1.f, z2), fmaf((float)bb[1], -1.f, z3));
+        } else {  // odd T: the upper half of the last 32-feature chunk is padding
+          zh[b][j >> 1].r[2 * (j & 1)] = 0;
+          zh[b][j >> 1].r[2 * (j & 1) + 1] = 0;
+          zl[b][j >> 1].r[2 * (j & 1)] = 0;
+          zl[b][j >> 1].r[2 * (j & 1) + 1] = 0;
+        }
+      }
+    }
+    // (3) S = I + Z Z^T on the f16 matrix pipe: zh zh^T + zh zl^T + zl zh^T, contraction over the features
+    f32x4 acc[tri(TN)];
+#pragma unroll
+    for (int t = 0; t < tri(TN); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = i; j < TN; ++j) acc[tidx(TN, i, j)] = mfma_h<8>(zh[i][q], zh[j][q], acc[tidx(TN, i, j)]);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = i; j < TN; ++j) acc[tidx(TN, i, j)] = mfma_h<8>(zh[i][q], zl[j][q], acc[tidx(TN, i, j)]);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = i; j < TN; ++j) acc[tidx(TN, i, j)] = mfma_h<8>(zl[i][q], zh[j][q], acc[tidx(TN, i, j)]);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = i; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[tidx(TN, i, j)][r] = i == j ? fmaf(acc[tidx(TN, i, j)][r], inv_sc2, idn[r]) : acc[tidx(TN, i, j)][r] * inv_sc2;
+    // (4) S v = q: Cholesky + triangular solves on the TN x TN tiles, in registers
+    float minpiv = 3.0e38f;
+    float vcol[TN];
+    if constexpr (TN >= 2) {
+      const float inv_s2row = row_scale<TN>(acc, qcol, lane);
+      cholesky_tiles<TN, true>(acc, lane, minpiv);
+      minpiv *= inv_s2row;
+    } else {
+      cholesky_tiles<TN>(acc, lane, minpiv);
+    }
+    solve_tiles<TN>(acc, qcol, vcol, lane);
+    // (5) x' = D^1/2 Z^T v / Sc.  Z sits with lane <-> entry; an MFMA against the identity turns one
+    // 16-entry x 16-feature piece into accumulator layout (lane (g,c) reg r = z[entry 4g+r][feature c],
+    // zh + zl added exactly in fp32), where the sum over the entries is 4 FMAs and one group reduction.
+    float xacc[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) xacc[j] = 0.f;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const f32x4 vrow = col_to_row(vcol[b], lane);
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        i32x2h ah, al;
+        ah[0] = zh[b][j >> 1].r[2 * (j & 1)];
+        ah[1] = zh[b][j >> 1].r[2 * (j & 1) + 1];
+        al[0] = zl[b][j >> 1].r[2 * (j & 1)];
+        al[1] = zl[b][j >> 1].r[2 * (j & 1) + 1];
+        f32x4 t = mfma16h(ah, ident, f32x4{0.f, 0.f, 0.f, 0.f});
+        t = mfma16h(al, ident, t);
+        xacc[j] = fmaf(t[0], vrow[0], xacc[j]);
+        xacc[j] = fmaf(t[1], vrow[1], xacc[j]);
+        xacc[j] = fmaf(t[2], vrow[2], xacc[j]);
+        xacc[j] = fmaf(t[3], vrow[3], xacc[j]);
+      }
+    }
+    const bool bad = !(minpiv > 0.5f);  // S >= I: only a non-finite input gets here
+    if (bad && lane == 0) atomicMin(p.bad_row, (unsigned long long)cur.id);
+    {
+      float* o = p.out + (int64_t)cur.id * p.k;
+      const float* dc = sD + (n - 1) * KP + c;
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        const float x = reduce_groups(xacc[j], lane) * dc[16 * j] * inv_sc;
+        if (lane < 16 && 16 * j + lane < p.k) o[16 * j + lane] = bad ? 0.f : x;
+      }
+    }
+    if (nxt.len <= 0) break;
+    cur = nxt;
+    nxt = nx2;
+    it += n_waves;
+  }
+}
+
+}  // namespace mals

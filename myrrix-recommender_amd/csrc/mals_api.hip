@@ -5,6 +5,8 @@
 // MALS_HIP_ERROR otherwise.
 #include "../../include/myrrix_als.h"
 #include "als_kernels.h"
+#include "dual_kernels.h"
+#include "host_eigen.h"
 #include "host_solver.h"
 #include "topn_kernels.h"
 
@@ -12,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,14 +55,22 @@ struct SideState {
   RowC* rowsC = nullptr;
   int64_t nC = 0;
   float* scratch = nullptr;
+  int32_t col_min = 0, col_max = -1;  // range of the column indices (checked against the opposite replica)
   float max_abs_val = 0.f;  // bound on |value| used for the operand scale (>= local_max_abs_val)
   float local_max_abs_val = 0.f;  // largest |value| of the shard
   // the lists are stored chunk-major (contiguous ranges of cfg.chunk_rows rows of the shard), each
   // chunk sorted by length; a chunk can be solved on its own so that the caller can overlap the
   // exchange of finished chunks with the solve of the next one
+  // itemsA of a chunk: [nA rows for the direct kernel, longest first, then ONE representative empty
+  // row] [the dual classes: nD[3] rows with 48 < len <= 64, nD[2] ..., nD[0] rows with len <= 16 --
+  // descending length throughout] [nZ further empty rows: x = 0, same verdict as the representative]
   struct ChunkRange {
     int64_t offA = 0, nA = 0, nnzA = 0, offB = 0, nB = 0, nnzB = 0, offC = 0, nC = 0;
+    int64_t nD[4] = {0, 0, 0, 0}, nnzD[4] = {0, 0, 0, 0}, nZ = 0;
+    int64_t n_dual() const { return nD[0] + nD[1] + nD[2] + nD[3]; }
+    int64_t nnz_dual() const { return nnzD[0] + nnzD[1] + nnzD[2] + nnzD[3]; }
   };
+  int64_t n_dual_rows = 0;
   std::vector<ChunkRange> chunks;
   // Gramian of THIS side's factors (consumed when solving the other side)
   double* G = nullptr;
@@ -72,7 +83,7 @@ struct SideState {
 
 struct PendingEvent {
   hipEvent_t a, b;
-  int kind;  // 0 = rows, 1 = segments, 2 = finish, 3 = gramian
+  int kind;  // 0 = rows, 1 = segments, 2 = finish, 3 = gramian, 4 = dual, 5 = rotate
   double bytes;
 };
 
@@ -82,11 +93,24 @@ struct mals_handle_s {
   mals_config cfg;
   int T = 0;
   bool split_f16 = false;  // cfg.gramian_mode resolved
+  int dual_blocks = 0;     // cfg.solve_mode resolved: rows up to 16*dual_blocks entries go to the dual lists (0 = none)
+  // dual path state (dual_kernels.h): rotated copy of the gathered factor matrix, Q / Q^T / eigenvalues
+  float* d_Mr = nullptr;
+  size_t Mr_cap = 0;          // floats
+  float* d_Q = nullptr;       // [2][16T][16T]: Q (k x 16T, zero padded) and Q^T
+  float* d_lam = nullptr;     // [2][16T]: eigenvalues, 1/sqrt(L + lambda alpha)
+  unsigned* d_zbound = nullptr;
+  double* h_G = nullptr;      // pinned k x k
+  hipEvent_t ev_G = nullptr;
+  int dual_side = -1;         // what the rotated copy currently holds: solved side, version of the opposite G
+  uint64_t dual_version = 0;
+  bool dual_ok = false;       // the half-iteration's systems qualify for the dual path
   float* d_zscale = nullptr;  // {S, 1/S^2} of the split-precision gather (gather_scale_kernel)
   int zs_side = -1;           // what d_zscale currently holds: solved side, version of the opposite G, value bound
   uint64_t zs_version = 0;
   float zs_bound = -1.f;
   unsigned* d_maxabs = nullptr;
+  int* d_colrange = nullptr;
   int n_cu = 256;
   SideState side[2];
   hipStream_t stream = nullptr;
@@ -177,6 +201,7 @@ int64_t slot_floats(int T) { return (int64_t)(tri(T) * 4 + T) * 64; }
 // Split the rows of a shard into the three work lists (DESIGN.md "work decomposition"), chunk by chunk.
 int build_work_lists(mals_handle h, SideState& s) {
   s.max_abs_val = 0.f;
+  s.n_dual_rows = 0;
   if (s.nnz > 0) {  // one pass over the values: bounds the Gramian weights (gather_scale_kernel)
     HIPCHK(h, hipMemsetAsync(h->d_maxabs, 0, sizeof(unsigned), h->stream));
     const unsigned blocks = (unsigned)std::min<int64_t>(4096, (s.nnz + 255) / 256);
@@ -186,6 +211,22 @@ int build_work_lists(mals_handle h, SideState& s) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   s.local_max_abs_val = s.max_abs_val;
+  s.col_min = 0;
+  s.col_max = -1;
+  if (s.nnz > 0) {  // the same pass over the column indices: an index outside the opposite replica would be an
+                    // out-of-bounds device access in the gather (and a write in the top-N mask)
+    const int init[2] = {std::numeric_limits<int>::max(), std::numeric_limits<int>::min()};
+    HIPCHK(h, hipMemcpyAsync(h->d_colrange, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    const unsigned blocks = (unsigned)std::min<int64_t>(4096, (s.nnz + 255) / 256);
+    hipLaunchKernelGGL(col_range_kernel, dim3(blocks), dim3(256), 0, h->stream, s.col, s.nnz, h->d_colrange);
+    HIPCHK(h, hipGetLastError());
+    int range[2];
+    HIPCHK(h, hipMemcpyAsync(range, h->d_colrange, sizeof(range), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    s.col_min = range[0];
+    s.col_max = range[1];
+    if (s.col_min < 0) return fail(h, MALS_INVALID_ARG, "negative column index");
+  }
   const int64_t n = s.n_local;
   const int seg = h->cfg.segment_nnz;
   const int64_t chunk_rows = h->cfg.chunk_rows > 0 ? h->cfg.chunk_rows : std::max<int64_t>(n, 1);
@@ -204,15 +245,26 @@ int build_work_lists(mals_handle h, SideState& s) {
     cr.offA = (int64_t)order.size();
     cr.offB = (int64_t)segs.size();
     cr.offC = (int64_t)rowsC.size();
-    // counting sort of the chunk's short rows by length, longest first
+    // counting sort of the chunk's short rows by length, longest first (stable: ascending row inside a length)
     std::fill(count.begin(), count.end(), 0);
+    const int64_t dual_len = 16 * (int64_t)h->dual_blocks;  // rows with 1..dual_len entries: dual lists
+    int64_t n_short = 0, n_direct = 0, n_empty = 0;
     for (int64_t r = r0; r < r1; ++r) {
       const int64_t len = rp[r + 1] - rp[r];
       if (len < 0) return fail(h, MALS_INVALID_ARG, "row_ptr must be non-decreasing");
       if (len <= seg) {
         ++count[(size_t)(seg - len)];
-        ++cr.nA;
-        cr.nnzA += len;
+        ++n_short;
+        if (len == 0) {
+          ++n_empty;
+        } else if (len <= dual_len) {
+          const int cls = (int)((len - 1) >> 4);
+          ++cr.nD[cls];
+          cr.nnzD[cls] += len;
+        } else {
+          ++n_direct;
+          cr.nnzA += len;
+        }
       } else {
         cr.nnzB += len;
       }
@@ -223,7 +275,7 @@ int build_work_lists(mals_handle h, SideState& s) {
       count[b] = acc;
       acc += cnt;
     }
-    order.resize((size_t)(cr.offA + cr.nA));
+    order.resize((size_t)(cr.offA + n_short));
     for (int64_t r = r0; r < r1; ++r) {
       const int64_t len = rp[r + 1] - rp[r];
       if (len <= seg) {
@@ -251,6 +303,17 @@ int build_work_lists(mals_handle h, SideState& s) {
         rowsC.push_back(rc);
       }
     }
+    // Every empty row has the same system (W = G, b = 0: ALS:447-494 with no entries): x = 0, and the
+    // verdict "singular" is shared.  One representative (the smallest row) goes through the kernel, right
+    // behind the direct rows; the others are only zero-filled.
+    const int64_t n_dual = cr.n_dual();
+    if (n_empty > 0 && n_dual > 0) {
+      auto first = order.begin() + (size_t)(cr.offA + n_direct);
+      std::rotate(first, first + (size_t)n_dual, first + (size_t)n_dual + 1);
+    }
+    cr.nA = n_direct + (n_empty > 0 ? 1 : 0);
+    cr.nZ = n_empty > 0 ? n_empty - 1 : 0;
+    s.n_dual_rows += n_dual;
     cr.nB = (int64_t)segs.size() - cr.offB;
     cr.nC = (int64_t)rowsC.size() - cr.offC;
     // longest segments first
@@ -277,10 +340,18 @@ int build_work_lists(mals_handle h, SideState& s) {
 
 int validate_matrix(mals_handle h, int side) {
   SideState& s = h->side[side];
-  const SideState& o = h->side[1 - side];
-  (void)o;
   if (s.h_row_ptr.size() != (size_t)s.n_local + 1 || s.h_row_ptr[0] != 0 || s.h_row_ptr[(size_t)s.n_local] != s.nnz)
     return fail(h, MALS_INVALID_ARG, "row_ptr must have n_rows_local+1 entries, start at 0 and end at nnz");
+  return MALS_OK;
+}
+
+// col_idx must index rows of the OPPOSITE side's factor replica (checked again at solve time: the
+// replica may be declared after the matrix)
+int validate_columns(mals_handle h, int side) {
+  const SideState& s = h->side[side];
+  const SideState& o = h->side[1 - side];
+  if (s.nnz > 0 && o.n_total > 0 && (int64_t)s.col_max >= o.n_total)
+    return fail(h, MALS_INVALID_ARG, "column index outside the opposite side's factor replica");
   return MALS_OK;
 }
 
@@ -311,6 +382,8 @@ int drain_events(mals_handle h) {
       case 0: st.rows_ms += ms; st.rows_launches += 1; st.rows_bytes += pe.bytes; break;
       case 1: st.segments_ms += ms; st.segments_launches += 1; st.segments_bytes += pe.bytes; break;
       case 2: st.finish_ms += ms; st.finish_launches += 1; st.finish_bytes += pe.bytes; break;
+      case 4: st.dual_ms += ms; st.dual_launches += 1; st.dual_bytes += pe.bytes; break;
+      case 5: st.rotate_ms += ms; st.rotate_launches += 1; st.rotate_bytes += pe.bytes; break;
       default: st.gramian_ms += ms; st.gramian_launches += 1; st.gramian_bytes += pe.bytes; break;
     }
     (void)hipEventDestroy(pe.a);
@@ -375,13 +448,16 @@ int persistent_grid(mals_handle h, K kernel, int64_t n_work, unsigned* grid) {
   return MALS_OK;
 }
 
+enum { LISTS_OWN = 1, LISTS_DUAL_ROWS = 2 };  // the direct kernels over: segments / rows / finish / zero-fill; the dual lists
+
 template <typename KA, typename KB, typename KC>
-int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, KA rows_kernel, KB segments_kernel, KC finish_kernel) {
+int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int which, KA rows_kernel, KB segments_kernel, KC finish_kernel) {
   const double per = 4.0 * p.k + 8.0;  // gathered row + col idx + value; written row + row_ptr
   const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
   PendingEvent pe;
   unsigned grid = 1;
-  if (cr.nB) {
+  const bool own = which & LISTS_OWN, dual_rows_too = which & LISTS_DUAL_ROWS;
+  if (own && cr.nB) {
     p.n_work = cr.nB;
     p.items = s.itemsB + cr.offB;
     if (int rc = persistent_grid(h, segments_kernel, cr.nB, &grid)) return rc;
@@ -389,7 +465,7 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, KA rows_
     hipLaunchKernelGGL(segments_kernel, dim3(grid), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
-  if (cr.nA) {
+  if (own && cr.nA) {
     p.n_work = cr.nA;
     p.items = s.itemsA + cr.offA;
     if (int rc = persistent_grid(h, rows_kernel, cr.nA, &grid)) return rc;
@@ -397,41 +473,225 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, KA rows_
     hipLaunchKernelGGL(rows_kernel, dim3(grid), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
-  if (cr.nC) {
+  if (dual_rows_too && cr.n_dual()) {  // the dual lists through the direct kernel (the half-iteration does not qualify)
+    p.n_work = cr.n_dual();
+    p.items = s.itemsA + cr.offA + cr.nA;
+    if (int rc = persistent_grid(h, rows_kernel, p.n_work, &grid)) return rc;
+    if (int rc = begin_timed(h, 0, (double)cr.nnz_dual() * per + (double)cr.n_dual() * per, pe)) return rc;
+    hipLaunchKernelGGL(rows_kernel, dim3(grid), dim3(256), 0, h->stream, p);
+    if (int rc = end_timed(h, pe)) return rc;
+  }
+  if (own && cr.nC) {
     p.n_work = cr.nC;
     p.rowsC = s.rowsC + cr.offC;
     if (int rc = begin_timed(h, 2, (double)cr.nC * per, pe)) return rc;
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((cr.nC + 3) / 4)), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
+  if (own && cr.nZ) {
+    const int64_t elems = cr.nZ * p.k;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, h->stream,
+                       s.itemsA + cr.offA + cr.nA + cr.n_dual(), cr.nZ, p.k, p.out);
+  }
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
 }
 
 template <int T, int D, bool FULL>
-int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk) {
+int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk, int which) {
   if (h->split_f16)
-    return launch_lists(h, s, p, chunk, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>, als_finish_kernel<T>);
-  return launch_lists(h, s, p, chunk, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
+    return launch_lists(h, s, p, chunk, which, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>, als_finish_kernel<T>);
+  return launch_lists(h, s, p, chunk, which, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
 }
 
 template <int T, int D>
-int launch_solve_T(mals_handle h, SideState& s, const SolveParams& p, int chunk) {
-  return p.k == 16 * T ? launch_solve_TF<T, D, true>(h, s, p, chunk) : launch_solve_TF<T, D, false>(h, s, p, chunk);
+int launch_solve_T(mals_handle h, SideState& s, const SolveParams& p, int chunk, int which) {
+  return p.k == 16 * T ? launch_solve_TF<T, D, true>(h, s, p, chunk, which) : launch_solve_TF<T, D, false>(h, s, p, chunk, which);
 }
 
-int launch_solve(mals_handle h, SideState& s, const SolveParams& p, int chunk) {
+// the direct kernels over a chunk's lists (LISTS_*)
+int launch_solve(mals_handle h, SideState& s, const SolveParams& p, int chunk, int which) {
   switch (h->T) {
-    case 1: return launch_solve_T<1, 4>(h, s, p, chunk);
-    case 2: return launch_solve_T<2, 4>(h, s, p, chunk);
-    case 3: return launch_solve_T<3, 4>(h, s, p, chunk);
-    case 4: return launch_solve_T<4, MALS_D4>(h, s, p, chunk);
-    case 5: return launch_solve_T<5, 2>(h, s, p, chunk);
-    case 6: return launch_solve_T<6, 2>(h, s, p, chunk);
-    case 7: return launch_solve_T<7, 2>(h, s, p, chunk);
-    case 8: return launch_solve_T<8, 2>(h, s, p, chunk);
+    case 1: return launch_solve_T<1, 4>(h, s, p, chunk, which);
+    case 2: return launch_solve_T<2, 4>(h, s, p, chunk, which);
+    case 3: return launch_solve_T<3, 4>(h, s, p, chunk, which);
+    case 4: return launch_solve_T<4, MALS_D4>(h, s, p, chunk, which);
+    case 5: return launch_solve_T<5, 2>(h, s, p, chunk, which);
+    case 6: return launch_solve_T<6, 2>(h, s, p, chunk, which);
+    case 7: return launch_solve_T<7, 2>(h, s, p, chunk, which);
+    case 8: return launch_solve_T<8, 2>(h, s, p, chunk, which);
   }
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
+// ---- dual path (dual_kernels.h) ------------------------------------------------------------------
+template <int T, bool LISTED>
+int launch_rotate_T(mals_handle h, const RotateParams& rp) {
+  const int64_t tiles = (rp.n_rows + 15) / 16;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, (int64_t)h->n_cu * 2));
+  hipLaunchKernelGGL((rotate_rows_kernel<T, LISTED>), dim3(grid), dim3(256), 0, h->stream, rp);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+template <bool LISTED>
+int launch_rotate(mals_handle h, const RotateParams& rp) {
+  switch (h->T) {
+    case 2: return launch_rotate_T<2, LISTED>(h, rp);
+    case 3: return launch_rotate_T<3, LISTED>(h, rp);
+    case 4: return launch_rotate_T<4, LISTED>(h, rp);
+    case 5: return launch_rotate_T<5, LISTED>(h, rp);
+    case 6: return launch_rotate_T<6, LISTED>(h, rp);
+    case 7: return launch_rotate_T<7, LISTED>(h, rp);
+    case 8: return launch_rotate_T<8, LISTED>(h, rp);
+  }
+  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
+template <int T, int TN>
+int launch_dual_TN(mals_handle h, DualParams dp) {
+  unsigned grid = 1;
+  if (int rc = persistent_grid(h, als_dual_kernel<T, TN>, dp.n_work, &grid)) return rc;
+  hipLaunchKernelGGL((als_dual_kernel<T, TN>), dim3(grid), dim3(256), 0, h->stream, dp);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+template <int T>
+int launch_dual_T(mals_handle h, const DualParams& dp, int tn) {
+  if constexpr (T >= 2) { if (tn == 1) return launch_dual_TN<T, 1>(h, dp); }
+  if constexpr (T >= 4) { if (tn == 2) return launch_dual_TN<T, 2>(h, dp); }
+  if constexpr (T >= 6) { if (tn == 3) return launch_dual_TN<T, 3>(h, dp); }
+  if constexpr (T >= 8) { if (tn == 4) return launch_dual_TN<T, 4>(h, dp); }
+  return fail(h, MALS_INVALID_ARG, "no dual kernel for this row class");
+}
+int launch_dual(mals_handle h, const DualParams& dp, int tn) {
+  switch (h->T) {
+    case 2: return launch_dual_T<2>(h, dp, tn);
+    case 3: return launch_dual_T<3>(h, dp, tn);
+    case 4: return launch_dual_T<4>(h, dp, tn);
+    case 5: return launch_dual_T<5>(h, dp, tn);
+    case 6: return launch_dual_T<6>(h, dp, tn);
+    case 7: return launch_dual_T<7>(h, dp, tn);
+    case 8: return launch_dual_T<8>(h, dp, tn);
+  }
+  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
+// Once per half-iteration: G (opposite side) -> host, eigendecomposition, Q / Q^T / eigenvalues ->
+// device, rotated copy of the opposite factors.  Called AFTER the direct kernels of the first chunk
+// have been enqueued, so the host work runs under them.  Sets h->dual_ok.
+int prepare_dual(mals_handle h, int side) {
+  SideState& s = h->side[side];
+  SideState& o = h->side[1 - side];
+  const int k = h->cfg.features, KP = 16 * h->T;
+  h->dual_side = side;
+  h->dual_version = o.G_version;
+  h->dual_ok = false;
+  HIPCHK(h, hipEventSynchronize(h->ev_G));  // h_G <- o.G was enqueued before the direct kernels
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<double> evals((size_t)k), V((size_t)k * k);
+  const bool ok = mals::symmetric_eigen(h->h_G, k, evals.data(), V.data());
+  h->stats.eigen_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!ok) return MALS_OK;
+  double lmin = evals[0];
+  for (int f = 0; f < k; ++f) lmin = std::min(lmin, evals[(size_t)f]);
+  const double la = h->cfg.lambda * h->cfg.alpha;
+  // A_u = G + lambda alpha n_u I must be safely positive definite for every n_u >= 1 (then W_u is too,
+  // and the direct path could not have flagged the row either); tiny negative eigenvalues of a
+  // rank-deficient G are rounding
+  if (!(lmin + la >= 1.0e-4)) return MALS_OK;
+  std::vector<float> Q((size_t)2 * KP * KP, 0.f), lam((size_t)2 * KP, 0.f);
+  for (int f = 0; f < k; ++f)
+    for (int j = 0; j < k; ++j) {
+      Q[(size_t)f * KP + j] = (float)V[(size_t)f * k + j];                        // forward: y' = y Q
+      Q[(size_t)KP * KP + (size_t)f * KP + j] = (float)V[(size_t)j * k + f];      // back: x = x' Q^T
+    }
+  for (int f = 0; f < KP; ++f) {
+    const double l = f < k ? std::max(evals[(size_t)f], 0.0) : 0.0;
+    lam[(size_t)f] = (float)l;
+    lam[(size_t)KP + f] = (float)(1.0 / std::sqrt(l + la));
+  }
+  if (!h->d_Q) HIPCHK(h, hipMalloc(&h->d_Q, sizeof(float) * Q.size()));
+  if (!h->d_lam) HIPCHK(h, hipMalloc(&h->d_lam, sizeof(float) * lam.size()));
+  if (!h->d_zbound) HIPCHK(h, hipMalloc(&h->d_zbound, sizeof(unsigned)));
+  const size_t need = (size_t)o.n_total * KP;
+  if (h->Mr_cap < need) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    free_dev(h->d_Mr);
+    h->Mr_cap = 0;
+    HIPCHK(h, hipMalloc(&h->d_Mr, sizeof(float) * need));
+    h->Mr_cap = need;
+  }
+  // pageable sources: these copies return once the data is staged, the vectors may go out of scope
+  HIPCHK(h, hipMemcpyAsync(h->d_Q, Q.data(), sizeof(float) * Q.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_lam, lam.data(), sizeof(float) * lam.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_zbound, 0, sizeof(unsigned), h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  RotateParams rp;
+  rp.src = o.F;
+  rp.dst = h->d_Mr;
+  rp.B = h->d_Q;
+  rp.items = nullptr;
+  rp.dmax = h->d_lam + KP;
+  rp.zbound = h->d_zbound;
+  rp.n_rows = o.n_total;
+  rp.k = k;
+  rp.src_stride = k;
+  rp.dst_stride = KP;
+  rp.dst_cols = KP;
+  PendingEvent pe;
+  if (int rc = begin_timed(h, 5, (double)o.n_total * (4.0 * k + 4.0 * KP), pe)) return rc;
+  if (int rc = launch_rotate<false>(h, rp)) return rc;
+  if (int rc = end_timed(h, pe)) return rc;
+  (void)s;
+  h->dual_ok = true;
+  return MALS_OK;
+}
+
+// the dual lists of one chunk: als_dual_kernel per row class, then x = Q x' in place
+int launch_dual_chunk(mals_handle h, int side, int chunk) {
+  SideState& s = h->side[side];
+  const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
+  const int k = h->cfg.features, KP = 16 * h->T;
+  const double per = 4.0 * k + 8.0;
+  DualParams dp;
+  dp.col = s.col;
+  dp.val = s.val;
+  dp.Mr = h->d_Mr;
+  dp.lam = h->d_lam;
+  dp.zbound = h->d_zbound;
+  dp.out = s.F + s.row_offset * k;
+  dp.bad_row = h->d_bad + side;
+  dp.k = k;
+  dp.alpha = (float)h->cfg.alpha;
+  dp.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);
+  dp.sqrt_w_max = (float)std::sqrt(std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
+  const WorkItem* base = s.itemsA + cr.offA + cr.nA;
+  int64_t off = 0;
+  PendingEvent pe;
+  for (int cls = 3; cls >= 0; --cls) {  // descending length, as stored
+    if (!cr.nD[cls]) continue;
+    dp.items = base + off;
+    dp.n_work = cr.nD[cls];
+    if (int rc = begin_timed(h, 4, (double)cr.nnzD[cls] * per + (double)cr.nD[cls] * per, pe)) return rc;
+    if (int rc = launch_dual(h, dp, cls + 1)) return rc;
+    if (int rc = end_timed(h, pe)) return rc;
+    off += cr.nD[cls];
+  }
+  RotateParams rp;
+  rp.src = dp.out;
+  rp.dst = dp.out;
+  rp.B = h->d_Q + (size_t)KP * KP;
+  rp.items = base;
+  rp.dmax = nullptr;
+  rp.zbound = nullptr;
+  rp.n_rows = cr.n_dual();
+  rp.k = k;
+  rp.src_stride = k;
+  rp.dst_stride = k;
+  rp.dst_cols = k;
+  if (int rc = begin_timed(h, 5, (double)cr.n_dual() * 8.0 * k, pe)) return rc;
+  if (int rc = launch_rotate<true>(h, rp)) return rc;
+  return end_timed(h, pe);
 }
 
 int ensure_gramian_buffers(mals_handle h, SideState& s) {
@@ -718,6 +978,7 @@ int mals_default_config(mals_config* cfg) {
   cfg->segment_nnz = 0;
   cfg->chunk_rows = 0;
   cfg->gramian_mode = MALS_GRAMIAN_AUTO;
+  cfg->solve_mode = MALS_SOLVE_AUTO;
   return MALS_OK;
 }
 
@@ -746,6 +1007,15 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
     case MALS_GRAMIAN_SPLIT_F16: h->split_f16 = true; break;
     default: delete h; return MALS_INVALID_ARG;
   }
+  // a negative alpha (accepted by the reference, ALS:506-509) has no real sqrt(alpha |r|): fp32 gather
+  if (cfg->alpha < 0.0) h->split_f16 = false;
+  switch (cfg->solve_mode) {
+    case MALS_SOLVE_AUTO: h->dual_blocks = h->T >= 3 ? dual_max_blocks(h->T) : 0; break;
+    case MALS_SOLVE_DIRECT: h->dual_blocks = 0; break;
+    case MALS_SOLVE_DUAL: h->dual_blocks = dual_max_blocks(h->T); break;
+    default: delete h; return MALS_INVALID_ARG;
+  }
+  if (h->cfg.flags != 0 || !(cfg->alpha > 0.0)) h->dual_blocks = 0;  // the dual path covers the default mode only
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -756,6 +1026,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(&h->h_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&h->d_zscale, 2 * sizeof(float)) != hipSuccess || hipMalloc(&h->d_maxabs, sizeof(unsigned)) != hipSuccess ||
+      hipMalloc(&h->d_colrange, 2 * sizeof(int)) != hipSuccess ||
       hipMemset(h->d_bad, 0xff, 2 * sizeof(unsigned long long)) != hipSuccess) {
     delete h;
     return MALS_HIP_ERROR;
@@ -805,6 +1076,13 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_bad);
   free_dev(h->d_zscale);
   free_dev(h->d_maxabs);
+  free_dev(h->d_colrange);
+  free_dev(h->d_Mr);
+  free_dev(h->d_Q);
+  free_dev(h->d_lam);
+  free_dev(h->d_zbound);
+  if (h->h_G) (void)hipHostFree(h->h_G);
+  if (h->ev_G) (void)hipEventDestroy(h->ev_G);
   if (h->h_bad) (void)hipHostFree(h->h_bad);
   free_dev(h->d_idx);
   free_dev(h->d_rows);
@@ -906,6 +1184,10 @@ int mals_set_matrix(mals_handle h, int side, int64_t row_offset, int64_t n_rows_
     free_matrix(s);
     return rc;
   }
+  if (int rc = validate_columns(h, side)) {
+    free_matrix(s);
+    return rc;
+  }
   s.has_matrix = true;
   return MALS_OK;
 }
@@ -968,6 +1250,10 @@ int mals_end_matrix(mals_handle h, int side) {
   if (int rc = use_device(h)) return rc;
   HIPCHK(h, hipMemcpy(s.row_ptr, s.h_row_ptr.data(), sizeof(int64_t) * (size_t)(s.n_local + 1), hipMemcpyHostToDevice));
   if (int rc = build_work_lists(h, s)) {
+    free_matrix(s);
+    return rc;
+  }
+  if (int rc = validate_columns(h, side)) {
     free_matrix(s);
     return rc;
   }
@@ -1102,6 +1388,7 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   if (!s.has_matrix) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
   if (!s.F || !o.F) return fail(h, MALS_INVALID_ARG, "factor replicas not allocated");
   if (s.row_offset + s.n_local > s.n_total) return fail(h, MALS_INVALID_ARG, "matrix rows exceed the factor replica");
+  if (int rc = validate_columns(h, side)) return rc;
   // the split-precision gather takes its scale from the Gramian's diagonal even when W does not start from G
   const bool use_g = !(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) || h->split_f16;
   if (use_g && !o.G_valid) return fail(h, MALS_INVALID_ARG, "Gramian of the opposite side not computed");
@@ -1142,11 +1429,36 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
     h->zs_version = o.G_version;
     h->zs_bound = s.max_abs_val;
   }
+  // dual path (dual_kernels.h): the reference's default mode only; the Gramian goes to the host first so
+  // that its eigendecomposition runs while the direct kernels of the first chunk execute
+  const bool want_dual = s.n_dual_rows > 0 && h->cfg.flags == 0 && h->cfg.alpha > 0.0 && o.G_valid;
+  const bool dual_stale = want_dual && (h->dual_side != side || h->dual_version != o.G_version);
+  if (dual_stale) {
+    if (!h->h_G) HIPCHK(h, hipHostMalloc(&h->h_G, sizeof(double) * (size_t)k * k));
+    if (!h->ev_G) HIPCHK(h, hipEventCreateWithFlags(&h->ev_G, hipEventDisableTiming));
+    HIPCHK(h, hipMemcpyAsync(h->h_G, o.G, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipEventRecord(h->ev_G, h->stream));
+  }
   for (int c = chunk_begin; c < chunk_end; ++c) {
-    if (int rc = launch_solve(h, s, p, c)) return rc;
     const SideState::ChunkRange& cr = s.chunks[(size_t)c];
-    h->stats.rows_solved += cr.nA + cr.nC;
-    h->stats.nnz_gathered += cr.nnzA + cr.nnzB;
+    bool dual_now = want_dual && !dual_stale && h->dual_ok;
+    if (want_dual && dual_stale && c == chunk_begin) {
+      if (int rc = launch_solve(h, s, p, c, LISTS_OWN)) return rc;  // direct lists first ...
+      if (int rc = prepare_dual(h, side)) return rc;            // ... host eigendecomposition under them
+      dual_now = h->dual_ok;
+      if (dual_now) {
+        if (int rc = launch_dual_chunk(h, side, c)) return rc;
+      } else if (cr.n_dual()) {  // does not qualify: the dual lists through the direct kernel after all
+        if (int rc = launch_solve(h, s, p, c, LISTS_DUAL_ROWS)) return rc;
+      }
+    } else {
+      if (int rc = launch_solve(h, s, p, c, dual_now ? LISTS_OWN : (LISTS_OWN | LISTS_DUAL_ROWS))) return rc;
+      if (dual_now && cr.n_dual())
+        if (int rc = launch_dual_chunk(h, side, c)) return rc;
+    }
+    h->stats.rows_solved += cr.nA + cr.nC + cr.n_dual() + cr.nZ;
+    h->stats.nnz_gathered += cr.nnzA + cr.nnzB + cr.nnz_dual();
+    if (dual_now) h->stats.rows_dual += cr.n_dual();
   }
   // this side's factors changed: its Gramian is stale.  (The OPPOSITE side's Gramian stays valid
   // for the remaining chunks of this half-iteration.)

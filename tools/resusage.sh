@@ -1,6 +1,6 @@
 #!/bin/bash
 # prints VGPR/AGPR/occupancy per kernel matching $1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Rpass-analysis=kernel-resource-usage -c /root/repo/myrrix-recommender_amd/csrc/mals_api.hip -o /tmp/x.o 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage -c /root/repo/myrrix-recommender_amd/csrc/mals_api.hip -o /tmp/x.o 2>&1 | python3 -c "
 import sys,re
 pat=sys.argv[1]
 cur=None;d={}
