@@ -88,9 +88,23 @@ def main():
     ap.add_argument("--segment-nnz", type=int, default=0)
     ap.add_argument("--gramian-mode", default="auto", choices=["auto", "fp32", "split_f16"],
                     help="mals_config.gramian_mode (A/B only; the headline number uses the library default)")
+    ap.add_argument("--solve-mode", default="auto", choices=["auto", "direct", "dual"],
+                    help="mals_config.solve_mode (A/B only; the headline number uses the library default)")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N>1: solve each slice in this many row chunks and all-gather a finished chunk while the next is solved")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execvp(cmd[0], cmd)
 
     import torch
     import torch.distributed as dist
@@ -101,8 +115,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed launcher (see the module docstring)" % args.gpus)
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -126,7 +138,8 @@ def main():
         upr = sharded.rows_per_rank(n_users, world)
         chunk_rows = (upr + args.exchange_chunks - 1) // args.exchange_chunks
     core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, chunk_rows=chunk_rows,
-                       gramian_mode={"auto": 0, "fp32": 1, "split_f16": 2}[args.gramian_mode])
+                       gramian_mode={"auto": 0, "fp32": 1, "split_f16": 2}[args.gramian_mode],
+                       solve_mode={"auto": 0, "direct": 1, "dual": 2}[args.solve_mode])
     core.set_stream(torch.cuda.current_stream().cuda_stream)
     als = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device=device, force_collectives=force)
     als.set_matrix_from_full(pkg.SIDE_X, *prob["r_csr"])
@@ -159,7 +172,8 @@ def main():
             als.half_iteration(side)
             torch.cuda.synchronize()
             h = core.stats()
-            halves[name] = {kk: round(h[kk + "_ms"], 3) for kk in ("rows", "segments", "finish", "gramian")}
+            halves[name] = {kk: round(h[kk + "_ms"], 3) for kk in ("rows", "segments", "finish", "gramian", "dual", "rotate")}
+            halves[name]["rows_dual"] = h["rows_dual"]
             halves[name]["rows_GBps"] = round(h["rows_bytes"] / max(h["rows_ms"], 1e-9) / 1e6, 1)
         core.enable_timing(False)
     # untimed: the exchange on its own ("report all-gather time separately") -- the
@@ -186,17 +200,32 @@ def main():
         dist.all_reduce(q)
         rec_sum, rec_cnt = float(q[0].item()), int(q[1].item())
 
+    planted_err = None
+    if world == 1:
+        planted_err = synth.planted_reconstruction_error(prob, als.factors(pkg.SIDE_X), als.factors(pkg.SIDE_Y))
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        # dominant kernel: the fused gather + Gramian + Cholesky kernel over list A (MODE 0); the
-        # split-precision variant (als_persistent_kernel_h) is what AUTO selects above k = 32
+        # dominant kernel = the one with the most time in the timed region: the fused gather + Gramian +
+        # Cholesky kernel over the direct rows (MODE 0; als_persistent_kernel_h is what AUTO selects above
+        # k = 32) or the dual kernels of the short rows (als_dual_kernel<T,TN>, all row classes together)
         split = args.gramian_mode == "split_f16" or (args.gramian_mode == "auto" and k > 32)
-        kernel_name = ("mals::als_persistent_kernel_h<T=%d,MODE=0> (fused gather + split-f16 Gramian + Cholesky, rows)"
-                       if split else
-                       "mals::als_persistent_kernel<T=%d,D,MODE=0> (fused gather + fp32 Gramian + Cholesky, rows)") % ((k + 15) // 16)
-        avg_ms = st["rows_ms"] / max(st["rows_launches"], 1)
-        bytes_per_launch = st["rows_bytes"] / max(st["rows_launches"], 1)
+        dom = "dual" if st["dual_ms"] > st["rows_ms"] else "rows"
+        if dom == "dual":
+            kernel_name = "mals::als_dual_kernel<T=%d,TN=1..%d> (short rows: gather of rotated rows + n_u x n_u system, all row classes of a half-iteration)" % ((k + 15) // 16, (k + 15) // 32)
+            # one "launch" = the dual kernels of one half-iteration (up to 4 row classes back to back)
+            n_launch = max(st["rows_launches"], 1) if st["rows_launches"] else max(st["dual_launches"], 1)
+        else:
+            kernel_name = ("mals::als_persistent_kernel_h<T=%d,MODE=0> (fused gather + split-f16 Gramian + Cholesky, rows)"
+                           if split else
+                           "mals::als_persistent_kernel<T=%d,D,MODE=0> (fused gather + fp32 Gramian + Cholesky, rows)") % ((k + 15) // 16)
+            n_launch = max(st["rows_launches"], 1)
+        avg_ms = st[dom + "_ms"] / n_launch
+        bytes_per_launch = st[dom + "_bytes"] / n_launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # the other roofline of the per-row systems: fp32-equivalent matrix-pipe work of the factorizations
+        # (k^3/3 + 2 k^2 flop per direct row) against the dense fp32 MFMA peak
+        k3_flop = (st["rows_solved"] - st["rows_dual"]) / args.steps * (k ** 3 / 3.0 + 2.0 * k * k)
+        k3_ms_at_peak = k3_flop / 157.3e12 * 1e3
         # HBM traffic per launch of the same kernel from the PMC passes committed under profiles/
         # (rocprofv3 cannot run inside this process); null when no profile matches this workload
         traffic, traffic_src = None, None
@@ -218,7 +247,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc, "users": n_users, "items": n_items, "nnz": int(prob["nnz"]), "features": k,
+            "config": {"workload": desc, "users": n_users, "items": n_items, "nnz": int(prob["nnz"]), "features": k, "planted": prob.get("planted"),
                        "alpha": 1.0, "lambda": 0.1,
                        "arithmetic": ("per-row Gramian: operands split into two f16 halves (22 significand bits), exact products, fp32 accumulate"
                                       if split else "per-row Gramian: fp32 products, fp32 accumulate") +
@@ -229,13 +258,21 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "launches": st["rows_launches"]},
-            "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian")},
+                         "launches": n_launch,
+                         "iteration": {"algorithmic_bytes": (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps,
+                                       "hbm_floor_ms": (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps / (HBM_PEAK_GBS * 1e6),
+                                       "direct_factorization_fp32_mfma_floor_ms": k3_ms_at_peak,
+                                       "binding": "hbm" if (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps / (HBM_PEAK_GBS * 1e6) >= k3_ms_at_peak else "mfma_fp32"}},
+            "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian", "dual", "rotate")},
+            "rows_dual_per_step": st["rows_dual"] / args.steps,
+            "eigen_host_ms_per_step": st["eigen_host_ms"] / args.steps,
             "half_iteration_kernel_ms": halves,
             "all_gather_alone_ms": exchange,
             "reconstruction_error": {"mean": rec_sum / max(rec_cnt, 1), "entries": rec_cnt,
                                      "what": "mean over stored entries of max(0, 1 - x_u.y_i) after warmup+steps iterations "
-                                             "(ReconstructionEvaluator.java:91-102), untimed"},
+                                             "(ReconstructionEvaluator.java:91-102), untimed; planted_part = the same over the entries of the "
+                                             "planted low-rank part (synth.torch_problem), the only part a factor model can predict",
+                                     "planted_part": planted_err},
         }
         if world == 1 and not args.no_cpu_baseline:
             X = als.factors(pkg.SIDE_X)

@@ -180,6 +180,12 @@ int mals_end_matrix(mals_handle h, int side);
  * on how the rows are sharded.  The override must be >= the local maximum. */
 int mals_get_value_bound(mals_handle h, int side, float* max_abs_value);
 int mals_set_value_bound(mals_handle h, int side, float max_abs_value);
+/* The same with the second statistic the split-precision gather looks at: sum of |value| and number of
+ * entries of the local rows (their ratio is the "typical" weight of the operand-range check that decides
+ * per launch between the split-precision and the fp32 gather).  A multi-GPU caller adds the sums and
+ * counts of all shards and installs max and mean everywhere. */
+int mals_get_value_stats(mals_handle h, int side, float* max_abs_value, double* sum_abs_value, int64_t* n_values);
+int mals_set_value_stats(mals_handle h, int side, float max_abs_value, double mean_abs_value);
 
 /* Host <-> device factor rows.  setPreviousY (ALS:172-174) = mals_set_factors(MALS_SIDE_Y, ...);
  * getX()/getY() (ALS:149-157) = mals_get_factors. */

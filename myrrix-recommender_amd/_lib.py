@@ -83,6 +83,9 @@ SYMBOLS = {
     "mals_end_matrix": (ctypes.c_int, [_H, ctypes.c_int]),
     "mals_get_value_bound": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     "mals_set_value_bound": (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_float]),
+    "mals_get_value_stats": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_int64)]),
+    "mals_set_value_stats": (ctypes.c_int, [_H, ctypes.c_int, ctypes.c_float, ctypes.c_double]),
     "mals_set_factors": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),
     "mals_get_factors": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),
     "mals_get_rows": (ctypes.c_int, [_H, ctypes.c_int, _P, _I32, _P]),

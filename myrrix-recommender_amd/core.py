@@ -223,6 +223,15 @@ class ALSCore:
     def set_value_bound(self, side, max_abs_value):
         self._chk(self._L.mals_set_value_bound(self._h, side, float(max_abs_value)))
 
+    def value_stats(self, side):
+        """(largest |value|, sum of |value|, number of entries) of the local rows."""
+        m, sm, n = ctypes.c_float(0.0), ctypes.c_double(0.0), ctypes.c_int64(0)
+        self._chk(self._L.mals_get_value_stats(self._h, side, ctypes.byref(m), ctypes.byref(sm), ctypes.byref(n)))
+        return m.value, sm.value, n.value
+
+    def set_value_stats(self, side, max_abs_value, mean_abs_value):
+        self._chk(self._L.mals_set_value_stats(self._h, side, float(max_abs_value), float(mean_abs_value)))
+
     # -- factors ----------------------------------------------------------------------------------
     def set_factors(self, side, rows, row_begin=0):
         rows = _host(rows, np.float32)

@@ -62,11 +62,11 @@ struct SolveParams {
   unsigned long long* bad_row; // first (smallest) local row with a non-PD system
   int64_t n_work;           // waves of work in the list this launch handles
   int32_t k;
-  int32_t flags;            // bit0 reconstructR, bit1 lossIgnoresUnspecified
+  int32_t flags;            // bit0 reconstructR, bit1 lossIgnoresUnspecified, bit3 run only if zscale[2] == 0
   float alpha;
   float lambda_alpha;       // lambda*alpha
   float sing_threshold;
-  const float* zscale;      // split-precision gather only: {S, 1/S^2}, written by gather_scale_kernel
+  const float* zscale;      // split-precision gather only: {S, 1/S^2, range flag}, written by gather_scale_kernel
   unsigned long long* trace;  // profiling only (MALS_DEBUG_TRACE): per-phase s_memtime stamps
   int trace_start;            // first traced row of a wave's list (MALS_DEBUG_TRACE=<n>)
 };
@@ -881,6 +881,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
   }
   int64_t it = wave;
   if (it >= p.n_work) return;
+  if ((p.flags & 8) && p.zscale[2] != 0.f) return;  // enqueued as the fallback of a split-precision launch that ran
   WorkItem cur = load_item(p, it);
   WorkItem nxt = load_item(p, it + n_waves);
   Pipe<T, D> pp;
@@ -999,6 +1000,7 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
   }
   int64_t it = wave;
   if (it >= p.n_work) return;
+  if (p.zscale[2] == 0.f) return;  // operand range too wide for the f16 split: the fp32 kernels behind this launch run
   const float zscale = __int_as_float(uniform(__float_as_int(p.zscale[0])));
   const float inv_s2 = __int_as_float(uniform(__float_as_int(p.zscale[1])));
   WorkItem cur = load_item(p, it);
@@ -1233,11 +1235,20 @@ __global__ void gramian_pack_kernel(const double* __restrict__ G, int k, int T, 
 
 // Split-precision gather: S = 2^p with  max|z| = sqrt(w_max) * S * max|y| <= 2^14.  max|y| is
 // bounded by sqrt(max_f G_ff) (G = M^T M of the gathered factor matrix, always at hand), w_max by
-// the largest |value| of the matrix side (max_abs_kernel at upload).  out = {S, 1/S^2}.
-__global__ void gather_scale_kernel(const double* __restrict__ G, int k, float sqrt_w_max, float* __restrict__ out) {
+// the largest |value| of the matrix side (max_abs_kernel at upload).  out = {S, 1/S^2, range flag}.
+// Range flag: a typical operand, sqrt(w_mean) * rms|y_f| (rms over the n_rows rows that make up G), sits
+// log2(bound / typical) binades below the bound; both f16 halves of z keep all their bits while
+// z S >= 2^-2, i.e. up to 16 binades.  Beyond that (an outlier value or factor row stretching the
+// bound) the launch is NOT run in split precision: flag = 0 makes the split kernels return at once and
+// the fp32-gather kernels enqueued behind them do the work (no host round trip).
+__global__ void gather_scale_kernel(const double* __restrict__ G, int k, float sqrt_w_max, float sqrt_w_mean, double n_rows,
+                                    int force_flag, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double d = 0.0;
-  for (int f = 0; f < k; ++f) d = fmax(d, G[(int64_t)f * k + f]);
+  double d = 0.0, tr = 0.0;
+  for (int f = 0; f < k; ++f) {
+    d = fmax(d, G[(int64_t)f * k + f]);
+    tr += G[(int64_t)f * k + f];
+  }
   const double bound = sqrt(d) * (double)sqrt_w_max;
   int e = 0;
   if (bound > 0.0 && bound < 1.0e300) {
@@ -1248,15 +1259,32 @@ __global__ void gather_scale_kernel(const double* __restrict__ G, int k, float s
   }
   out[0] = (float)ldexp(1.0, e);
   out[1] = (float)ldexp(1.0, -2 * e);
+  const double typical = (double)sqrt_w_mean * sqrt(tr / ((double)k * fmax(n_rows, 1.0)));
+  float ok = 1.f;
+  if (typical > 0.0 && bound > 0.0 && bound / typical > 65536.0) ok = 0.f;
+  if (!(bound < 1.0e300)) ok = 0.f;  // non-finite Gramian: leave it to the fp32 kernels
+  if (force_flag >= 0) ok = (float)force_flag;
+  out[2] = ok;
 }
 
-// max |v| over a value array, as the bit pattern of a non-negative float (atomicMax on uint)
-__global__ void max_abs_kernel(const float* __restrict__ v, int64_t n, unsigned* __restrict__ out) {
+// max |v| over a value array, as the bit pattern of a non-negative float (atomicMax on uint), and
+// sum |v| (for the mean: the dynamic-range check of the split-precision gather)
+__global__ void max_abs_kernel(const float* __restrict__ v, int64_t n, unsigned* __restrict__ out, double* __restrict__ sum_out) {
   float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(v[i]));
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = fabsf(v[i]);
+    m = fmaxf(m, a);
+    s += (double)a;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, off));
+    s += __shfl_xor(s, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, __float_as_uint(m));
+    atomicAdd(sum_out, s);
+  }
 }
 
 // {min, max} over a column-index array (matrix upload: indices must stay inside the opposite replica)

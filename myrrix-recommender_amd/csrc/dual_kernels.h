@@ -17,7 +17,7 @@
 // with cond(G) = 1e6 and lambda = 0).
 //
 // Pieces (all launched by mals_api.hip on the handle's stream):
-//   rotate_rows_kernel<T,false>  Mr = M Q, row stride padded to 16T floats (fp32 matrix cores), plus the
+//   rotate_rows_kernel<T,false>  Mr = M Q, row stride padded to 16T floats (fp32 or fp64 matrix cores), plus the
 //                                bound max |y'_f| / sqrt(L_f + rho_1) for the f16 operand scale
 //   als_dual_kernel<T,TN>        one wave per row with 16(TN-1) < n_u <= 16 TN: gather the rotated rows
 //                                with lane <-> entry (the MFMA operand layout of Z, no cross-lane moves),
@@ -52,7 +52,8 @@ struct DualParams {
 struct RotateParams {
   const float* src;
   float* dst;
-  const float* B;           // k x 16T row-major: forward Q (zero padded columns), listed Q^T
+  const double* B;          // k x 16T row-major: forward Q (zero padded columns), listed Q^T
+  const float* Bf;          // the same in fp32
   const WorkItem* items;    // LISTED: the rows are items[i].id
   const float* dmax;        // forward: 1 / sqrt(L_f + rho_1) per output column (16T floats)
   unsigned* zbound;
@@ -67,67 +68,85 @@ __host__ __device__ constexpr int dual_waves(int T, int TN) {
   return regs > 168 ? 2 : (regs > 128 ? 3 : (regs > 102 ? 4 : 5));
 }
 
-// dst rows = src rows x B on v_mfma_f32_16x16x4_f32: one wave per 16 rows, B (<= 64 KB) staged in LDS
-// once per workgroup with its columns rotated by 16 (f & 3) so that the four lane groups of a read hit
-// different banks.
-template <int T, bool LISTED>
+// dst rows = src rows x B on the matrix cores, rounded to fp32 at the end.  One wave per 64 (fp32) or 32
+// (fp64) rows; B (k x 16T, <= 128 KB as doubles) is read through L1/L2.
+// Two arithmetics, chosen per half-iteration on the host from the spectrum of G:
+//   F64 = false  v_mfma_f32_16x16x4_f32 (33 cycles): fp32 products and sums -- fine as long as no rotated
+//                coordinate is a tiny difference of large products, i.e. for cond(G + rho I) <= 1e5;
+//   F64 = true   v_mfma_f64_16x16x4_f64 (64 cycles): with one factor row 1e4 times the others, G's leading
+//                eigenvector is that row's direction and its OTHER rotated coordinates are 1e-7 of its norm --
+//                an fp32 accumulation loses them entirely (measured 1e-2 error in x).
+// The un-rotation x = Q x' (LISTED) has no such cancellation and always runs in fp32.
+// C/D layouts: f32: lane l reg r = D[row 4 (l>>4) + r][col l&15];  f64: D[row (l>>4) + 4 r][col l&15].
+template <int T, bool LISTED, bool F64>
 __global__ __launch_bounds__(256, 2) void rotate_rows_kernel(RotateParams p) {
   constexpr int KP = 16 * T;
-  __shared__ float sB[KP * KP];
+  // 16-row tiles per wave: every B operand read from L1/L2 feeds NT matrix instructions, enough of them
+  // (NT T x 33 or 64 cycles per T loads) to cover the latency of the next step's reads
+  constexpr int NT = F64 ? 2 : 4;
+  typedef typename std::conditional<F64, double, float>::type real;
+  typedef typename std::conditional<F64, f64x4, f32x4>::type real4;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  for (int e = threadIdx.x; e < KP * KP; e += 256) {
-    const int f = e / KP, j = e - f * KP;
-    const float v = f < p.k ? p.B[(int64_t)f * KP + j] : 0.f;
-    sB[f * KP + 16 * (((j >> 4) + (f & 3)) % T) + (j & 15)] = v;
-  }
-  __syncthreads();
-  const int64_t n_tiles = (p.n_rows + 15) >> 4;
+  const int64_t n_tiles = (p.n_rows + 16 * NT - 1) / (16 * NT);
   const int64_t n_waves = (int64_t)gridDim.x * 4;
-  int offs[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) offs[t] = 16 * ((t + g) % T) + c;
+  const real* B = reinterpret_cast<const real*>(F64 ? (const void*)p.B : (const void*)p.Bf);
   float dmaxcol[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) dmaxcol[t] = (!LISTED && p.dmax) ? p.dmax[16 * t + c] : 0.f;
   float zmax = 0.f;
   const int n_steps = (p.k + 3) >> 2;
   for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
-    const int64_t rc = tile * 16 + c;
-    const bool okc = rc < p.n_rows;
-    const int64_t row_c = LISTED ? (int64_t)p.items[okc ? rc : p.n_rows - 1].id : rc;
-    const float* sp = p.src + row_c * (int64_t)p.src_stride + g;
-    f32x4 acc[T];
+    const float* sp[NT];
+    bool okc[NT];
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < n_steps; s0 += 4) {
-      float a[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int f = 4 * (s0 + u) + g;
-        a[u] = (okc && f < p.k) ? sp[4 * (s0 + u)] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int f = 4 * (s0 + u) + g;
-        const float* bp = sB + (f < KP ? f : KP - 1) * KP;
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = mfma4(a[u], bp[offs[t]], acc[t]);
-      }
+    for (int h = 0; h < NT; ++h) {
+      const int64_t rc = tile * (16 * NT) + 16 * h + c;
+      okc[h] = rc < p.n_rows;
+      const int64_t row_c = LISTED ? (int64_t)p.items[okc[h] ? rc : p.n_rows - 1].id : (okc[h] ? rc : 0);
+      sp[h] = p.src + row_c * (int64_t)p.src_stride + g;
     }
-    // acc[t][r] = out[row 4g+r][16t+c]
+    real4 acc[NT][T];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t rr = tile * 16 + 4 * g + r;
-      if (rr < p.n_rows) {
-        const int64_t row = LISTED ? (int64_t)p.items[rr].id : rr;
-        float* o = p.dst + row * (int64_t)p.dst_stride;
+    for (int h = 0; h < NT; ++h)
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (16 * t + c < p.dst_cols) o[16 * t + c] = acc[t][r];
-          if (!LISTED) zmax = fmaxf(zmax, fabsf(acc[t][r]) * dmaxcol[t]);
+      for (int t = 0; t < T; ++t) acc[h][t] = real4{0, 0, 0, 0};
+    for (int s = 0; s < n_steps; ++s) {
+      const int f = 4 * s + g;
+      const bool okf = f < p.k;
+      real a[NT];
+#pragma unroll
+      for (int h = 0; h < NT; ++h) a[h] = (okc[h] && okf) ? (real)sp[h][4 * s] : (real)0;
+      const real* bp = B + (int64_t)(okf ? f : 0) * KP + c;
+      real b[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) b[t] = bp[16 * t];
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int h = 0; h < NT; ++h) {
+          if constexpr (F64) {
+            acc[h][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h], b[t], acc[h][t], 0, 0, 0);
+          } else {
+            acc[h][t] = mfma4(a[h], b[t], acc[h][t]);
+          }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NT; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t rr = tile * (16 * NT) + 16 * h + (F64 ? g + 4 * r : 4 * g + r);
+        if (rr < p.n_rows) {
+          const int64_t row = LISTED ? (int64_t)p.items[rr].id : rr;
+          float* o = p.dst + row * (int64_t)p.dst_stride;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const float v = (float)acc[h][t][r];
+            if (16 * t + c < p.dst_cols) o[16 * t + c] = v;
+            if (!LISTED) zmax = fmaxf(zmax, fabsf(v) * dmaxcol[t]);
+          }
         }
       }
-    }
   }
   if (!LISTED && p.zbound) {
     for (int off = 32; off > 0; off >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off));

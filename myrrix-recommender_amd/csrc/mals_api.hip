@@ -22,6 +22,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #ifndef MALS_D4
@@ -58,6 +59,8 @@ struct SideState {
   int32_t col_min = 0, col_max = -1;  // range of the column indices (checked against the opposite replica)
   float max_abs_val = 0.f;  // bound on |value| used for the operand scale (>= local_max_abs_val)
   float local_max_abs_val = 0.f;  // largest |value| of the shard
+  double mean_abs_val = 0.0;      // mean |value| used by the operand-range check (all shards if the caller synced it)
+  double local_mean_abs_val = 0.0;  // mean |value| of the shard
   // the lists are stored chunk-major (contiguous ranges of cfg.chunk_rows rows of the shard), each
   // chunk sorted by length; a chunk can be solved on its own so that the caller can overlap the
   // exchange of finished chunks with the solve of the next one
@@ -97,7 +100,9 @@ struct mals_handle_s {
   // dual path state (dual_kernels.h): rotated copy of the gathered factor matrix, Q / Q^T / eigenvalues
   float* d_Mr = nullptr;
   size_t Mr_cap = 0;          // floats
-  float* d_Q = nullptr;       // [2][16T][16T]: Q (k x 16T, zero padded) and Q^T
+  double* d_Q = nullptr;      // [2][16T][16T]: Q (k x 16T, zero padded) and Q^T
+  float* d_Qf = nullptr;      // the same in fp32
+  bool rotate_f64 = false;    // this half-iteration's forward rotation runs on the fp64 matrix cores
   float* d_lam = nullptr;     // [2][16T]: eigenvalues, 1/sqrt(L + lambda alpha)
   unsigned* d_zbound = nullptr;
   double* h_G = nullptr;      // pinned k x k
@@ -109,6 +114,7 @@ struct mals_handle_s {
   int zs_side = -1;           // what d_zscale currently holds: solved side, version of the opposite G, value bound
   uint64_t zs_version = 0;
   float zs_bound = -1.f;
+  double zs_mean = -1.0;
   unsigned* d_maxabs = nullptr;
   int* d_colrange = nullptr;
   int n_cu = 256;
@@ -201,14 +207,23 @@ int64_t slot_floats(int T) { return (int64_t)(tri(T) * 4 + T) * 64; }
 // Split the rows of a shard into the three work lists (DESIGN.md "work decomposition"), chunk by chunk.
 int build_work_lists(mals_handle h, SideState& s) {
   s.max_abs_val = 0.f;
+  s.mean_abs_val = 0.0;
+  s.local_mean_abs_val = 0.0;
   s.n_dual_rows = 0;
   if (s.nnz > 0) {  // one pass over the values: bounds the Gramian weights (gather_scale_kernel)
-    HIPCHK(h, hipMemsetAsync(h->d_maxabs, 0, sizeof(unsigned), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_maxabs, 0, 4 * sizeof(unsigned), h->stream));
     const unsigned blocks = (unsigned)std::min<int64_t>(4096, (s.nnz + 255) / 256);
-    hipLaunchKernelGGL(max_abs_kernel, dim3(blocks), dim3(256), 0, h->stream, s.val, s.nnz, h->d_maxabs);
+    hipLaunchKernelGGL(max_abs_kernel, dim3(blocks), dim3(256), 0, h->stream, s.val, s.nnz, h->d_maxabs,
+                       reinterpret_cast<double*>(h->d_maxabs + 2));
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(&s.max_abs_val, h->d_maxabs, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    unsigned raw[4];
+    HIPCHK(h, hipMemcpyAsync(raw, h->d_maxabs, sizeof(raw), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(&s.max_abs_val, &raw[0], sizeof(float));
+    double sum = 0.0;
+    std::memcpy(&sum, &raw[2], sizeof(double));
+    s.mean_abs_val = sum / (double)s.nnz;
+    s.local_mean_abs_val = s.mean_abs_val;
   }
   s.local_max_abs_val = s.max_abs_val;
   s.col_min = 0;
@@ -450,36 +465,45 @@ int persistent_grid(mals_handle h, K kernel, int64_t n_work, unsigned* grid) {
 
 enum { LISTS_OWN = 1, LISTS_DUAL_ROWS = 2 };  // the direct kernels over: segments / rows / finish / zero-fill; the dual lists
 
-template <typename KA, typename KB, typename KC>
-int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int which, KA rows_kernel, KB segments_kernel, KC finish_kernel) {
+// One persistent launch, plus -- for a split-precision kernel -- its fp32-gather twin right behind it with
+// flag bit 3: exactly one of the two does the work (gather_scale_kernel's range flag), the other returns at once.
+template <typename K, typename KF>
+int launch_persistent(mals_handle h, K kernel, KF fallback, const SolveParams& p, int kind, double bytes) {
+  PendingEvent pe;
+  unsigned grid = 1;
+  if (int rc = persistent_grid(h, kernel, p.n_work, &grid)) return rc;
+  if (int rc = begin_timed(h, kind, bytes, pe)) return rc;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, h->stream, p);
+  if constexpr (!std::is_same<KF, std::nullptr_t>::value) {
+    SolveParams pf = p;
+    pf.flags |= 8;
+    if (int rc = persistent_grid(h, fallback, p.n_work, &grid)) return rc;
+    hipLaunchKernelGGL(fallback, dim3(grid), dim3(256), 0, h->stream, pf);
+  }
+  return end_timed(h, pe);
+}
+
+template <typename KA, typename KB, typename KFA, typename KFB, typename KC>
+int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int which, KA rows_kernel, KB segments_kernel, KFA rows_fallback,
+                 KFB segments_fallback, KC finish_kernel) {
   const double per = 4.0 * p.k + 8.0;  // gathered row + col idx + value; written row + row_ptr
   const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
   PendingEvent pe;
-  unsigned grid = 1;
   const bool own = which & LISTS_OWN, dual_rows_too = which & LISTS_DUAL_ROWS;
   if (own && cr.nB) {
     p.n_work = cr.nB;
     p.items = s.itemsB + cr.offB;
-    if (int rc = persistent_grid(h, segments_kernel, cr.nB, &grid)) return rc;
-    if (int rc = begin_timed(h, 1, (double)cr.nnzB * per, pe)) return rc;
-    hipLaunchKernelGGL(segments_kernel, dim3(grid), dim3(256), 0, h->stream, p);
-    if (int rc = end_timed(h, pe)) return rc;
+    if (int rc = launch_persistent(h, segments_kernel, segments_fallback, p, 1, (double)cr.nnzB * per)) return rc;
   }
   if (own && cr.nA) {
     p.n_work = cr.nA;
     p.items = s.itemsA + cr.offA;
-    if (int rc = persistent_grid(h, rows_kernel, cr.nA, &grid)) return rc;
-    if (int rc = begin_timed(h, 0, (double)cr.nnzA * per + (double)cr.nA * per, pe)) return rc;
-    hipLaunchKernelGGL(rows_kernel, dim3(grid), dim3(256), 0, h->stream, p);
-    if (int rc = end_timed(h, pe)) return rc;
+    if (int rc = launch_persistent(h, rows_kernel, rows_fallback, p, 0, (double)cr.nnzA * per + (double)cr.nA * per)) return rc;
   }
   if (dual_rows_too && cr.n_dual()) {  // the dual lists through the direct kernel (the half-iteration does not qualify)
     p.n_work = cr.n_dual();
     p.items = s.itemsA + cr.offA + cr.nA;
-    if (int rc = persistent_grid(h, rows_kernel, p.n_work, &grid)) return rc;
-    if (int rc = begin_timed(h, 0, (double)cr.nnz_dual() * per + (double)cr.n_dual() * per, pe)) return rc;
-    hipLaunchKernelGGL(rows_kernel, dim3(grid), dim3(256), 0, h->stream, p);
-    if (int rc = end_timed(h, pe)) return rc;
+    if (int rc = launch_persistent(h, rows_kernel, rows_fallback, p, 0, (double)cr.nnz_dual() * per + (double)cr.n_dual() * per)) return rc;
   }
   if (own && cr.nC) {
     p.n_work = cr.nC;
@@ -500,8 +524,10 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int whic
 template <int T, int D, bool FULL>
 int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk, int which) {
   if (h->split_f16)
-    return launch_lists(h, s, p, chunk, which, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>, als_finish_kernel<T>);
-  return launch_lists(h, s, p, chunk, which, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
+    return launch_lists(h, s, p, chunk, which, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>,
+                        als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
+  return launch_lists(h, s, p, chunk, which, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>,
+                      nullptr, nullptr, als_finish_kernel<T>);
 }
 
 template <int T, int D>
@@ -525,24 +551,24 @@ int launch_solve(mals_handle h, SideState& s, const SolveParams& p, int chunk, i
 }
 
 // ---- dual path (dual_kernels.h) ------------------------------------------------------------------
-template <int T, bool LISTED>
+template <int T, bool LISTED, bool F64>
 int launch_rotate_T(mals_handle h, const RotateParams& rp) {
-  const int64_t tiles = (rp.n_rows + 15) / 16;
-  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, (int64_t)h->n_cu * 2));
-  hipLaunchKernelGGL((rotate_rows_kernel<T, LISTED>), dim3(grid), dim3(256), 0, h->stream, rp);
+  const int64_t tiles = (rp.n_rows + (F64 ? 31 : 63)) / (F64 ? 32 : 64);
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, (int64_t)h->n_cu * 16));
+  hipLaunchKernelGGL((rotate_rows_kernel<T, LISTED, F64>), dim3(grid), dim3(256), 0, h->stream, rp);
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
 }
-template <bool LISTED>
+template <bool LISTED, bool F64>
 int launch_rotate(mals_handle h, const RotateParams& rp) {
   switch (h->T) {
-    case 2: return launch_rotate_T<2, LISTED>(h, rp);
-    case 3: return launch_rotate_T<3, LISTED>(h, rp);
-    case 4: return launch_rotate_T<4, LISTED>(h, rp);
-    case 5: return launch_rotate_T<5, LISTED>(h, rp);
-    case 6: return launch_rotate_T<6, LISTED>(h, rp);
-    case 7: return launch_rotate_T<7, LISTED>(h, rp);
-    case 8: return launch_rotate_T<8, LISTED>(h, rp);
+    case 2: return launch_rotate_T<2, LISTED, F64>(h, rp);
+    case 3: return launch_rotate_T<3, LISTED, F64>(h, rp);
+    case 4: return launch_rotate_T<4, LISTED, F64>(h, rp);
+    case 5: return launch_rotate_T<5, LISTED, F64>(h, rp);
+    case 6: return launch_rotate_T<6, LISTED, F64>(h, rp);
+    case 7: return launch_rotate_T<7, LISTED, F64>(h, rp);
+    case 8: return launch_rotate_T<8, LISTED, F64>(h, rp);
   }
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
 }
@@ -592,25 +618,35 @@ int prepare_dual(mals_handle h, int side) {
   const bool ok = mals::symmetric_eigen(h->h_G, k, evals.data(), V.data());
   h->stats.eigen_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (!ok) return MALS_OK;
-  double lmin = evals[0];
-  for (int f = 0; f < k; ++f) lmin = std::min(lmin, evals[(size_t)f]);
+  double lmin = evals[0], lmax = evals[0];
+  for (int f = 0; f < k; ++f) {
+    lmin = std::min(lmin, evals[(size_t)f]);
+    lmax = std::max(lmax, evals[(size_t)f]);
+  }
   const double la = h->cfg.lambda * h->cfg.alpha;
   // A_u = G + lambda alpha n_u I must be safely positive definite for every n_u >= 1 (then W_u is too,
   // and the direct path could not have flagged the row either); tiny negative eigenvalues of a
   // rank-deficient G are rounding
   if (!(lmin + la >= 1.0e-4)) return MALS_OK;
-  std::vector<float> Q((size_t)2 * KP * KP, 0.f), lam((size_t)2 * KP, 0.f);
+  std::vector<double> Q((size_t)2 * KP * KP, 0.0);
+  std::vector<float> lam((size_t)2 * KP, 0.f);
   for (int f = 0; f < k; ++f)
     for (int j = 0; j < k; ++j) {
-      Q[(size_t)f * KP + j] = (float)V[(size_t)f * k + j];                        // forward: y' = y Q
-      Q[(size_t)KP * KP + (size_t)f * KP + j] = (float)V[(size_t)j * k + f];      // back: x = x' Q^T
+      Q[(size_t)f * KP + j] = V[(size_t)f * k + j];                        // forward: y' = y Q
+      Q[(size_t)KP * KP + (size_t)f * KP + j] = V[(size_t)j * k + f];      // back: x = x' Q^T
     }
   for (int f = 0; f < KP; ++f) {
     const double l = f < k ? std::max(evals[(size_t)f], 0.0) : 0.0;
     lam[(size_t)f] = (float)l;
     lam[(size_t)KP + f] = (float)(1.0 / std::sqrt(l + la));
   }
-  if (!h->d_Q) HIPCHK(h, hipMalloc(&h->d_Q, sizeof(float) * Q.size()));
+  std::vector<float> Qf(Q.begin(), Q.end());
+  // fp32 rotation unless the spectrum is wide enough for a rotated coordinate to be a small difference of
+  // large products (dual_kernels.h, rotate_rows_kernel)
+  h->rotate_f64 = (lmax + la) > 1.0e5 * (std::max(lmin, 0.0) + la);
+  if (const char* e = std::getenv("MALS_ROTATE_F64")) h->rotate_f64 = std::atoi(e) != 0;  // tests / A-B
+  if (!h->d_Q) HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * Q.size()));
+  if (!h->d_Qf) HIPCHK(h, hipMalloc(&h->d_Qf, sizeof(float) * Qf.size()));
   if (!h->d_lam) HIPCHK(h, hipMalloc(&h->d_lam, sizeof(float) * lam.size()));
   if (!h->d_zbound) HIPCHK(h, hipMalloc(&h->d_zbound, sizeof(unsigned)));
   const size_t need = (size_t)o.n_total * KP;
@@ -622,7 +658,8 @@ int prepare_dual(mals_handle h, int side) {
     h->Mr_cap = need;
   }
   // pageable sources: these copies return once the data is staged, the vectors may go out of scope
-  HIPCHK(h, hipMemcpyAsync(h->d_Q, Q.data(), sizeof(float) * Q.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_Q, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_Qf, Qf.data(), sizeof(float) * Qf.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->d_lam, lam.data(), sizeof(float) * lam.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_zbound, 0, sizeof(unsigned), h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -630,6 +667,7 @@ int prepare_dual(mals_handle h, int side) {
   rp.src = o.F;
   rp.dst = h->d_Mr;
   rp.B = h->d_Q;
+  rp.Bf = h->d_Qf;
   rp.items = nullptr;
   rp.dmax = h->d_lam + KP;
   rp.zbound = h->d_zbound;
@@ -640,7 +678,7 @@ int prepare_dual(mals_handle h, int side) {
   rp.dst_cols = KP;
   PendingEvent pe;
   if (int rc = begin_timed(h, 5, (double)o.n_total * (4.0 * k + 4.0 * KP), pe)) return rc;
-  if (int rc = launch_rotate<false>(h, rp)) return rc;
+  if (int rc = h->rotate_f64 ? launch_rotate<false, true>(h, rp) : launch_rotate<false, false>(h, rp)) return rc;
   if (int rc = end_timed(h, pe)) return rc;
   (void)s;
   h->dual_ok = true;
@@ -681,6 +719,7 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
   rp.src = dp.out;
   rp.dst = dp.out;
   rp.B = h->d_Q + (size_t)KP * KP;
+  rp.Bf = h->d_Qf + (size_t)KP * KP;
   rp.items = base;
   rp.dmax = nullptr;
   rp.zbound = nullptr;
@@ -690,7 +729,7 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
   rp.dst_stride = k;
   rp.dst_cols = k;
   if (int rc = begin_timed(h, 5, (double)cr.n_dual() * 8.0 * k, pe)) return rc;
-  if (int rc = launch_rotate<true>(h, rp)) return rc;
+  if (int rc = launch_rotate<true, false>(h, rp)) return rc;
   return end_timed(h, pe);
 }
 
@@ -1025,7 +1064,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   h->stats.struct_size = (int32_t)sizeof(mals_stats);
   if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(&h->h_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc(&h->d_zscale, 2 * sizeof(float)) != hipSuccess || hipMalloc(&h->d_maxabs, sizeof(unsigned)) != hipSuccess ||
+      hipMalloc(&h->d_zscale, 4 * sizeof(float)) != hipSuccess || hipMalloc(&h->d_maxabs, 4 * sizeof(unsigned)) != hipSuccess ||
       hipMalloc(&h->d_colrange, 2 * sizeof(int)) != hipSuccess ||
       hipMemset(h->d_bad, 0xff, 2 * sizeof(unsigned long long)) != hipSuccess) {
     delete h;
@@ -1079,6 +1118,7 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_colrange);
   free_dev(h->d_Mr);
   free_dev(h->d_Q);
+  free_dev(h->d_Qf);
   free_dev(h->d_lam);
   free_dev(h->d_zbound);
   if (h->h_G) (void)hipHostFree(h->h_G);
@@ -1277,6 +1317,24 @@ int mals_set_value_bound(mals_handle h, int side, float max_abs_value) {
   return MALS_OK;
 }
 
+int mals_get_value_stats(mals_handle h, int side, float* max_abs_value, double* sum_abs_value, int64_t* n_values) {
+  CHECK_SIDE(h, side);
+  const SideState& s = h->side[side];
+  if (!s.has_matrix) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
+  if (max_abs_value) *max_abs_value = s.local_max_abs_val;
+  if (sum_abs_value) *sum_abs_value = s.local_mean_abs_val * (double)s.nnz;
+  if (n_values) *n_values = s.nnz;
+  return MALS_OK;
+}
+
+int mals_set_value_stats(mals_handle h, int side, float max_abs_value, double mean_abs_value) {
+  CHECK_SIDE(h, side);
+  if (!(mean_abs_value >= 0.0) || !std::isfinite(mean_abs_value)) return fail(h, MALS_INVALID_ARG, "mean |value| must be finite and >= 0");
+  if (int rc = mals_set_value_bound(h, side, max_abs_value)) return rc;
+  h->side[side].mean_abs_val = mean_abs_value;
+  return MALS_OK;
+}
+
 int mals_set_factors(mals_handle h, int side, int64_t row_begin, int64_t n_rows, const float* host_rows) {
   CHECK_SIDE(h, side);
   SideState& s = h->side[side];
@@ -1419,15 +1477,20 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);  // ALS:435
   p.sing_threshold = (float)h->cfg.singularity_threshold;
   p.zscale = h->d_zscale;
-  if (h->split_f16 && (h->zs_side != side || h->zs_version != o.G_version || h->zs_bound != s.max_abs_val)) {
+  if (h->split_f16 && (h->zs_side != side || h->zs_version != o.G_version || h->zs_bound != s.max_abs_val || h->zs_mean != s.mean_abs_val)) {
     // once per half-iteration, not per chunk: the scale only depends on G and on the value bound
     const double base_w = (h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) ? 1.0 : 0.0;
     const double w_max = base_w + ((h->cfg.flags & MALS_FLAG_RECONSTRUCT_R) ? 0.0 : std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
-    hipLaunchKernelGGL(gather_scale_kernel, dim3(1), dim3(64), 0, h->stream, o.G, k, (float)std::sqrt(w_max), h->d_zscale);
+    const double w_mean = base_w + ((h->cfg.flags & MALS_FLAG_RECONSTRUCT_R) ? 0.0 : std::fabs(h->cfg.alpha) * s.mean_abs_val);
+    int force = -1;  // MALS_FORCE_RANGE_FLAG=0/1 (tests): override the range decision
+    if (const char* e = std::getenv("MALS_FORCE_RANGE_FLAG")) force = std::atoi(e) != 0;
+    hipLaunchKernelGGL(gather_scale_kernel, dim3(1), dim3(64), 0, h->stream, o.G, k, (float)std::sqrt(w_max), (float)std::sqrt(w_mean),
+                       (double)o.n_total, force, h->d_zscale);
     HIPCHK(h, hipGetLastError());
     h->zs_side = side;
     h->zs_version = o.G_version;
     h->zs_bound = s.max_abs_val;
+    h->zs_mean = s.mean_abs_val;
   }
   // dual path (dual_kernels.h): the reference's default mode only; the Gramian goes to the host first so
   // that its eigendecomposition runs while the direct kernels of the first chunk execute

@@ -65,9 +65,17 @@ class ShardedALS:
         if self.single:
             return
         import torch.distributed as dist
-        t = self.torch.tensor([self.core.value_bound(side)], dtype=self.torch.float32, device=self.device)
+        if not hasattr(self.core, "value_stats"):   # duck-typed stand-ins of the CPU tests
+            t = self.torch.tensor([self.core.value_bound(side)], dtype=self.torch.float32, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self.core.set_value_bound(side, float(t.item()))
+            return
+        m, sm, n = self.core.value_stats(side)
+        t = self.torch.tensor([m], dtype=self.torch.float32, device=self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        self.core.set_value_bound(side, float(t.item()))
+        q = self.torch.tensor([sm, float(n)], dtype=self.torch.float64, device=self.device)
+        dist.all_reduce(q)
+        self.core.set_value_stats(side, float(t.item()), float(q[0].item()) / max(float(q[1].item()), 1.0))
 
     def set_factors(self, side, rows):
         """Install (replicated) factor rows [0, len(rows)) -- e.g. the initial Y."""

@@ -2,8 +2,8 @@
 
 Item popularity is a power law (popularity rank = floor(I * u^3), i.e. density ~ rank^(-2/3); ranks
 are mapped to item ids by a seeded random permutation so that id order carries no popularity
-information), user activity is log-normal (sigma 1), strengths are integers 1..5.  Duplicate (user,item) pairs are merged, so
-the realised nnz is slightly below the request.  Seed 1234567890 = RandomManager.java:52.
+information), user activity is log-normal (sigma 1), strengths are integers 1..5.  Duplicate (user,item) pairs are merged;
+`torch_problem` tops the sample up to exactly the requested nnz and plants a low-rank part (see there).  Seed 1234567890 = RandomManager.java:52.
 `numpy_problem` is for tests (host arrays), `torch_problem` builds the large bench matrices on the
 GPU (CSR by user and CSR by item, int64 row_ptr / int32 col / fp32 val)."""
 import numpy as np
@@ -41,9 +41,21 @@ def numpy_problem(n_users, n_items, nnz, k, seed=SEED, negatives=0.0):
     return r_csr, c_csr, Y0
 
 
-def torch_problem(n_users, n_items, nnz, k, device, seed=SEED, chunk=1 << 27):
+PLANT_CLUSTERS = 32   # taste clusters of the planted part
+PLANT_CORE = 64       # core items per cluster: item ids [64 c, 64 c + 64)
+
+
+def torch_problem(n_users, n_items, nnz, k, device, seed=SEED, chunk=1 << 27, planted=0.3):
     """Large problems, generated on `device`.  Returns dict with r_csr, c_csr (torch tensors on the
-    device), Y0 and the realised nnz."""
+    device), Y0, the realised nnz (exactly the request unless the matrix cannot hold it) and the
+    description of the planted part.
+
+    Planted low-rank part: user u belongs to taste cluster u % 32; a fraction `planted` of the sampled
+    interactions goes to the 64 core items of the user's cluster (item ids 64 c .. 64 c + 63, squared
+    uniform inside the core), the rest follows the global popularity law.  The (user cluster x core)
+    blocks are dense enough (tens of percent) for a rank >= 32 model to predict them, so the
+    reconstruction error over those entries says whether ALS is learning; over the long tail nothing is
+    predictable at 1e-4 density, which is why the overall mean stays near 1."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -51,17 +63,40 @@ def torch_problem(n_users, n_items, nnz, k, device, seed=SEED, chunk=1 << 27):
     cdf = torch.cumsum(act.double(), 0)
     cdf = (cdf / cdf[-1]).float()
     perm = torch.randperm(n_items, generator=g, device=device)
-    keys = []
-    done = 0
-    while done < nnz:
-        m = min(chunk, nnz - done)
+    n_core = PLANT_CLUSTERS * PLANT_CORE
+    if n_items < 4 * n_core:
+        planted = 0.0
+
+    def draw(m):
         uu = torch.searchsorted(cdf, torch.rand(m, generator=g, device=device)).clamp_(max=n_users - 1)
         ii = (n_items * torch.rand(m, generator=g, device=device, dtype=torch.float64) ** 3).long().clamp_(max=n_items - 1)
         ii = perm[ii]
-        keys.append(uu * n_items + ii)
-        done += m
-        del uu, ii
-    keys = torch.unique(torch.cat(keys))          # sorted by (user, item)
+        if planted > 0:
+            core = (uu % PLANT_CLUSTERS) * PLANT_CORE + (PLANT_CORE * torch.rand(m, generator=g, device=device) ** 2).long().clamp_(max=PLANT_CORE - 1)
+            ii = torch.where(torch.rand(m, generator=g, device=device) < planted, core, ii)
+        return uu * n_items + ii
+
+    target = min(nnz, n_users * n_items)
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    want = target
+    for _ in range(64):          # top up until the merged (user, item) pairs reach the request
+        parts = [keys]
+        done = 0
+        while done < want:
+            m = min(chunk, want - done)
+            parts.append(draw(m))
+            done += m
+        keys = torch.unique(torch.cat(parts))     # sorted by (user, item)
+        del parts
+        if keys.numel() >= target:
+            break
+        want = int((target - keys.numel()) * 1.1) + 1024
+    if keys.numel() > target:                     # drop a random surplus: exactly `target` entries
+        drop = torch.randperm(keys.numel(), generator=g, device=device)[:keys.numel() - target]
+        mask = torch.ones(keys.numel(), dtype=torch.bool, device=device)
+        mask[drop] = False
+        keys = keys[mask]
+        del mask, drop
     n = keys.numel()
     u = torch.div(keys, n_items, rounding_mode="floor")
     i = keys - u * n_items
@@ -80,4 +115,29 @@ def torch_problem(n_users, n_items, nnz, k, device, seed=SEED, chunk=1 << 27):
     del order, u, i
     Y0 = torch.randn(n_items, k, generator=g, device=device, dtype=torch.float32)
     Y0 /= Y0.norm(dim=1, keepdim=True)
-    return {"r_csr": r_csr, "c_csr": c_csr, "Y0": Y0, "nnz": n}
+    return {"r_csr": r_csr, "c_csr": c_csr, "Y0": Y0, "nnz": n,
+            "planted": {"fraction": planted, "clusters": PLANT_CLUSTERS, "core_items": PLANT_CORE} if planted > 0 else None}
+
+
+def planted_reconstruction_error(prob, X, Y, sample=4_000_000):
+    """Mean of max(0, 1 - x_u . y_i) over (a sample of) the stored entries of the planted part: core items
+    of the user's own cluster.  torch on the device; diagnostics only."""
+    import torch
+    if not prob.get("planted"):
+        return None
+    rp, col, _ = prob["r_csr"]
+    n_core = PLANT_CLUSTERS * PLANT_CORE
+    idx = torch.nonzero(col < n_core).squeeze(1)
+    if idx.numel() > sample:
+        idx = idx[torch.randperm(idx.numel(), device=idx.device)[:sample]]
+    users = torch.searchsorted(rp, idx, right=True) - 1
+    items = col[idx].long()
+    own = (items // PLANT_CORE) == (users % PLANT_CLUSTERS)
+    users, items = users[own], items[own]
+    if users.numel() == 0:
+        return None
+    err = 0.0
+    for s in range(0, users.numel(), 1 << 20):
+        d = (X[users[s:s + (1 << 20)]].double() * Y[items[s:s + (1 << 20)]].double()).sum(1)
+        err += torch.clamp(1.0 - d, min=0.0).sum().item()
+    return {"mean": err / users.numel(), "entries_sampled": int(users.numel())}
