@@ -90,6 +90,9 @@ def main():
                     help="mals_config.gramian_mode (A/B only; the headline number uses the library default)")
     ap.add_argument("--solve-mode", default="auto", choices=["auto", "direct", "dual"],
                     help="mals_config.solve_mode (A/B only; the headline number uses the library default)")
+    ap.add_argument("--exchange", default="group", choices=["group", "torch"],
+                    help="N>1: 'group' = the library's own RCCL exchange below the C-ABI (mals_group_*, cost-balanced slices); "
+                         "'torch' = equal-row slices exchanged with torch.distributed collectives (sharded.py)")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N>1: solve each slice in this many row chunks and all-gather a finished chunk while the next is solved")
     args = ap.parse_args()
@@ -134,17 +137,54 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     chunk_rows = 0
-    if (world > 1 or force) and args.exchange_chunks > 1:
-        upr = sharded.rows_per_rank(n_users, world)
-        chunk_rows = (upr + args.exchange_chunks - 1) // args.exchange_chunks
-    core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, chunk_rows=chunk_rows,
-                       gramian_mode={"auto": 0, "fp32": 1, "split_f16": 2}[args.gramian_mode],
-                       solve_mode={"auto": 0, "direct": 1, "dual": 2}[args.solve_mode])
-    core.set_stream(torch.cuda.current_stream().cuda_stream)
-    als = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device=device, force_collectives=force)
-    als.set_matrix_from_full(pkg.SIDE_X, *prob["r_csr"])
-    als.set_matrix_from_full(pkg.SIDE_Y, *prob["c_csr"])
-    als.set_factors(pkg.SIDE_Y, prob["Y0"])
+    gmode = {"auto": 0, "fp32": 1, "split_f16": 2}[args.gramian_mode]
+    smode = {"auto": 0, "direct": 1, "dual": 2}[args.solve_mode]
+    use_group = (world > 1 or force) and args.exchange == "group"
+    if use_group:
+        # one rank per process; torch.distributed only carried the RCCL unique id (and the barriers of the
+        # timing bracket): slices, partial Gramians, all-reduce and the chunked exchange are the library's
+        grp = pkg.GroupALS.from_torch_distributed(k, local_rank, alpha=1.0, lam=0.1, segment_nnz=args.segment_nnz, gramian_mode=gmode,
+                                                  solve_mode=smode, exchange_chunks=args.exchange_chunks, world=world, rank=rank,
+                                                  one_rank_communicator=force)
+        grp.set_factor_rows(pkg.SIDE_X, n_users)
+        grp.set_factor_rows(pkg.SIDE_Y, n_items)
+        grp.set_matrix(pkg.SIDE_X, *prob["r_csr"])
+        grp.set_matrix(pkg.SIDE_Y, *prob["c_csr"])
+        grp.set_factors(pkg.SIDE_Y, prob["Y0"].cpu().numpy())
+        core = grp.local(0)[0]
+
+        class GroupDriver:
+            per = {pkg.SIDE_X: (n_users + world - 1) // world, pkg.SIDE_Y: (n_items + world - 1) // world}
+
+            def iterate(self, n, check=True):
+                grp.iterate(n)          # every half-iteration ends with the agreed status (ALS:346-361)
+
+            def half_iteration(self, side):
+                grp.half_iteration(side)
+
+            def _all_gather(self, side):
+                grp.exchange_only(side)
+
+            def factors(self, side):
+                ptr, n = core.factor_device_ptr(side)
+
+                class _View:
+                    __cuda_array_interface__ = {"shape": (n, k), "typestr": "<f4", "data": (ptr, False), "version": 2}
+                return torch.as_tensor(_View(), device=device)[:(n_users if side == pkg.SIDE_X else n_items)]
+        als = GroupDriver()
+        slice_info = {"x_bounds": grp.bounds(pkg.SIDE_X).tolist(), "y_bounds": grp.bounds(pkg.SIDE_Y).tolist()}
+    else:
+        if (world > 1 or force) and args.exchange_chunks > 1:
+            upr = sharded.rows_per_rank(n_users, world)
+            chunk_rows = (upr + args.exchange_chunks - 1) // args.exchange_chunks
+        core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, chunk_rows=chunk_rows,
+                           gramian_mode=gmode, solve_mode=smode)
+        core.set_stream(torch.cuda.current_stream().cuda_stream)
+        als = sharded.ShardedALS(core, n_users, n_items, k, rank=rank, world=world, device=device, force_collectives=force)
+        als.set_matrix_from_full(pkg.SIDE_X, *prob["r_csr"])
+        als.set_matrix_from_full(pkg.SIDE_Y, *prob["c_csr"])
+        als.set_factors(pkg.SIDE_Y, prob["Y0"])
+        slice_info = None
 
     def barrier():
         torch.cuda.synchronize()
@@ -252,7 +292,10 @@ def main():
                        "arithmetic": ("per-row Gramian: operands split into two f16 halves (22 significand bits), exact products, fp32 accumulate"
                                       if split else "per-row Gramian: fp32 products, fp32 accumulate") +
                                      "; M^T M: fp64; Cholesky and solves: fp32; factors stored fp32 like the reference",
-                       "sharding": "rows x%d, %s all-gather + kxk all-reduce" % (world, "in-place" if chunk_rows == 0 else "chunked (%d rows) pipelined" % chunk_rows),
+                       "sharding": ("rows x%d, cost-balanced slices, RCCL below the C-ABI (mals_group_*): kxk all-reduce + exchange in %d chunks behind the solve" % (world, args.exchange_chunks))
+                                   if use_group else
+                                   ("rows x%d, %s all-gather + kxk all-reduce (torch.distributed)" % (world, "in-place" if chunk_rows == 0 else "chunked (%d rows) pipelined" % chunk_rows)),
+                       "slices": slice_info,
                        "setup_s": round(t_gen, 2)},
             "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS,

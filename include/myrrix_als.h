@@ -214,6 +214,9 @@ int mals_solve_side(mals_handle h, int side);
  * (all chunks, in any order, = mals_solve_side).  mals_num_chunks = ceil(n_rows_local/chunk_rows). */
 int mals_solve_chunk(mals_handle h, int side, int32_t chunk);
 int mals_num_chunks(mals_handle h, int side, int32_t* n_chunks);
+/* cfg.chunk_rows for one side only (the two sides of a shard usually differ in size); takes effect at the
+ * next matrix upload of that side.  0 = one chunk. */
+int mals_set_chunk_rows(mals_handle h, int side, int64_t chunk_rows);
 
 /* Synchronise the stream and report MALS_SINGULAR if any row solved since the last check had a
  * non-positive-definite system (the reference throws SingularMatrixSolverException, CMLSS:46-54). */
@@ -384,6 +387,81 @@ int mals_model_get(mals_model m, mals_model_view* out);
 int mals_model_destroy(mals_model m);
 /* message of the last failed mals_model_* call of this thread */
 const char* mals_model_last_error(void);
+
+/* ---- the multi-GPU half-iteration below the C-ABI ------------------------------
+ * Rows within a half-iteration are independent given the full opposite factor matrix and its Gramian --
+ * how the reference threads it (ALS:391-410, one writer per output row ALS:497-499).  A GROUP is `world`
+ * ranks, one GPU each, every rank holding the CSR rows of its slice of users and of items plus FULL
+ * replicas of X and Y.  Per half-iteration: partial Gramian of the rank's own slice + k x k fp64 all-reduce;
+ * solve the slice in `exchange_chunks` row chunks; as soon as a chunk is solved its rows go to every other
+ * replica (in place, on a second stream, while the next chunk is being solved).  Slices are contiguous row
+ * ranges balanced by COST (entries + row_cost per row, mals_plan_shards), not by row count, so the
+ * exchange is an all-gather with per-rank counts: one grouped ncclSend/ncclRecv per peer pair (RCCL; on a
+ * fully connected xGMI node every pair has its own link).
+ * Two ways to form a group, same calls afterwards:
+ *   mals_group_create         ONE process drives all GPUs (the JVM deployment): ncclCommInitAll;
+ *   mals_group_create_rank    one process per GPU (torchrun / MPI style): rank 0 calls mals_group_unique_id,
+ *                             ships the 128 bytes to the others by its own means, every rank calls
+ *                             create_rank; all later mals_group_* calls are collective (every rank, same
+ *                             order, same arguments apart from host buffers).
+ * backend: MALS_GROUP_RCCL (RCCL, dlopen'ed: librccl.so.1 must be loadable) or MALS_GROUP_PEER_COPY
+ * (single-process groups only: hipMemcpyPeerAsync between the replicas -- the SDMA engines move the
+ * slices, no CU is taken from the solve -- and the k x k sum through the host).
+ * Errors: MALS_COMM_ERROR for a failed RCCL call; a per-row error (MALS_SINGULAR ...) found by any rank is
+ * returned by every rank. */
+typedef struct mals_group_s* mals_group;
+enum { MALS_GROUP_RCCL = 0, MALS_GROUP_PEER_COPY = 1 };
+
+/* Contiguous row slices of equal cost: row r costs (row_ptr[r+1]-row_ptr[r]) + row_cost (row_cost < 0: a
+ * default for `features`: the factorization of a row in entry-gathers, ~ features^2 / 200).
+ * bounds_out[world+1]: slice j = rows [bounds_out[j], bounds_out[j+1]).  Host only. */
+int mals_plan_shards(const int64_t* row_ptr, int64_t n_rows, int32_t world, double row_cost, int32_t features,
+                     int64_t* bounds_out);
+
+int mals_group_create(const mals_config* cfg, const int32_t* devices, int32_t n_devices, int32_t backend, mals_group* out);
+int mals_group_unique_id(void* id_out_128_bytes);
+int mals_group_create_rank(const mals_config* cfg, int32_t world, int32_t rank, const void* id_128_bytes, mals_group* out);
+int mals_group_destroy(mals_group g);
+const char* mals_group_last_error(mals_group g);
+int mals_group_world(mals_group g);
+/* the handle of local member i (0 .. n_local-1; n_local = world for mals_group_create, 1 for create_rank)
+ * and its rank -- for per-GPU calls such as mals_get_stats, mals_recommend, mals_reconstruction_error */
+int mals_group_local(mals_group g, int32_t i, mals_handle* handle_out, int32_t* rank_out);
+int mals_group_set_exchange_chunks(mals_group g, int32_t n_chunks); /* default 4 */
+
+/* Replicas: n_rows_total rows per side on every rank (>= the matrix rows: stale Y rows, ALS:304-308). */
+int mals_group_set_factor_rows(mals_group g, int side, int64_t n_rows_total);
+/* host rows -> every local replica / rows of local member 0's replica -> host */
+int mals_group_set_factors(mals_group g, int side, int64_t row_begin, int64_t n_rows, const float* host_rows);
+int mals_group_get_factors(mals_group g, int side, int64_t row_begin, int64_t n_rows, float* host_out);
+int mals_group_get_rows(mals_group g, int side, const int64_t* row_idx, int32_t n, float* host_out);
+
+/* The FULL matrix of a side (CSR, n_rows rows, global row_ptr; host or device arrays of the calling
+ * process): slices are planned from row_ptr (mals_plan_shards with row_cost < 0) and every local member
+ * uploads its own.  Device arrays are borrowed (col_idx / val) like mals_set_matrix(MALS_MEM_DEVICE). */
+int mals_group_set_matrix(mals_group g, int side, int64_t n_rows, int64_t nnz, const int64_t* row_ptr,
+                          const int32_t* col_idx, const float* val, int mem_kind);
+/* The same for callers that cannot hold one array per matrix (Java arrays are < 2^31 entries): the full
+ * row_ptr first (n_rows+1 longs always fit), then the entries of consecutive rows in any number of
+ * pieces (each piece = whole rows), then end. */
+int mals_group_begin_matrix(mals_group g, int side, int64_t n_rows, const int64_t* row_ptr);
+int mals_group_append_rows(mals_group g, int side, int64_t n_rows, const int32_t* col_idx, const float* val);
+int mals_group_end_matrix(mals_group g, int side);
+/* slice bounds of a side after its matrix was set: bounds_out[world+1] */
+int mals_group_bounds(mals_group g, int side, int64_t* bounds_out);
+
+/* iterateXFromY / iterateYFromX (ALS:340-389) and call() (ALS:176-262) on the group; arguments as for
+ * mals_half_iteration / mals_factorize. */
+int mals_group_half_iteration(mals_group g, int side);
+int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max_iterations, int32_t random_y,
+                         int32_t iterate, const int64_t* test_users, int32_t n_test_users, const int64_t* test_items,
+                         int32_t n_test_items, int32_t* iterations_out, double* convergence_out);
+/* diagnostic: the exchange of a side on its own (the current slices into every replica again), to price the
+ * wire separately from the solve it normally hides behind */
+int mals_group_exchange_only(mals_group g, int side);
+int mals_group_cancel(mals_group g);
+/* wait for everything enqueued on the local members' streams (timing brackets) */
+int mals_group_synchronize(mals_group g);
 
 int mals_enable_timing(mals_handle h, int32_t on);
 int mals_reset_stats(mals_handle h);

@@ -20,12 +20,13 @@ from .core import ALSCore, Cancelled, HostSolver, IllConditioned, MalsError, Sin
 from .factorizer import (AlternatingLeastSquares, ExecutionException, InterruptedException,
                          MatrixFactorizer, MatrixUtils, SingularMatrixSolverException,
                          SolverException, System)
+from .group import GroupALS, plan_shards
 from .generation import Generation, IllConditionedSolverException, Solver
 from .ingest import Ingest, readInputRecords
 from .serializer import GenerationSerializer, SerializedGeneration
 from ._lib import (FLAG_LOSS_IGNORES_UNSPECIFIED, FLAG_RECONSTRUCT_R, SIDE_X, SIDE_Y)
 
-__all__ = ["GenerationSerializer", "SerializedGeneration", "ALSCore", "HostSolver", "IllConditioned", "Generation", "Solver", "Ingest", "readInputRecords",
+__all__ = ["GroupALS", "plan_shards", "GenerationSerializer", "SerializedGeneration", "ALSCore", "HostSolver", "IllConditioned", "Generation", "Solver", "Ingest", "readInputRecords",
            "IllConditionedSolverException", "MalsError", "SingularSystem", "Cancelled", "AlternatingLeastSquares",
            "MatrixFactorizer", "MatrixUtils", "System", "ExecutionException",
            "InterruptedException", "SolverException", "SingularMatrixSolverException",

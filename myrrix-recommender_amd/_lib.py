@@ -15,6 +15,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
 SOLVE_AUTO, SOLVE_DIRECT, SOLVE_DUAL = 0, 1, 2
 ABI_VERSION = 2
+GROUP_RCCL, GROUP_PEER_COPY = 0, 1
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
                 COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM",
@@ -95,6 +96,7 @@ SYMBOLS = {
     "mals_solve_side": (ctypes.c_int, [_H, ctypes.c_int]),
     "mals_solve_chunk": (ctypes.c_int, [_H, ctypes.c_int, _I32]),
     "mals_num_chunks": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(_I32)]),
+    "mals_set_chunk_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64]),
     "mals_check": (ctypes.c_int, [_H]),
     "mals_singular_info": (ctypes.c_int, [_H, ctypes.POINTER(_I32), ctypes.POINTER(_I64), ctypes.POINTER(_I32)]),
     "mals_half_iteration": (ctypes.c_int, [_H, ctypes.c_int]),
@@ -122,6 +124,30 @@ SYMBOLS = {
     "mals_ingest_install": (ctypes.c_int, [_H, _H]),
     "mals_ingest_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I32)]),
+    "mals_plan_shards": (ctypes.c_int, [_P, _I64, _I32, ctypes.c_double, _I32, _P]),
+    "mals_group_create": (ctypes.c_int, [ctypes.POINTER(Config), _P, _I32, _I32, ctypes.POINTER(_H)]),
+    "mals_group_unique_id": (ctypes.c_int, [_P]),
+    "mals_group_create_rank": (ctypes.c_int, [ctypes.POINTER(Config), _I32, _I32, _P, ctypes.POINTER(_H)]),
+    "mals_group_destroy": (ctypes.c_int, [_H]),
+    "mals_group_last_error": (ctypes.c_char_p, [_H]),
+    "mals_group_world": (ctypes.c_int, [_H]),
+    "mals_group_local": (ctypes.c_int, [_H, _I32, ctypes.POINTER(_H), ctypes.POINTER(_I32)]),
+    "mals_group_set_exchange_chunks": (ctypes.c_int, [_H, _I32]),
+    "mals_group_set_factor_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64]),
+    "mals_group_set_factors": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),
+    "mals_group_get_factors": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),
+    "mals_group_get_rows": (ctypes.c_int, [_H, ctypes.c_int, _P, _I32, _P]),
+    "mals_group_set_matrix": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P, _P, _P, ctypes.c_int]),
+    "mals_group_begin_matrix": (ctypes.c_int, [_H, ctypes.c_int, _I64, _P]),
+    "mals_group_append_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64, _P, _P]),
+    "mals_group_end_matrix": (ctypes.c_int, [_H, ctypes.c_int]),
+    "mals_group_bounds": (ctypes.c_int, [_H, ctypes.c_int, _P]),
+    "mals_group_half_iteration": (ctypes.c_int, [_H, ctypes.c_int]),
+    "mals_group_factorize": (ctypes.c_int, [_H, ctypes.c_double, _I32, _I32, _I32, _P, _I32, _P, _I32,
+                                            ctypes.POINTER(_I32), ctypes.POINTER(ctypes.c_double)]),
+    "mals_group_exchange_only": (ctypes.c_int, [_H, ctypes.c_int]),
+    "mals_group_cancel": (ctypes.c_int, [_H]),
+    "mals_group_synchronize": (ctypes.c_int, [_H]),
     "mals_enable_timing": (ctypes.c_int, [_H, _I32]),
     "mals_model_write": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ModelView)]),
     "mals_model_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(_H)]),

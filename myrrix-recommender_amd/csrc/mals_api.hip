@@ -74,6 +74,7 @@ struct SideState {
     int64_t nnz_dual() const { return nnzD[0] + nnzD[1] + nnzD[2] + nnzD[3]; }
   };
   int64_t n_dual_rows = 0;
+  int64_t chunk_rows_override = -1;  // mals_set_chunk_rows: per-side value of cfg.chunk_rows (-1 = use cfg)
   std::vector<ChunkRange> chunks;
   // Gramian of THIS side's factors (consumed when solving the other side)
   double* G = nullptr;
@@ -244,7 +245,8 @@ int build_work_lists(mals_handle h, SideState& s) {
   }
   const int64_t n = s.n_local;
   const int seg = h->cfg.segment_nnz;
-  const int64_t chunk_rows = h->cfg.chunk_rows > 0 ? h->cfg.chunk_rows : std::max<int64_t>(n, 1);
+  const int64_t want_chunk = s.chunk_rows_override >= 0 ? s.chunk_rows_override : h->cfg.chunk_rows;
+  const int64_t chunk_rows = want_chunk > 0 ? want_chunk : std::max<int64_t>(n, 1);
   const int n_chunks = (int)std::max<int64_t>(1, (n + chunk_rows - 1) / chunk_rows);
   const std::vector<int64_t>& rp = s.h_row_ptr;
   std::vector<WorkItem> order;
@@ -1537,6 +1539,13 @@ int mals_solve_side(mals_handle h, int side) {
 int mals_solve_chunk(mals_handle h, int side, int32_t chunk) {
   CHECK_SIDE(h, side);
   return solve_chunks(h, side, chunk, chunk + 1);
+}
+
+int mals_set_chunk_rows(mals_handle h, int side, int64_t chunk_rows) {
+  CHECK_SIDE(h, side);
+  if (chunk_rows < 0) return fail(h, MALS_INVALID_ARG, "chunk_rows must be >= 0");
+  h->side[side].chunk_rows_override = chunk_rows;
+  return MALS_OK;
 }
 
 int mals_num_chunks(mals_handle h, int side, int32_t* n_chunks) {

@@ -11,6 +11,10 @@ M^T M is computed as per-rank partials over the rank's own slice + a k x k fp64 
 Slices are equal-sized (rows_per_rank = ceil(n/world), the tail of the last slice is zero padding
 that no column index references), so the all-gather is the plain in-place NCCL all-gather.
 
+This is the torch.distributed variant.  The product path for N > 1 is the library's own exchange below
+the C-ABI (mals_group_*, group.py: cost-balanced slices, RCCL send/recv per peer); this module stays as
+the multi-process alternative and as the vehicle of the world-2 gloo logic tests on CPU.
+
 torch.distributed is plumbing here (rendezvous, RCCL communicator, stream ordering); all compute
 is in libmyrrix_als.so.  `core` is duck-typed so that the world_size-2 gloo test on CPU can inject
 a checker-backed stand-in (tests/test_sharded_gloo.py); the product path passes an ALSCore.
@@ -42,6 +46,13 @@ class ShardedALS:
             self.F[side] = torch.zeros(self.per[side] * world, features, dtype=torch.float32, device=device)
             core.bind_factors(side, self.F[side])
         self._gp = torch.zeros(features, features, dtype=torch.float64, device=device)
+        self._bind_stream()
+
+    def _bind_stream(self):
+        """The library's kernels and torch.distributed's collectives must share one stream order: the
+        handle works on torch's CURRENT stream (collectives synchronise with it, not with the null stream)."""
+        if hasattr(self.core, "set_stream") and str(self.device) != "cpu" and self.torch.cuda.is_available():
+            self.core.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- data -------------------------------------------------------------------------------------
     def slice_bounds(self, side, rank=None):
@@ -105,12 +116,13 @@ class ShardedALS:
         mine = full[self.rank * self.per[side]:(self.rank + 1) * self.per[side]]
         try:
             dist.all_gather_into_tensor(full, mine)
-        except (RuntimeError, NotImplementedError):
+        except NotImplementedError:   # backends without the flat variant (gloo on CPU); a real RCCL failure must surface
             chunks = list(full.chunk(self.world, dim=0))
             dist.all_gather(chunks, mine.clone())
 
     def half_iteration(self, side):
         """iterateXFromY (ALS:340-362) for SIDE_X / iterateYFromX (ALS:367-389) for SIDE_Y."""
+        self._bind_stream()
         self._gramian(1 - side)
         cr = getattr(self.core, "chunk_rows", 0)
         if self.single or cr <= 0 or cr >= self.per[side]:
@@ -125,19 +137,36 @@ class ShardedALS:
         full, per = self.F[side], self.per[side]
         n_chunks = (per + cr - 1) // cr
         mine = self.core.num_chunks(side)
-        works = []
+        works, stages = [], []
+        k = full.shape[1]
+        flat_ok = hasattr(dist, "all_gather_into_tensor") and dist.get_backend() != "gloo"
         for c in range(n_chunks):
             if c < mine:
                 self.core.solve_chunk(side, c)
             lo, hi = c * cr, min((c + 1) * cr, per)
-            outs = [full[r * per + lo:r * per + hi] for r in range(self.world)]
-            works.append(dist.all_gather(outs, outs[self.rank], async_op=True))
+            if flat_ok:
+                # one contiguous staging buffer per chunk: the flat all-gather writes it in place (no list-output
+                # temporaries inside the backend), one strided copy then drops the pieces into the replica
+                stage = self.torch.empty(self.world, hi - lo, k, dtype=full.dtype, device=full.device)
+                works.append(dist.all_gather_into_tensor(stage.view(self.world * (hi - lo), k), full[self.rank * per + lo:self.rank * per + hi],
+                                                         async_op=True))
+                stages.append((stage, lo, hi))
+            else:
+                outs = [full[r * per + lo:r * per + hi] for r in range(self.world)]
+                works.append(dist.all_gather(outs, outs[self.rank], async_op=True))
         for w in works:
             w.wait()
+        for stage, lo, hi in stages:
+            full.view(self.world, per, k)[:, lo:hi].copy_(stage)
 
     def iterate(self, n=1, check=True):
+        """check: report a singular row after EVERY half-iteration, before its zeroed factors are
+        exchanged into later Gramians (the reference fails at the f.get() of that half, ALS:346-361);
+        check=False defers to the caller (timing loops)."""
         for _ in range(n):
             self.half_iteration(SIDE_X)
+            if check:
+                self.core.check()
             self.half_iteration(SIDE_Y)
-        if check:
-            self.core.check()
+            if check:
+                self.core.check()

@@ -31,9 +31,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # mals_config: 2 x int32, 3 x double, 6 x int32 ; mals_stats: 2 x int32, 4 x double, 4 x int64, 4 x double, 2 x int64
+    # mals_config: 2 x int32, 3 x double, 6 x int32 ; mals_stats (ABI 2): 2 x int32, 4 x double, 4 x int64, 4 x double,
+    # 2 x int64, then 2 x double, 2 x int64, 2 x double, int64, double
     assert ctypes.sizeof(_lib.Config) == 56
-    assert ctypes.sizeof(_lib.Stats) == 120
+    assert ctypes.sizeof(_lib.Stats) == 184
     cfg = _lib.Config()
     assert _lib.load().mals_default_config(ctypes.byref(cfg)) == _lib.OK
     assert cfg.struct_size == 56 and cfg.features == 30            # MatrixFactorizer.java:34
@@ -81,3 +82,13 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     solver, rank = ctypes.c_void_p(), ctypes.c_int32()
     assert L.mals_solver_create(None, 3, 1e-5, ctypes.byref(solver), ctypes.byref(rank)) == _lib.INVALID_ARG
     assert L.mals_solver_dim(None) == 0
+    # group / planner entry points
+    grp = ctypes.c_void_p()
+    cfg = _lib.Config()
+    L.mals_default_config(ctypes.byref(cfg))
+    assert L.mals_group_create(ctypes.byref(cfg), None, 2, 0, ctypes.byref(grp)) == _lib.INVALID_ARG
+    assert L.mals_group_create_rank(ctypes.byref(cfg), 2, 5, None, ctypes.byref(grp)) == _lib.INVALID_ARG   # rank >= world
+    assert L.mals_group_half_iteration(None, 0) == _lib.INVALID_ARG
+    assert L.mals_group_world(None) == 0
+    assert L.mals_plan_shards(None, 0, 2, -1.0, 64, None) == _lib.INVALID_ARG
+    assert L.mals_set_chunk_rows(None, 0, 10) == _lib.INVALID_ARG
