@@ -456,6 +456,9 @@ int mals_group_half_iteration(mals_group g, int side);
 int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max_iterations, int32_t random_y,
                          int32_t iterate, const int64_t* test_users, int32_t n_test_users, const int64_t* test_items,
                          int32_t n_test_items, int32_t* iterations_out, double* convergence_out);
+/* details of the last MALS_SINGULAR as mals_singular_info reports them, from whichever local member hit it
+ * (side = -1: none of the local members did) */
+int mals_group_singular_info(mals_group g, int32_t* side, int64_t* row, int32_t* apparent_rank);
 /* diagnostic: the exchange of a side on its own (the current slices into every replica again), to price the
  * wire separately from the solve it normally hides behind */
 int mals_group_exchange_only(mals_group g, int side);

@@ -145,6 +145,7 @@ SYMBOLS = {
     "mals_group_half_iteration": (ctypes.c_int, [_H, ctypes.c_int]),
     "mals_group_factorize": (ctypes.c_int, [_H, ctypes.c_double, _I32, _I32, _I32, _P, _I32, _P, _I32,
                                             ctypes.POINTER(_I32), ctypes.POINTER(ctypes.c_double)]),
+    "mals_group_singular_info": (ctypes.c_int, [_H, ctypes.POINTER(_I32), ctypes.POINTER(_I64), ctypes.POINTER(_I32)]),
     "mals_group_exchange_only": (ctypes.c_int, [_H, ctypes.c_int]),
     "mals_group_cancel": (ctypes.c_int, [_H]),
     "mals_group_synchronize": (ctypes.c_int, [_H]),

@@ -700,6 +700,24 @@ int mals_group_half_iteration(mals_group g, int side) {
   return agree_status(g, local_rc, local_msg);
 }
 
+int mals_group_singular_info(mals_group g, int32_t* side, int64_t* row, int32_t* apparent_rank) {
+  if (!g) return MALS_INVALID_ARG;
+  if (side) *side = -1;
+  if (row) *row = -1;
+  if (apparent_rank) *apparent_rank = 0;
+  for (Member& mb : g->m) {  // the local member that reported it (multi-process groups: each process knows its own)
+    int32_t sd = -1, rk = 0;
+    int64_t rw = -1;
+    if (mals_singular_info(mb.h, &sd, &rw, &rk) == MALS_OK && sd >= 0) {
+      if (side) *side = sd;
+      if (row) *row = rw;
+      if (apparent_rank) *apparent_rank = rk;
+      return MALS_OK;
+    }
+  }
+  return MALS_OK;
+}
+
 int mals_group_exchange_only(mals_group g, int side) {
   GSIDE(g, side);
   if (g->bounds[side].empty()) return gfail(g, MALS_INVALID_ARG, "matrix of this side not set");

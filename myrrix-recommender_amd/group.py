@@ -135,7 +135,9 @@ class GroupALS:
             return
         msg = (self._L.mals_group_last_error(self._g) or b"").decode("utf-8", "replace")
         if rc == _lib.SINGULAR:
-            raise SingularSystem(rc, msg, -1, -1, 0)
+            side, row, rank = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int32()
+            self._L.mals_group_singular_info(self._g, ctypes.byref(side), ctypes.byref(row), ctypes.byref(rank))
+            raise SingularSystem(rc, msg, side.value, row.value, rank.value)
         if rc == _lib.CANCELLED:
             raise Cancelled(rc, msg)
         raise MalsError(rc, msg)

@@ -53,9 +53,14 @@ def check_half(core, side, csr, M_host, G, n_rows, rng, torch, n_sample=300, n_l
 
 
 @pytest.mark.parametrize("name,n_users,n_items,nnz,k", [
+    ("C1 MovieLens-100K shape", 943, 1_682, 100_000, 10),
     ("C2 MovieLens-25M shape", 162_541, 59_047, 25_000_095, 50),
     ("C3 Netflix-Prize shape", 480_189, 17_770, 100_480_507, 100),
     ("C4 synthetic 10M x 1M", 10_000_000, 1_000_000, 1_000_000_000, 64),
+    # C5 (100M x 10M, 5e9 entries, k=128) is an 8-GPU configuration: one rank's share of the user rows
+    # against the full item side -- the shapes, row lengths and kernels (k = 128: dual path for the short
+    # rows, T = 8 direct kernels for the long ones) of a C5 rank
+    ("C5 one-rank shard (1/8 of the users)", 12_500_000, 10_000_000, 625_000_000, 128),
 ])
 def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
     import torch
@@ -70,9 +75,16 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
         Y0 = prob["Y0"].cpu().numpy()
         core.set_factors(pkg.SIDE_Y, Y0)
 
-        # --- Gramian of Y0: GPU fp64 vs oracle on the whole matrix (1M x 64 at most here)
+        # --- Gramian of Y0: GPU fp64 vs oracle on the whole matrix (up to 1M rows; a 1M-row slice beyond)
         Gy = core.gramian(pkg.SIDE_Y, fetch=True)
-        assert rel(Gy, oracle.gramian(Y0)) < 5e-7
+        if n_items <= 1_000_000:
+            assert rel(Gy, oracle.gramian(Y0)) < 5e-7
+        else:
+            gs = torch.zeros(k, k, dtype=torch.float64, device=dev)
+            core.gramian_partial(pkg.SIDE_Y, 12_345, 1_000_000, gs)
+            torch.cuda.synchronize()
+            assert rel(gs.cpu().numpy(), oracle.gramian(Y0[12_345:1_012_345])) < 5e-7
+        core.reset_stats()
         # --- X half
         core.solve_side(pkg.SIDE_X)
         core.check()
@@ -102,6 +114,10 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
         max_len_y = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, Gx, n_items, rng, torch)
         if "C4" in name or "C3" in name:
             assert max_len_y > 4096, "C3 / C4 must exercise the long-row (segments) path"
+        st = core.stats()
+        assert st["rows_solved"] == n_users + n_items
+        if k > 32:
+            assert st["rows_dual"] > 0, "k > 32: the short rows go through the dual kernels"
         Y = core.get_factors(pkg.SIDE_Y)
         assert np.all(np.isfinite(Y))
         # a solved factor matrix is not degenerate
