@@ -242,6 +242,14 @@ int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iter
                    const int64_t* test_items, int32_t n_test_items, int32_t* iterations_out,
                    double* convergence_out);
 
+/* The convergence sample on the device (ALS:230-238): host_out[i*n_test_items+j] =
+ * SimpleVectorMath.dot(X[test_users[i]], Y[test_items[j]]) (float product, double sum, features in order --
+ * bit-identical to the Java loop) from the resident factors; 8 bytes per pair cross PCIe instead of the
+ * sampled rows.  mals_factorize / mals_group_factorize use it every iteration and keep only the
+ * order-dependent DoubleWeightedMean on the host. */
+int mals_sample_dots(mals_handle h, const int64_t* test_users, int32_t n_test_users, const int64_t* test_items,
+                     int32_t n_test_items, double* host_out);
+
 /* Cooperative cancellation (InterruptedException path, MatrixFactorizer.java:43-44): checked
  * between half-iterations of mals_factorize. */
 int mals_cancel(mals_handle h);

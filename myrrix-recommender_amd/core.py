@@ -365,6 +365,15 @@ class ALSCore:
     def reset_stats(self):
         self._chk(self._L.mals_reset_stats(self._h))
 
+    def sample_dots(self, test_users, test_items):
+        """est[i, j] = SimpleVectorMath.dot(X[test_users[i]], Y[test_items[j]]) from the resident factors."""
+        tu = _host(test_users, np.int64)
+        ti = _host(test_items, np.int64)
+        out = np.empty((len(tu), len(ti)), dtype=np.float64)
+        self._chk(self._L.mals_sample_dots(self._h, tu.ctypes.data_as(ctypes.c_void_p), len(tu), ti.ctypes.data_as(ctypes.c_void_p),
+                                           len(ti), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def stats(self):
         st = _lib.Stats()
         self._chk(self._L.mals_get_stats(self._h, ctypes.byref(st)))

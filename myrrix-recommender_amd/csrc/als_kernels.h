@@ -1351,6 +1351,20 @@ __global__ __launch_bounds__(256) void reconstruction_kernel(const int64_t* __re
   }
 }
 
+// The convergence sample of call() (ALS:230-238): est[i][j] = SimpleVectorMath.dot(X[test_users[i]],
+// Y[test_items[j]]) (SimpleVectorMath.java:34-41: float product, double sum, features in order), one thread
+// per pair, from the resident factors -- bit-identical to the host loop it replaces.
+__global__ void sample_dots_kernel(const float* __restrict__ X, const float* __restrict__ Y, const int64_t* __restrict__ users,
+                                   const int64_t* __restrict__ items, int n_users, int n_items, int k, double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_users * n_items) return;
+  const float* x = X + users[e / n_items] * (int64_t)k;
+  const float* y = Y + items[e % n_items] * (int64_t)k;
+  double d = 0.0;
+  for (int f = 0; f < k; ++f) d += (double)__fmul_rn(x[f], y[f]);
+  out[e] = d;
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ F, const int64_t* __restrict__ idx, int n, int k,
                                    float* __restrict__ out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;

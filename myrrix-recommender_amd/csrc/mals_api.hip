@@ -142,6 +142,9 @@ struct mals_handle_s {
   size_t tn_host_words = 0;
   float* tn_q = nullptr;       // query vectors of one pass
   int64_t* tn_qidx = nullptr;  // [2][TOPN_MAX_QUERIES]: user indices, local rows
+  double* d_sd = nullptr;       // mals_sample_dots: estimates, indices
+  int64_t* d_sd_idx = nullptr;
+  size_t sd_cap = 0, sd_idx_cap = 0;
   int64_t* d_idx = nullptr;  // gather scratch
   float* d_rows = nullptr;
   int32_t idx_cap = 0;
@@ -753,17 +756,6 @@ void dwm_increment(double& total_weight, double& mean, double datum, double weig
   }
 }
 
-// SimpleVectorMath.dot (common/src/net/myrrix/common/math/SimpleVectorMath.java:34-41):
-// float product, double accumulation
-double dot_f(const float* x, const float* y, int k) {
-  double d = 0.0;
-  for (int i = 0; i < k; ++i) {
-    const volatile float p = x[i] * y[i];
-    d += (double)p;
-  }
-  return d;
-}
-
 }  // namespace
 
 namespace {
@@ -1128,6 +1120,8 @@ int mals_destroy(mals_handle h) {
   if (h->h_bad) (void)hipHostFree(h->h_bad);
   free_dev(h->d_idx);
   free_dev(h->d_rows);
+  free_dev(h->d_sd);
+  free_dev(h->d_sd_idx);
   free_dev(h->tn_scores);
   free_dev(h->tn_out);
   free_dev(h->tn_state);
@@ -1704,6 +1698,42 @@ int mals_half_iteration(mals_handle h, int side) {
   return mals_check(h);                                            // ALS:346-361 f.get()
 }
 
+int mals_sample_dots(mals_handle h, const int64_t* test_users, int32_t n_test_users, const int64_t* test_items, int32_t n_test_items,
+                     double* host_out) {
+  if (!h) return MALS_INVALID_ARG;
+  SideState& x = h->side[MALS_SIDE_X];
+  SideState& y = h->side[MALS_SIDE_Y];
+  if (!x.F || !y.F) return fail(h, MALS_INVALID_ARG, "factor replicas not allocated");
+  if (n_test_users < 0 || n_test_items < 0 || (n_test_users > 0 && !test_users) || (n_test_items > 0 && !test_items) ||
+      (int64_t)n_test_users * n_test_items > (1 << 24))
+    return fail(h, MALS_INVALID_ARG, "bad convergence sample");
+  const int64_t n = (int64_t)n_test_users * n_test_items;
+  if (n == 0) return MALS_OK;
+  if (!host_out) return fail(h, MALS_INVALID_ARG, "null output");
+  for (int i = 0; i < n_test_users; ++i)
+    if (test_users[i] < 0 || test_users[i] >= x.n_total) return fail(h, MALS_INVALID_ARG, "test user outside the factor replica");
+  for (int j = 0; j < n_test_items; ++j)
+    if (test_items[j] < 0 || test_items[j] >= y.n_total) return fail(h, MALS_INVALID_ARG, "test item outside the factor replica");
+  if (int rc = use_device(h)) return rc;
+  const size_t idx_bytes = sizeof(int64_t) * (size_t)(n_test_users + n_test_items);
+  if (h->sd_cap < (size_t)n || h->sd_idx_cap < idx_bytes) {
+    free_dev(h->d_sd);
+    free_dev(h->d_sd_idx);
+    HIPCHK(h, hipMalloc(&h->d_sd, sizeof(double) * (size_t)n));
+    HIPCHK(h, hipMalloc(&h->d_sd_idx, idx_bytes));
+    h->sd_cap = (size_t)n;
+    h->sd_idx_cap = idx_bytes;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->d_sd_idx, test_users, sizeof(int64_t) * (size_t)n_test_users, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_sd_idx + n_test_users, test_items, sizeof(int64_t) * (size_t)n_test_items, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(sample_dots_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, x.F, y.F, h->d_sd_idx,
+                     h->d_sd_idx + n_test_users, n_test_users, n_test_items, h->cfg.features, h->d_sd);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(host_out, h->d_sd, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MALS_OK;
+}
+
 int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iterations, int32_t random_y, int32_t iterate,
                    const int64_t* test_users, int32_t n_test_users, const int64_t* test_items, int32_t n_test_items,
                    int32_t* iterations_out, double* convergence_out) {
@@ -1717,21 +1747,20 @@ int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iter
     return fail(h, MALS_INVALID_ARG, "bad convergence sample");
   h->cancelled.store(0);
   if (!iterate) return mals_half_iteration(h, MALS_SIDE_X);  // ALS:196-204
-  const int k = h->cfg.features;
   std::vector<double> est((size_t)n_test_users * (size_t)n_test_items, 0.0);  // ALS:215: X empty => 0
-  std::vector<float> xu((size_t)n_test_users * k), yi((size_t)n_test_items * k);
+  std::vector<double> fresh(est.size());
   int it = 0;
   for (;;) {
     if (h->cancelled.load()) return fail(h, MALS_CANCELLED, "cancelled");
     if (int rc = mals_half_iteration(h, MALS_SIDE_X)) return rc;  // ALS:228
     if (h->cancelled.load()) return fail(h, MALS_CANCELLED, "cancelled");
     if (int rc = mals_half_iteration(h, MALS_SIDE_Y)) return rc;  // ALS:229
-    if (int rc = mals_get_rows(h, MALS_SIDE_X, test_users, n_test_users, xu.data())) return rc;
-    if (int rc = mals_get_rows(h, MALS_SIDE_Y, test_items, n_test_items, yi.data())) return rc;
+    // the sample dots on the device (ALS:234), the order-dependent running mean on the host (ALS:237)
+    if (int rc = mals_sample_dots(h, test_users, n_test_users, test_items, n_test_items, fresh.data())) return rc;
     double tw = 0.0, mean = std::numeric_limits<double>::quiet_NaN();
     for (int i = 0; i < n_test_users; ++i) {
       for (int j = 0; j < n_test_items; ++j) {  // ALS:231-238
-        const double nv = dot_f(&xu[(size_t)i * k], &yi[(size_t)j * k], k);
+        const double nv = fresh[(size_t)i * n_test_items + j];
         const double ov = est[(size_t)i * n_test_items + j];
         est[(size_t)i * n_test_items + j] = nv;
         dwm_increment(tw, mean, std::fabs(nv - ov), nv > 0.0 ? nv : 0.0);

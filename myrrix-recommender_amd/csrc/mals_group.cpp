@@ -762,9 +762,7 @@ int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max
     return gfail(g, MALS_INVALID_ARG, "bad convergence sample");
   g->cancelled.store(0);
   if (!iterate) return mals_group_half_iteration(g, MALS_SIDE_X);  // ALS:196-204
-  const int k = g->cfg.features;
-  std::vector<double> est((size_t)n_test_users * (size_t)n_test_items, 0.0);
-  std::vector<float> xu((size_t)n_test_users * k), yi((size_t)n_test_items * k);
+  std::vector<double> est((size_t)n_test_users * (size_t)n_test_items, 0.0), fresh(est.size());
   int it = 0;
   for (;;) {
     // a cancellation is local knowledge: agree on it before entering a collective
@@ -772,17 +770,14 @@ int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max
     if (int rc = mals_group_half_iteration(g, MALS_SIDE_X)) return rc;  // ALS:228
     if (int rc = agree_status(g, g->cancelled.load() ? MALS_CANCELLED : MALS_OK, "cancelled")) return rc;
     if (int rc = mals_group_half_iteration(g, MALS_SIDE_Y)) return rc;  // ALS:229
-    if (int rc = mals_group_get_rows(g, MALS_SIDE_X, test_users, n_test_users, xu.data())) return rc;
-    if (int rc = mals_group_get_rows(g, MALS_SIDE_Y, test_items, n_test_items, yi.data())) return rc;
-    // ALS:231-238 with SimpleVectorMath.dot (float product, double sum) and DoubleWeightedMean.increment
+    // ALS:231-238: the sample dots (SimpleVectorMath.dot) on the device from a complete replica (every replica
+    // holds the same factors once the exchange is in), DoubleWeightedMean.increment on the host
+    if (int rc = mals_group_synchronize(g)) return rc;
+    if (int rc = mals_sample_dots(g->m[0].h, test_users, n_test_users, test_items, n_test_items, fresh.data())) return mfail(g, g->m[0], rc);
     double tw = 0.0, mean = std::numeric_limits<double>::quiet_NaN();
     for (int i = 0; i < n_test_users; ++i)
       for (int j = 0; j < n_test_items; ++j) {
-        double nv = 0.0;
-        for (int f = 0; f < k; ++f) {
-          const volatile float p = xu[(size_t)i * k + f] * yi[(size_t)j * k + f];
-          nv += (double)p;
-        }
+        const double nv = fresh[(size_t)i * n_test_items + j];
         double& slot = est[(size_t)i * n_test_items + j];
         const double datum = std::fabs(nv - slot), weight = nv > 0.0 ? nv : 0.0;
         slot = nv;

@@ -43,3 +43,25 @@ def test_empty_and_missing_inputs():
         core.set_factor_rows(pkg.SIDE_Y, 2)
         core.set_matrix(pkg.SIDE_X, np.array([0, 0, 0, 0], np.int64), np.zeros(0, np.int32), np.zeros(0, np.float32))
         assert core.reconstruction_error() == (0.0, 0)
+
+
+def test_sample_dots_are_bit_identical_to_the_reference_dot():
+    """the ~100 x 100 convergence sample of call() (ALS:230-238) computed on the device
+    must be SimpleVectorMath.dot (float product, double sum, features in order) bit for bit."""
+    rng = np.random.default_rng(5)
+    for k in (2, 30, 64, 100, 128):
+        n_users, n_items = 900, 400
+        X = rng.standard_normal((n_users, k)).astype(np.float32)
+        Y = (rng.standard_normal((n_items, k)) * np.logspace(0, -4, k)[None, :]).astype(np.float32)
+        tu = rng.choice(n_users, 100, replace=False).astype(np.int64)
+        ti = rng.choice(n_items, 97, replace=False).astype(np.int64)
+        with pkg.ALSCore(k) as core:
+            core.set_factor_rows(pkg.SIDE_X, n_users)
+            core.set_factor_rows(pkg.SIDE_Y, n_items)
+            core.set_factors(pkg.SIDE_X, X)
+            core.set_factors(pkg.SIDE_Y, Y)
+            got = core.sample_dots(tu, ti)
+            with pytest.raises(pkg.MalsError):
+                core.sample_dots(np.array([n_users], dtype=np.int64), ti)
+        expect = np.array([[oracle.dot(X[u], Y[i]) for i in ti] for u in tu])
+        assert np.array_equal(got, expect), (k, np.abs(got - expect).max())
