@@ -47,6 +47,7 @@ struct DualParams {
   float alpha;
   float lambda_alpha;
   float sqrt_w_max;         // sqrt(alpha * max |r|): bound of C^1/2
+  unsigned* xbound;         // bit pattern of the largest |x'| stored so far (operand scale of the un-rotation)
 };
 
 struct RotateParams {
@@ -150,7 +151,145 @@ __global__ __launch_bounds__(256, 2) void rotate_rows_kernel(RotateParams p) {
   }
   if (!LISTED && p.zbound) {
     for (int off = 32; off > 0; off >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off));
-    if (lane == 0) atomicMax(p.zbound, __float_as_uint(zmax));
+    if (lane == 0 && zmax > __uint_as_float(__builtin_nontemporal_load(p.zbound))) atomicMax(p.zbound, __float_as_uint(zmax));
+  }
+}
+
+// The same product on the f16 matrix pipe (v_mfma_f32_16x16x32_f16), operands split into two f16 halves
+// like the per-row Gramians: 3 x 16 cycles per 16 x 16 x 32 block instead of 8 x 33 -- the forward rotation
+// of a well-conditioned half-iteration and every un-rotation run here (k a multiple of 8).
+//   A (rows): lane (g,c) reads features 32 q + 8 g .. + 7 of row c of a 16-row tile (two 16-byte loads), times a
+//             power of two sA with max |value| sA <= 2^14 -- forward: max |y| <= sqrt(max_f G_ff) from the host;
+//             un-rotation: the largest |x'| the dual kernels stored (a device scalar they maintain) -- then
+//             hi = round toward zero, lo = round to nearest of the exact residual;
+//   B (Q):    split once on the host into the operand layout  Bs[q][t][hi|lo][lane] (16 bytes each), scale 2^13.
+// One wave per NT 16-row tiles that share every B operand.
+struct RotateSplitParams {
+  const float* src;
+  float* dst;
+  const i32x4* Bs;          // [KC][T][2][64] operand-layout halves of Q (forward) or Q^T (LISTED), times 2^13
+  const WorkItem* items;
+  const float* dmax;
+  unsigned* zbound;
+  const unsigned* bound_bits;  // device scalar: bit pattern of a bound on |src| (LISTED); NULL: bound_host
+  float bound_host;
+  int64_t n_rows;
+  int32_t k;
+  int32_t src_stride, dst_stride, dst_cols;
+};
+
+// 16-row tiles per wave
+__host__ __device__ constexpr int rotate_split_tiles(int T) { return T >= 7 ? 2 : 4; }
+
+template <int T, bool LISTED>
+__global__ __launch_bounds__(256, 2) void rotate_rows_split_kernel(RotateSplitParams p) {
+  constexpr int KC = (T + 1) / 2, NT = rotate_split_tiles(T);
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t n_tiles = (p.n_rows + 16 * NT - 1) / (16 * NT);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  float sa, inv_scale;
+  {
+    const float bound = p.bound_bits ? __uint_as_float(uniform((int)*p.bound_bits)) : p.bound_host;
+    const int eb = ((__float_as_int(bound) >> 23) & 255) - 126;   // bound < 2^eb
+    int pw = 14 - eb;
+    pw = pw < -100 ? -100 : (pw > 100 ? 100 : pw);
+    if (!(bound > 0.f)) pw = 0;
+    sa = __int_as_float((pw + 127) << 23);
+    inv_scale = __int_as_float((127 - pw) << 23) * (1.0f / 8192.0f);   // 1 / (sA * 2^13)
+  }
+  float dmaxcol[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) dmaxcol[t] = (!LISTED && p.dmax) ? p.dmax[16 * t + c] : 0.f;
+  float zmax = 0.f;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
+    const float* sp[NT];
+    bool okc[NT];
+#pragma unroll
+    for (int h = 0; h < NT; ++h) {
+      const int64_t rc = tile * (16 * NT) + 16 * h + c;
+      okc[h] = rc < p.n_rows;
+      const int64_t row_c = LISTED ? (int64_t)p.items[okc[h] ? rc : p.n_rows - 1].id : (okc[h] ? rc : 0);
+      sp[h] = p.src + row_c * (int64_t)p.src_stride + 8 * g;
+    }
+    f32x4 acc[NT][T];
+#pragma unroll
+    for (int h = 0; h < NT; ++h)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // chunk q+1 is requested before the products of chunk q
+    f32x4 raw[NT][2], nxt[NT][2];
+    auto load_chunk = [&](int q, f32x4 (&dstv)[NT][2]) {
+#pragma unroll
+      for (int h = 0; h < NT; ++h) {
+        const bool okf = okc[h] && 32 * q + 8 * g < p.k;   // k is a multiple of 8: a lane's 8 features are all in or all out
+        dstv[h][0] = okf ? *reinterpret_cast<const f32x4*>(sp[h] + 32 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dstv[h][1] = okf ? *reinterpret_cast<const f32x4*>(sp[h] + 32 * q + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    load_chunk(0, raw);
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+      if (q + 1 < KC) load_chunk(q + 1, nxt);
+      ZOp<8> ah[NT], al[NT];
+#pragma unroll
+      for (int h = 0; h < NT; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x4 z = raw[h][u] * sa;
+          const int h01 = pk_rtz(z[0], z[1]), h23 = pk_rtz(z[2], z[3]);
+          const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 r01 = {z[0] - (float)a[0], z[1] - (float)a[1]}, r23 = {z[2] - (float)b[0], z[3] - (float)b[1]};
+          ah[h].r[2 * u] = h01;
+          ah[h].r[2 * u + 1] = h23;
+          al[h].r[2 * u] = __builtin_bit_cast(int, __builtin_convertvector(r01, f16x2));      // v_cvt_pk_f16_f32: round to nearest
+          al[h].r[2 * u + 1] = __builtin_bit_cast(int, __builtin_convertvector(r23, f16x2));
+        }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const i32x4* bp = p.Bs + ((size_t)(q * T + t) * 2) * 64 + lane;
+        const i32x4 b_hi = bp[0], b_lo = bp[64];
+        ZOp<8> bh, bl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bh.r[e] = b_hi[e];
+          bl.r[e] = b_lo[e];
+        }
+#pragma unroll
+        for (int h = 0; h < NT; ++h) {
+          acc[h][t] = mfma_h<8>(ah[h], bh, acc[h][t]);
+          acc[h][t] = mfma_h<8>(ah[h], bl, acc[h][t]);
+          acc[h][t] = mfma_h<8>(al[h], bh, acc[h][t]);
+        }
+        // the B operands of a few (q,t) ahead are enough in flight; left alone the scheduler hoists all KC x T of them
+        if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int h = 0; h < NT; ++h) {
+        raw[h][0] = nxt[h][0];
+        raw[h][1] = nxt[h][1];
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NT; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t rr = tile * (16 * NT) + 16 * h + 4 * g + r;
+        if (rr < p.n_rows) {
+          const int64_t row = LISTED ? (int64_t)p.items[rr].id : rr;
+          float* o = p.dst + row * (int64_t)p.dst_stride;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const float v = acc[h][t][r] * inv_scale;
+            if (16 * t + c < p.dst_cols) o[16 * t + c] = v;
+            if (!LISTED) zmax = fmaxf(zmax, fabsf(v) * dmaxcol[t]);
+          }
+        }
+      }
+  }
+  if (!LISTED && p.zbound) {
+    for (int off = 32; off > 0; off >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off));
+    if (lane == 0 && zmax > __uint_as_float(__builtin_nontemporal_load(p.zbound))) atomicMax(p.zbound, __float_as_uint(zmax));
   }
 }
 
@@ -233,6 +372,7 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
   WorkItem cur = dual_load_item(p, it);
   WorkItem nxt = dual_load_item(p, it + n_waves);
   DualEntries<TN> en = dual_load_entries<TN>(p, cur, c);
+  float xmax = 0.f;
   for (;;) {
     const int n = cur.len;
     // (1) all gathers of the row: lane (g,c) reads, for entry c of every 16-entry block, 16 bytes at
@@ -360,13 +500,21 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
 #pragma unroll
       for (int j = 0; j < T; ++j) {
         const float x = reduce_groups(xacc[j], lane) * dc[16 * j] * inv_sc;
-        if (lane < 16 && 16 * j + lane < p.k) o[16 * j + lane] = bad ? 0.f : x;
+        if (lane < 16 && 16 * j + lane < p.k) {
+          o[16 * j + lane] = bad ? 0.f : x;
+          xmax = fmaxf(xmax, bad ? 0.f : fabsf(x));
+        }
       }
     }
     if (nxt.len <= 0) break;
     cur = nxt;
     nxt = nx2;
     it += n_waves;
+  }
+  if (p.xbound) {
+    for (int off = 8; off > 0; off >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, off));
+    // same-address atomics serialise in L2 (~10 ns each, 1e5 waves): only waves that raise the bound issue one
+    if (lane == 0 && xmax > __uint_as_float(__builtin_nontemporal_load(p.xbound))) atomicMax(p.xbound, __float_as_uint(xmax));
   }
 }
 

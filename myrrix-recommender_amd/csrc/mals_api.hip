@@ -104,6 +104,9 @@ struct mals_handle_s {
   double* d_Q = nullptr;      // [2][16T][16T]: Q (k x 16T, zero padded) and Q^T
   float* d_Qf = nullptr;      // the same in fp32
   bool rotate_f64 = false;    // this half-iteration's forward rotation runs on the fp64 matrix cores
+  bool rotate_split = false;  // k % 8 == 0: rotations on the f16 matrix pipe with split operands
+  int32_t* d_Bs = nullptr;    // [2][KC][T][2][64][4]: Q and Q^T as split-f16 B operands
+  size_t Bs_stride = 0;
   float* d_lam = nullptr;     // [2][16T]: eigenvalues, 1/sqrt(L + lambda alpha)
   unsigned* d_zbound = nullptr;
   double* h_G = nullptr;      // pinned k x k
@@ -578,6 +581,74 @@ int launch_rotate(mals_handle h, const RotateParams& rp) {
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
 }
 
+template <int T, bool LISTED>
+int launch_rotate_split_T(mals_handle h, const RotateSplitParams& rp) {
+  const int rows_per_wave = 16 * rotate_split_tiles(T);
+  const int64_t tiles = (rp.n_rows + rows_per_wave - 1) / rows_per_wave;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, (int64_t)h->n_cu * 16));
+  hipLaunchKernelGGL((rotate_rows_split_kernel<T, LISTED>), dim3(grid), dim3(256), 0, h->stream, rp);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+template <bool LISTED>
+int launch_rotate_split(mals_handle h, const RotateSplitParams& rp) {
+  switch (h->T) {
+    case 2: return launch_rotate_split_T<2, LISTED>(h, rp);
+    case 3: return launch_rotate_split_T<3, LISTED>(h, rp);
+    case 4: return launch_rotate_split_T<4, LISTED>(h, rp);
+    case 5: return launch_rotate_split_T<5, LISTED>(h, rp);
+    case 6: return launch_rotate_split_T<6, LISTED>(h, rp);
+    case 7: return launch_rotate_split_T<7, LISTED>(h, rp);
+    case 8: return launch_rotate_split_T<8, LISTED>(h, rp);
+  }
+  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
+// fp32 -> f16 bit pattern, round to nearest even (the compiler's conversion) / toward zero
+uint16_t half_rne(float v) {
+  const _Float16 x = (_Float16)v;
+  uint16_t b;
+  std::memcpy(&b, &x, 2);
+  return b;
+}
+uint16_t half_rtz(float v) {
+  uint16_t b = half_rne(v);
+  _Float16 x;
+  std::memcpy(&x, &b, 2);
+  if (std::fabs((float)x) > std::fabs(v)) --b;  // one step toward zero: f16 magnitudes order like their bit patterns
+  return b;
+}
+float half_to_float(uint16_t b) {
+  _Float16 x;
+  std::memcpy(&x, &b, 2);
+  return (float)x;
+}
+
+// Q (or Q^T), times 2^13, as the split-f16 B operands of rotate_rows_split_kernel: Bs[q][t][hi|lo][lane][4 dwords],
+// lane (g,c) slot s = element [32 q + 8 g + s][16 t + c]
+void split_rotation_operand(const double* B, int k, int KP, int T, std::vector<int32_t>& out) {
+  const int KC = (T + 1) / 2;
+  out.assign((size_t)KC * T * 2 * 64 * 4, 0);
+  for (int q = 0; q < KC; ++q)
+    for (int t = 0; t < T; ++t)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, c = lane & 15;
+        uint16_t hi[8], lo[8];
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const int f = 32 * q + 8 * g + s8;
+          const float v = f < k ? (float)(B[(size_t)f * KP + 16 * t + c] * 8192.0) : 0.f;
+          hi[s8] = half_rtz(v);
+          lo[s8] = half_rne(v - half_to_float(hi[s8]));
+        }
+        int32_t* oh = &out[(((size_t)(q * T + t) * 2 + 0) * 64 + lane) * 4];
+        int32_t* ol = &out[(((size_t)(q * T + t) * 2 + 1) * 64 + lane) * 4];
+        for (int e = 0; e < 4; ++e) {
+          oh[e] = (int32_t)((uint32_t)hi[2 * e] | ((uint32_t)hi[2 * e + 1] << 16));
+          ol[e] = (int32_t)((uint32_t)lo[2 * e] | ((uint32_t)lo[2 * e + 1] << 16));
+        }
+      }
+}
+
 template <int T, int TN>
 int launch_dual_TN(mals_handle h, DualParams dp) {
   unsigned grid = 1;
@@ -650,10 +721,17 @@ int prepare_dual(mals_handle h, int side) {
   // large products (dual_kernels.h, rotate_rows_kernel)
   h->rotate_f64 = (lmax + la) > 1.0e5 * (std::max(lmin, 0.0) + la);
   if (const char* e = std::getenv("MALS_ROTATE_F64")) h->rotate_f64 = std::atoi(e) != 0;  // tests / A-B
+  h->rotate_split = k % 8 == 0 && !std::getenv("MALS_ROTATE_NO_SPLIT");
+  std::vector<int32_t> Bs[2];
+  if (h->rotate_split) {
+    split_rotation_operand(Q.data(), k, KP, h->T, Bs[0]);
+    split_rotation_operand(Q.data() + (size_t)KP * KP, k, KP, h->T, Bs[1]);
+    if (!h->d_Bs) HIPCHK(h, hipMalloc(&h->d_Bs, sizeof(int32_t) * 2 * Bs[0].size()));
+  }
   if (!h->d_Q) HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * Q.size()));
   if (!h->d_Qf) HIPCHK(h, hipMalloc(&h->d_Qf, sizeof(float) * Qf.size()));
   if (!h->d_lam) HIPCHK(h, hipMalloc(&h->d_lam, sizeof(float) * lam.size()));
-  if (!h->d_zbound) HIPCHK(h, hipMalloc(&h->d_zbound, sizeof(unsigned)));
+  if (!h->d_zbound) HIPCHK(h, hipMalloc(&h->d_zbound, 2 * sizeof(unsigned)));  // {z bound of the dual kernels, x' bound of the un-rotation}
   const size_t need = (size_t)o.n_total * KP;
   if (h->Mr_cap < need) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -665,8 +743,13 @@ int prepare_dual(mals_handle h, int side) {
   // pageable sources: these copies return once the data is staged, the vectors may go out of scope
   HIPCHK(h, hipMemcpyAsync(h->d_Q, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->d_Qf, Qf.data(), sizeof(float) * Qf.size(), hipMemcpyHostToDevice, h->stream));
+  if (h->rotate_split) {
+    HIPCHK(h, hipMemcpyAsync(h->d_Bs, Bs[0].data(), sizeof(int32_t) * Bs[0].size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_Bs + Bs[0].size(), Bs[1].data(), sizeof(int32_t) * Bs[1].size(), hipMemcpyHostToDevice, h->stream));
+    h->Bs_stride = Bs[0].size();
+  }
   HIPCHK(h, hipMemcpyAsync(h->d_lam, lam.data(), sizeof(float) * lam.size(), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_zbound, 0, sizeof(unsigned), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_zbound, 0, 2 * sizeof(unsigned), h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   RotateParams rp;
   rp.src = o.F;
@@ -683,7 +766,19 @@ int prepare_dual(mals_handle h, int side) {
   rp.dst_cols = KP;
   PendingEvent pe;
   if (int rc = begin_timed(h, 5, (double)o.n_total * (4.0 * k + 4.0 * KP), pe)) return rc;
-  if (int rc = h->rotate_f64 ? launch_rotate<false, true>(h, rp) : launch_rotate<false, false>(h, rp)) return rc;
+  if (h->rotate_split && !h->rotate_f64) {
+    RotateSplitParams sp;
+    sp.src = rp.src; sp.dst = rp.dst; sp.items = nullptr; sp.dmax = rp.dmax; sp.zbound = rp.zbound; sp.n_rows = rp.n_rows; sp.k = k;
+    sp.src_stride = rp.src_stride; sp.dst_stride = rp.dst_stride; sp.dst_cols = rp.dst_cols;
+    sp.Bs = reinterpret_cast<const i32x4*>(h->d_Bs);
+    sp.bound_bits = nullptr;
+    double gmax = 0.0;   // max |y_f| <= sqrt(max_f G_ff)
+    for (int f = 0; f < k; ++f) gmax = std::max(gmax, h->h_G[(size_t)f * k + f]);
+    sp.bound_host = (float)std::sqrt(gmax);
+    if (int rc = launch_rotate_split<false>(h, sp)) return rc;
+  } else if (int rc = h->rotate_f64 ? launch_rotate<false, true>(h, rp) : launch_rotate<false, false>(h, rp)) {
+    return rc;
+  }
   if (int rc = end_timed(h, pe)) return rc;
   (void)s;
   h->dual_ok = true;
@@ -708,6 +803,7 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
   dp.alpha = (float)h->cfg.alpha;
   dp.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);
   dp.sqrt_w_max = (float)std::sqrt(std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
+  dp.xbound = h->d_zbound + 1;
   const WorkItem* base = s.itemsA + cr.offA + cr.nA;
   int64_t off = 0;
   PendingEvent pe;
@@ -734,7 +830,17 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
   rp.dst_stride = k;
   rp.dst_cols = k;
   if (int rc = begin_timed(h, 5, (double)cr.n_dual() * 8.0 * k, pe)) return rc;
-  if (int rc = launch_rotate<true, false>(h, rp)) return rc;
+  if (h->rotate_split) {
+    RotateSplitParams sp;
+    sp.src = rp.src; sp.dst = rp.dst; sp.items = rp.items; sp.dmax = nullptr; sp.zbound = nullptr; sp.n_rows = rp.n_rows; sp.k = k;
+    sp.src_stride = k; sp.dst_stride = k; sp.dst_cols = k;
+    sp.Bs = reinterpret_cast<const i32x4*>(h->d_Bs + h->Bs_stride);
+    sp.bound_bits = h->d_zbound + 1;
+    sp.bound_host = 0.f;
+    if (int rc = launch_rotate_split<true>(h, sp)) return rc;
+  } else if (int rc = launch_rotate<true, false>(h, rp)) {
+    return rc;
+  }
   return end_timed(h, pe);
 }
 
@@ -1113,6 +1219,7 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_Mr);
   free_dev(h->d_Q);
   free_dev(h->d_Qf);
+  free_dev(h->d_Bs);
   free_dev(h->d_lam);
   free_dev(h->d_zbound);
   if (h->h_G) (void)hipHostFree(h->h_G);

@@ -16,6 +16,7 @@
 #include <zlib.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -134,7 +135,7 @@ int32_t checked_count(int64_t n, const char* what) {
 
 void write_matrix(BlockOut& b, int64_t n, const int64_t* ids, const float* rows, int32_t k, const char* what) {
   b.i32(checked_count(n, what));
-  if (n && (!ids || !rows)) fail(MALS_INVALID_ARG, std::string(what) + ": null array");
+  if (n && (!ids || (k > 0 && !rows))) fail(MALS_INVALID_ARG, std::string(what) + ": null array");
   for (int64_t r = 0; r < n; ++r) {
     b.i64(ids[r]);
     b.i32(k);
@@ -357,14 +358,15 @@ void skip_class_name_object(GzIn& in) {  // className1 of an object-typed field:
 void read_matrix(BlockIn& b, std::vector<int64_t>& ids, std::vector<float>& rows, int32_t& features, bool& have_features,
                  const char* what) {
   const int32_t n = b.count(what);
-  ids.reserve(n);
+  // the counts come from the file: a corrupt header must not drive a multi-GB allocation before any data is read
+  ids.reserve(std::min<size_t>((size_t)n, (size_t)1 << 20));
   for (int32_t r = 0; r < n; ++r) {
     ids.push_back(b.i64());
     const int32_t k = b.count(what);
     if (!have_features) {
       features = k;
       have_features = true;
-      rows.reserve((size_t)n * k);
+      rows.reserve(std::min<size_t>((size_t)n * (size_t)k, (size_t)1 << 24));
     } else if (k != features) {
       fail(MALS_INVALID_ARG, std::string(what) + ": rows of different lengths");
     }
