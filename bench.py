@@ -249,6 +249,7 @@ def main():
         # Cholesky kernel over the direct rows (MODE 0; als_persistent_kernel_h is what AUTO selects above
         # k = 32) or the dual kernels of the short rows (als_dual_kernel<T,TN>, all row classes together)
         split = args.gramian_mode == "split_f16" or (args.gramian_mode == "auto" and k > 32)
+        T_blocks = (k + 15) // 16
         dom = "dual" if st["dual_ms"] > st["rows_ms"] else "rows"
         if dom == "dual":
             kernel_name = "mals::als_dual_kernel<T=%d,TN=1..%d> (short rows: gather of rotated rows + n_u x n_u system, all row classes of a half-iteration)" % ((k + 15) // 16, (k + 15) // 32)
@@ -268,12 +269,14 @@ def main():
         k3_ms_at_peak = k3_flop / 157.3e12 * 1e3
         # HBM traffic per launch of the same kernel from the PMC passes committed under profiles/
         # (rocprofv3 cannot run inside this process); null when no profile matches this workload
-        traffic, traffic_src = None, None
+        traffic, traffic_src, gram_busy = None, None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pm.get("workload") == args.workload and pm.get("k") == k and world == 1:
-                traffic = pm["traffic_bytes_per_launch"]
-                traffic_src = "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+                if dom == "rows":
+                    traffic = pm["traffic_bytes_per_launch"]
+                    traffic_src = "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+                gram_busy = pm.get("gramian_mfma_busy_fraction")
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -307,6 +310,11 @@ def main():
                                        "direct_factorization_fp32_mfma_floor_ms": k3_ms_at_peak,
                                        "binding": "hbm" if (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps / (HBM_PEAK_GBS * 1e6) >= k3_ms_at_peak else "mfma_fp32"}},
             "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian", "dual", "rotate")},
+            "gramian": {"ms_per_step": st["gramian_ms"] / args.steps, "kernel": "mals::gramian_partial_kernel<T=%d> (M^T M, v_mfma_f64_16x16x4_f64)" % ((k + 15) // 16),
+                        # rows x tri(T) tiles x 2048 flop per 16x16x4 instruction, one instruction per 4 rows
+                        "fp64_mfma_TFLOPs": (st["gramian_bytes"] / (4.0 * k)) * (T_blocks * (T_blocks + 1) // 2) * 512.0 / max(st["gramian_ms"], 1e-9) / 1e9,
+                        "fp64_mfma_peak_TFLOPs": 78.6,
+                        "mfma_busy_frac": gram_busy, "mfma_busy_source": "profiles/pmc_traffic.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs))" if gram_busy is not None else None},
             "rows_dual_per_step": st["rows_dual"] / args.steps,
             "eigen_host_ms_per_step": st["eigen_host_ms"] / args.steps,
             "half_iteration_kernel_ms": halves,

@@ -30,9 +30,12 @@ def main():
         out[name] = {c: tot[name][c] / max(len(disp[name][c]), 1) for c in tot[name]}
         out[name]["dispatches"] = max(len(v) for v in disp[name].values())
     json.dump(out, open(prefix + "_pmc_per_dispatch.json", "w"), indent=1)
-    rows = [n for n in out if "als_persistent_kernel" in n and ", 0, " in n]
+    rows = [n for n in out if "als_persistent_kernel_h" in n and ", 0, " in n] or \
+           [n for n in out if "als_persistent_kernel" in n and ", 0, " in n]
+    rows = sorted(rows, key=lambda n: -out[n].get("GRBM_GUI_ACTIVE", 0.0))[:1]   # the variant that did the work (its fp32 twin returns at once)
     assert len(rows) == 1, rows
     r = out[rows[0]]
+    gram = [n for n in out if "gramian_partial_kernel" in n]
     read_fetch = 2.0 * 1024.0 * r["FETCH_SIZE"]            # KiB, x2: MI355X_MICROARCH.md (gfx950 reports half)
     read_rdreq = 128.0 * r["TCC_EA0_RDREQ_128B"] + 64.0 * r["TCC_EA0_RDREQ_64B"]
     write = 1024.0 * r["WRITE_SIZE"]
@@ -48,6 +51,10 @@ def main():
         # SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs: 1024 SIMDs x (GRBM/8) cycles
         "matrix_pipe_busy_fraction": r["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * r["GRBM_GUI_ACTIVE"] / 8.0),
         "wave_cycles_split": {kk: r[kk] / r["SQ_WAVE_CYCLES"] for kk in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")},
+        # K1 (M^T M on the fp64 matrix cores): busy fraction of the matrix pipe over its launches (north_star:
+        # "MFMA utilisation on the Gramian")
+        "gramian_mfma_busy_fraction": (out[gram[0]]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * out[gram[0]]["GRBM_GUI_ACTIVE"] / 8.0)) if gram else None,
+        "gramian_kernel": gram[0] if gram else None,
     }
     json.dump(traffic, open(os.path.join(os.path.dirname(prefix), "pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
