@@ -78,6 +78,48 @@ def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, budget_rows=(10000
             "sample": "; ".join(sample_desc) + "; per-side times extrapolated by row count; Gramian single-threaded as in the reference"}
 
 
+def jvm_baseline(torch, prob, n_users, n_items, k, sample_users=20000):
+    """Opportunistic "reference JVM path" (BASELINE.md section 4): only when java, javac and the reference's
+    jars (env MYRRIX_CP) exist on this host -- never in the build image.  Times the real
+    AlternatingLeastSquares through java/bench/ReferenceAlsTimer.java (ours) on the rows of a user sample
+    restricted to the items they touch.  Returns None when the toolchain is absent."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    cp = os.environ.get("MYRRIX_CP")
+    if not cp or not shutil.which("java") or not shutil.which("javac"):
+        return None
+    import numpy as np
+    rp, col, val = prob["r_csr"]
+    users = np.sort(np.random.default_rng(99).choice(n_users, size=min(sample_users, n_users), replace=False))
+    rp_h = rp.cpu().numpy()
+    tmp = tempfile.mkdtemp(prefix="mals_jvm_")
+    path = os.path.join(tmp, "entries.bin")
+    n = 0
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", 0))
+        for u in users:
+            a, b = int(rp_h[u]), int(rp_h[u + 1])
+            cs, vs = col[a:b].cpu().numpy(), val[a:b].cpu().numpy()
+            for c, v in zip(cs, vs):
+                f.write(struct.pack("<qqf", int(u), int(c), float(v)))
+            n += b - a
+        f.seek(0)
+        f.write(struct.pack("<i", n))
+    src = os.path.join(ROOT, "java", "bench", "ReferenceAlsTimer.java")
+    try:
+        subprocess.check_call(["javac", "-cp", cp, "-d", tmp, src])
+        out = subprocess.check_output(["java", "-cp", cp + os.pathsep + tmp, "bench.ReferenceAlsTimer", path, str(k), "2"],
+                                      text=True, timeout=600)
+    except (subprocess.SubprocessError, OSError) as e:
+        return {"error": str(e)[:200]}
+    line = [ln for ln in out.splitlines() if ln.startswith("rows_per_s=")][-1]
+    fields = dict(t.split("=") for t in line.split())
+    return {"value": float(fields["rows_per_s"]), "unit": "rows/s", "cores": int(fields["threads"]), "kind": "reference",
+            "sample": "the real net.myrrix AlternatingLeastSquares on %d sampled users x the items they touch (%d entries), JVM on this host" % (len(users), n)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,6 +371,9 @@ def main():
             X = als.factors(pkg.SIDE_X)
             Y = als.factors(pkg.SIDE_Y)
             out["cpu_baseline"] = cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k)
+            jvm = jvm_baseline(torch, prob, n_users, n_items, k)
+            if jvm is not None:
+                out["cpu_baseline_reference_jvm"] = jvm
         # the JSON line must be the last thing on stdout: RCCL's banner sits in the C stdio buffer of
         # this process until exit, so flush that first
         try:
