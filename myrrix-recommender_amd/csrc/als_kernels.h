@@ -621,21 +621,33 @@ __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, 
     const float* ptr = p.M + ((uint64_t)(uint32_t)col[i] * (uint32_t)p.k + (uint32_t)c);
 #pragma unroll
     for (int v = 0; v < T - 1; ++v) raw[v][e] = ptr[16 * v];
-    if (FULL || 16 * (T - 1) + c < p.k) raw[T - 1][e] = ptr[16 * (T - 1)];
+    if constexpr (FULL) {
+      raw[T - 1][e] = ptr[16 * (T - 1)];
+    } else {
+      // partial last block: no predicated load (the exec-mask juggling cost 36 VGPRs of spills at k = 50): the
+      // lanes past k read the row's LAST valid feature instead and convert_pair_h zeroes them with a 0/1 lane mask
+      const int last = p.k - 1 - 16 * (T - 1);   // index of the last valid lane of the block, 0..14
+      raw[T - 1][e] = ptr[16 * (T - 1) + ((c > last ? last : c) - c)];
+    }
   }
 }
 
 // raw rows of one entry pair -> scaled, split f16 operands; RHS partial sums (fp32, raw rows)
-template <int T, int E, int PART, int E2>
-__device__ __forceinline__ void convert_pair_h(const Chunk& ch, int lane, const float (&raw)[T][E], ZOp<E> (&zh)[T], ZOp<E> (&zl)[T],
-                                               float (&bpart)[T]) {
+template <int T, int E, bool FULL, int PART, int E2>
+__device__ __forceinline__ void convert_pair_h(const SolveParams& p, const Chunk& ch, int lane, const float (&raw)[T][E], ZOp<E> (&zh)[T],
+                                               ZOp<E> (&zl)[T], float (&bpart)[T]) {
   const int gb = (lane >> 4) << 2;
+  const float last_mask = (FULL || 16 * (T - 1) + (lane & 15) < p.k) ? 1.f : 0.f;   // partial last block: see issue_pair_h
   constexpr int o0 = 16 * E * PART + 32 * E2, o1 = o0 + 16;
   float s0, s1, c0, c1;
   bperm2x2<o0, o1>(gb, ch.w, ch.cb, s0, s1, c0, c1);
 #pragma unroll
   for (int v = 0; v < T; ++v) {
-    const float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
+    float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
+    if (!FULL && v == T - 1) {
+      y0 *= last_mask;
+      y1 *= last_mask;
+    }
     const float z0 = y0 * s0, z1 = y1 * s1;
     // zh = the top 11 significand bits (round toward zero straight into f16), zl = what is left: written
     // as an FMA on the widened half so that hipcc emits one v_fma_mix_f32 per value (and folds the
@@ -657,20 +669,20 @@ template <int T, int E, bool FULL, int PART>
 __device__ __forceinline__ void convert_refill_h(const SolveParams& p, const Chunk& ch, int next_col, int next_off, int lane,
                                                  float (&raw)[T][E], ZOp<E> (&zh)[T], ZOp<E> (&zl)[T], float (&bpart)[T]) {
 #define MALS_SB __builtin_amdgcn_sched_barrier(0)
-  convert_pair_h<T, E, PART, 0>(ch, lane, raw, zh, zl, bpart);
+  convert_pair_h<T, E, FULL, PART, 0>(p, ch, lane, raw, zh, zl, bpart);
   MALS_SB;
   issue_pair_h<T, E, FULL, 0>(p, next_col, next_off, lane, raw);
   MALS_SB;
-  convert_pair_h<T, E, PART, 1>(ch, lane, raw, zh, zl, bpart);
+  convert_pair_h<T, E, FULL, PART, 1>(p, ch, lane, raw, zh, zl, bpart);
   MALS_SB;
   issue_pair_h<T, E, FULL, 1>(p, next_col, next_off, lane, raw);
   if constexpr (E == 8) {
     MALS_SB;
-    convert_pair_h<T, E, PART, 2>(ch, lane, raw, zh, zl, bpart);
+    convert_pair_h<T, E, FULL, PART, 2>(p, ch, lane, raw, zh, zl, bpart);
     MALS_SB;
     issue_pair_h<T, E, FULL, 2>(p, next_col, next_off, lane, raw);
     MALS_SB;
-    convert_pair_h<T, E, PART, 3>(ch, lane, raw, zh, zl, bpart);
+    convert_pair_h<T, E, FULL, PART, 3>(p, ch, lane, raw, zh, zl, bpart);
     MALS_SB;
     issue_pair_h<T, E, FULL, 3>(p, next_col, next_off, lane, raw);
   }

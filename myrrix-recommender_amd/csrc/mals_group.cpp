@@ -9,7 +9,8 @@
 //
 // RCCL is resolved with dlopen at group creation (no link-time dependency for single-GPU users; inside
 // a process that already loaded PyTorch's copy the same library is reused).  Collectives of several
-// local members are always enclosed in ncclGroupStart/End (one thread drives all devices).
+// local members are always enclosed in ncclGroupStart/End (one thread drives all devices), and every RCCL call
+// of a rank is issued on that rank's comm stream -- a communicator is never used from two streams at once.
 #include "../../include/myrrix_als.h"
 
 #include <dlfcn.h>
@@ -210,15 +211,20 @@ int allreduce_stat(mals_group g, int n, int op) {
     }
     return MALS_OK;
   }
+  // every RCCL call of a rank goes to ITS comm stream: one communicator is never used from two streams at once
   GNCCL(g, g_rccl.GroupStart());
   for (Member& mb : g->m) {
-    const ncclResult_t r = g_rccl.AllReduce(mb.d_stat, mb.d_stat, (size_t)n, ncclDouble, op ? ncclMax : ncclSum, mb.nccl, mb.compute);
+    const ncclResult_t r = g_rccl.AllReduce(mb.d_stat, mb.d_stat, (size_t)n, ncclDouble, op ? ncclMax : ncclSum, mb.nccl, mb.comm);
     if (r != ncclSuccess) {
       (void)g_rccl.GroupEnd();
       return gfail(g, MALS_COMM_ERROR, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
     }
   }
   GNCCL(g, g_rccl.GroupEnd());
+  for (Member& mb : g->m) {
+    GHIP(g, hipSetDevice(mb.device));
+    GHIP(g, hipStreamSynchronize(mb.comm));
+  }
   return MALS_OK;
 }
 
@@ -364,15 +370,26 @@ int group_gramian(mals_group g, int side) {
         GHIP(g, hipStreamSynchronize(mb.compute));
       }
     } else {
+      // partial Gramian (compute stream) -> all-reduce (comm stream, behind whatever exchange is still on it) -> compute
+      for (Member& mb : g->m) {
+        GHIP(g, hipSetDevice(mb.device));
+        GHIP(g, hipEventRecord(mb.ev_solved, mb.compute));
+        GHIP(g, hipStreamWaitEvent(mb.comm, mb.ev_solved, 0));
+      }
       GNCCL(g, g_rccl.GroupStart());
       for (Member& mb : g->m) {
-        const ncclResult_t r = g_rccl.AllReduce(mb.d_gp, mb.d_gp, kk, ncclDouble, ncclSum, mb.nccl, mb.compute);
+        const ncclResult_t r = g_rccl.AllReduce(mb.d_gp, mb.d_gp, kk, ncclDouble, ncclSum, mb.nccl, mb.comm);
         if (r != ncclSuccess) {
           (void)g_rccl.GroupEnd();
           return gfail(g, MALS_COMM_ERROR, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
         }
       }
       GNCCL(g, g_rccl.GroupEnd());
+      for (Member& mb : g->m) {
+        GHIP(g, hipSetDevice(mb.device));
+        GHIP(g, hipEventRecord(mb.ev_exchanged, mb.comm));
+        GHIP(g, hipStreamWaitEvent(mb.compute, mb.ev_exchanged, 0));
+      }
     }
   }
   for (Member& mb : g->m) {
