@@ -1597,7 +1597,11 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   }
   // dual path (dual_kernels.h): the reference's default mode only; the Gramian goes to the host first so
   // that its eigendecomposition runs while the direct kernels of the first chunk execute
-  const bool want_dual = s.n_dual_rows > 0 && h->cfg.flags == 0 && h->cfg.alpha > 0.0 && o.G_valid;
+  // ... and only when it pays: the rotation of the gathered matrix costs ~1/30 of what a dual row saves
+  // (measured, k = 64 and 128), so a side with few short rows against a huge opposite matrix (the item half of
+  // C5: 1.25M long rows per rank gathering from 100M users) stays on the direct kernels
+  const bool dual_pays = h->cfg.solve_mode == MALS_SOLVE_DUAL || s.n_dual_rows * 32 >= o.n_total;
+  const bool want_dual = s.n_dual_rows > 0 && dual_pays && h->cfg.flags == 0 && h->cfg.alpha > 0.0 && o.G_valid;
   const bool dual_stale = want_dual && (h->dual_side != side || h->dual_version != o.G_version);
   if (dual_stale) {
     if (!h->h_G) HIPCHK(h, hipHostMalloc(&h->h_G, sizeof(double) * (size_t)k * k));
