@@ -1193,7 +1193,22 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
 // 64 (tile, reg, lane) elements per workgroup: each of the 4 waves sums a contiguous quarter of the
 // wave partials in order (coalesced 512-byte reads), the quarters are then added in order -- a fixed
 // summation tree, so the result is deterministic.
-template <int T>
+// first stage for the many slab partials of gramian_split_kernel: group q of `groups` sums its share of the slabs
+// (fixed order) into one set of doubles, element by element, coalesced -- thousands of workgroups instead of the 144 of
+// the finalize kernel
+__global__ __launch_bounds__(256) void gramian_reduce_slabs_kernel(const float* __restrict__ partial, int64_t n_slabs, int elems,
+                                                                   int groups, double* __restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int q = blockIdx.y;
+  if (e >= elems) return;
+  const int64_t per = (n_slabs + groups - 1) / groups;
+  const int64_t w0 = q * per, w1 = (q + 1) * per < n_slabs ? (q + 1) * per : n_slabs;
+  double acc = 0.0;
+  for (int64_t w = w0; w < w1; ++w) acc += (double)partial[w * (int64_t)elems + e];
+  out[(int64_t)q * elems + e] = acc;
+}
+
+template <int T, bool F64_LAYOUT>
 __global__ __launch_bounds__(256) void gramian_finalize_kernel(const double* __restrict__ partial, int64_t n_waves, int k,
                                                                double* __restrict__ G, float* __restrict__ Gf) {
   __shared__ double part[4][64];
@@ -1214,8 +1229,13 @@ __global__ __launch_bounds__(256) void gramian_finalize_kernel(const double* __r
     ++i;
   }
   const int j = i + rem;
-  const int row = 16 * i + (lane >> 4) + 4 * reg;  // f64 C/D layout
+  // C/D layout of the partials: f64 instruction: row (lane>>4) + 4 reg; f32-accumulating instructions: row 4 (lane>>4) + reg
+  const int row = F64_LAYOUT ? 16 * i + (lane >> 4) + 4 * reg : 16 * i + 4 * (lane >> 4) + reg;
   const int col = 16 * j + (lane & 15);
+  // A diagonal tile holds both (a,b) and (b,a).  The fp64 instruction computes them bit-identically; with split
+  // operands the three partial products reach the two in a different order (an ulp apart): only the upper element
+  // writes, to both places -- no two threads ever store different values to one address.
+  if (i == j && row > col) return;
   if (G && row < k && col < k) {
     G[(int64_t)row * k + col] = s;
     G[(int64_t)col * k + row] = s;
@@ -1228,6 +1248,111 @@ __global__ __launch_bounds__(256) void gramian_finalize_kernel(const double* __r
     Gf[(t * 64 + 16 * (lr >> 2) + lc) * 4 + (lr & 3)] = f;
     if (i == j) Gf[(t * 64 + 16 * (lc >> 2) + lr) * 4 + (lc & 3)] = f;
   }
+}
+
+// K1 for LARGE matrices on the f16 matrix pipe.  The fp64 instruction above costs 64 cycles per 16x16x4 block and
+// is 8 % of a k = 128 iteration; v_mfma_f32_16x16x16_f16 on operands split into two f16 halves (hi = round toward
+// zero, lo = round to nearest of the exact residual: 22 significand bits, unbiased, every product exact) does a
+// 16x16x16 block in 3 x 16 cycles.  What fp64 bought -- no rounding in the sum -- is kept where it matters: a wave
+// accumulates in fp32 only over its slab of rows_per_slab rows (512: 32 steps), the slab partials are summed in fp64
+// in a fixed order by gramian_finalize_kernel.  Per slab the fp32 sum carries <= 6e-8 x sqrt(32) relative (random);
+// over the hundreds of slabs this kernel is used for that averages far below the reference's own product rounding
+// (MU:232 rounds every product to fp32), and stays at 3e-7 even when a handful of rows dominate G.  Small matrices keep the fp64 kernel (launch_gramian).
+// Operand scale: a power of two per wave, lowered (with an exact rescale of the accumulators) whenever a 16-row
+// step brings a larger |value| than any before it -- no bound is needed from outside and an outlier row costs
+// the rows after it a few low bits relative to sums it already dominates.
+// Layout: lane (g,c) holds, for rows r0 + 4g + s (s = 0..3) and every 16-block v, feature 16v + c -- the A and the B
+// operand of the instruction at once (contraction over the 16 rows of the step).
+template <int T>
+__global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __restrict__ M, int64_t n_rows, int k,
+                                                               int64_t rows_per_slab, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  const int64_t slab = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t r0 = slab * rows_per_slab;
+  int64_t r1 = r0 + rows_per_slab;
+  if (r1 > n_rows) r1 = n_rows;
+  f32x4 acc[tri(T)];
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int pw = 100;  // current scale 2^pw: max |z| <= 2^14
+  for (int64_t r = r0; r < r1; r += 16) {
+    // all 4T loads of the step first, no arithmetic on them in between (a use right behind each load makes the
+    // compiler wait for every one in turn: 13 us per step instead of one memory latency)
+    float raw[T][4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int64_t row = r + 4 * g + s4;
+      const float* p = M + (row < r1 ? row : r0) * k;
+#pragma unroll
+      for (int v = 0; v < T; ++v) {
+        const int f = 16 * v + c;
+        raw[v][s4] = p[f < k ? f : k - 1];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float amax = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const bool ok = r + 4 * g + s4 < r1;
+#pragma unroll
+      for (int v = 0; v < T; ++v) {
+        if (!(ok && 16 * v + c < k)) raw[v][s4] = 0.f;
+        amax = fmaxf(amax, fabsf(raw[v][s4]));
+      }
+    }
+    int m = __float_as_int(amax);  // non-negative floats order like their bit patterns
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    m = uniform(m);
+    if (m != 0) {
+      const int eb = ((m >> 23) & 255) - 126;  // step max < 2^eb
+      const int want = 14 - eb;
+      if (want < pw) {  // a larger value than any before: lower the scale, bring the sums along (exact)
+        if (pw != 100) {
+          int d2 = 2 * (want - pw);
+          d2 = d2 < -120 ? -120 : d2;
+          const float f = __int_as_float((d2 + 127) << 23);
+#pragma unroll
+          for (int t = 0; t < tri(T); ++t) acc[t] *= f;
+        }
+        pw = want;
+      }
+    }
+    const int pwc = pw == 100 ? 0 : (pw < -100 ? -100 : (pw > 100 ? 100 : pw));
+    const float sc = __int_as_float((pwc + 127) << 23);
+    ZOp<4> zh[T], zl[T];
+#pragma unroll
+    for (int v = 0; v < T; ++v) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const float z0 = raw[v][0] * sc, z1 = raw[v][1] * sc, z2 = raw[v][2] * sc, z3 = raw[v][3] * sc;
+      const int h01 = pk_rtz(z0, z1), h23 = pk_rtz(z2, z3);
+      const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
+      const f32x2 r01 = {z0 - (float)a[0], z1 - (float)a[1]}, r23 = {z2 - (float)b[0], z3 - (float)b[1]};
+      zh[v].r[0] = h01;
+      zh[v].r[1] = h23;
+      zl[v].r[0] = __builtin_bit_cast(int, __builtin_convertvector(r01, f16x2));  // v_cvt_pk_f16_f32: round to nearest
+      zl[v].r[1] = __builtin_bit_cast(int, __builtin_convertvector(r23, f16x2));
+    }
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<4>(zh[i], zh[j], acc[tidx(T, i, j)]);
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<4>(zh[i], zl[j], acc[tidx(T, i, j)]);
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<4>(zl[i], zh[j], acc[tidx(T, i, j)]);
+  }
+  int d2 = pw == 100 ? 0 : -2 * pw;
+  d2 = d2 < -126 ? -126 : (d2 > 126 ? 126 : d2);
+  const float back = __int_as_float((d2 + 127) << 23);
+  float* o = partial + slab * (int64_t)(tri(T) * 4 * 64) + lane;
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[(t * 4 + r) * 64] = acc[t][r] * back;
 }
 
 // G (k x k fp64 row-major) -> fp32 acc-layout image used by K2 (see gramian_finalize_kernel)

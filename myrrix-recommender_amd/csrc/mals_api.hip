@@ -79,8 +79,8 @@ struct SideState {
   // Gramian of THIS side's factors (consumed when solving the other side)
   double* G = nullptr;
   float* Gf = nullptr;
-  double* partials = nullptr;
-  int64_t partial_waves = 0;
+  double* partials = nullptr;   // wave / slab partials of K1 (doubles, or floats for the split kernel)
+  size_t partial_bytes = 0;
   bool G_valid = false;
   uint64_t G_version = 0;  // bumped whenever G changes (cached operand scale of the split-precision gather)
 };
@@ -417,23 +417,56 @@ int drain_events(mals_handle h) {
 }
 
 // ---- kernel dispatch ---------------------------------------------------------------------------
+// fp64 kernel below this many rows, split-f16 kernel (slabs of 512 rows = 32 accumulation steps, fp64 sum over the
+// slabs) from there on: even when a few rows dominate G (no averaging over slabs) the fp32 slab sums stay within
+// 6e-8 x sqrt(32) of it (als_kernels.h, gramian_split_kernel)
+constexpr int64_t GRAMIAN_SPLIT_MIN_ROWS = 262144;
+constexpr int64_t GRAMIAN_SLAB_ROWS = 512;
+
 template <int T>
 int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows, double* G_out, float* Gf_out) {
   const int k = h->cfg.features;
+  const int elems = tri(T) * 256;
+  static const bool force_f64 = std::getenv("MALS_GRAMIAN_F64") != nullptr;  // A/B
+  if (n_rows >= GRAMIAN_SPLIT_MIN_ROWS && !force_f64) {
+    int64_t n_slabs = (n_rows + GRAMIAN_SLAB_ROWS - 1) / GRAMIAN_SLAB_ROWS;
+    n_slabs = (n_slabs + 3) & ~(int64_t)3;  // whole workgroups
+    constexpr int GROUPS = 64;              // first-stage sums (doubles) behind the slab partials (floats)
+    const size_t slab_bytes = sizeof(float) * (size_t)n_slabs * tri(T) * 256;
+    const size_t bytes = slab_bytes + sizeof(double) * (size_t)GROUPS * tri(T) * 256;
+    if (s.partial_bytes < bytes) {
+      free_dev(s.partials);
+      s.partial_bytes = 0;
+      void* pbuf = nullptr;
+      HIPCHK(h, hipMalloc(&pbuf, bytes));
+      s.partials = static_cast<double*>(pbuf);
+      s.partial_bytes = bytes;
+    }
+    float* pf = reinterpret_cast<float*>(s.partials);
+    double* pd = reinterpret_cast<double*>(reinterpret_cast<char*>(s.partials) + slab_bytes);  // slab_bytes is a multiple of 1024
+    hipLaunchKernelGGL((gramian_split_kernel<T>), dim3((unsigned)(n_slabs / 4)), dim3(256), 0, h->stream, M, n_rows, k,
+                       GRAMIAN_SLAB_ROWS, pf);
+    hipLaunchKernelGGL(gramian_reduce_slabs_kernel, dim3((unsigned)((elems + 255) / 256), GROUPS), dim3(256), 0, h->stream, pf, n_slabs,
+                       elems, GROUPS, pd);
+    hipLaunchKernelGGL((gramian_finalize_kernel<T, false>), dim3(elems / 64), dim3(256), 0, h->stream, pd, (int64_t)GROUPS, k, G_out, Gf_out);
+    HIPCHK(h, hipGetLastError());
+    return MALS_OK;
+  }
   // waves: at least 64 rows each, at most 2048 waves
   int64_t n_waves = std::min<int64_t>(2048, std::max<int64_t>(1, (n_rows + 255) / 256));
   n_waves = (n_waves + 3) & ~(int64_t)3;
   int64_t rows_per_wave = (n_rows + n_waves - 1) / n_waves;
   rows_per_wave = std::max<int64_t>(4, (rows_per_wave + 3) & ~(int64_t)3);
-  if (s.partial_waves < n_waves) {
+  const size_t bytes = sizeof(double) * (size_t)n_waves * tri(T) * 256;
+  if (s.partial_bytes < bytes) {
     free_dev(s.partials);
-    HIPCHK(h, hipMalloc(&s.partials, sizeof(double) * (size_t)n_waves * tri(T) * 256));
-    s.partial_waves = n_waves;
+    s.partial_bytes = 0;
+    HIPCHK(h, hipMalloc(&s.partials, bytes));
+    s.partial_bytes = bytes;
   }
   hipLaunchKernelGGL((gramian_partial_kernel<T>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, h->stream, M, n_rows, k,
                      rows_per_wave, s.partials);
-  const int elems = tri(T) * 256;
-  hipLaunchKernelGGL((gramian_finalize_kernel<T>), dim3(elems / 64), dim3(256), 0, h->stream, s.partials, n_waves,
+  hipLaunchKernelGGL((gramian_finalize_kernel<T, true>), dim3(elems / 64), dim3(256), 0, h->stream, s.partials, n_waves,
                      k, G_out, Gf_out);
   HIPCHK(h, hipGetLastError());
   return MALS_OK;

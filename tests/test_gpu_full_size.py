@@ -97,7 +97,9 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
         for i in range(3):
             core.gramian_partial(pkg.SIDE_X, cuts[i], cuts[i + 1] - cuts[i], parts[i])
         torch.cuda.synchronize()
-        assert rel(parts.sum(0).cpu().numpy(), Gx) < 1e-12
+        # below 262144 rows every piece runs the fp64 kernel (exact products, fp64 sums): 1e-12; above, the whole
+        # matrix runs the split-f16 kernel (fp32 sums inside 2048-row slabs, fp64 across): <= 2e-7
+        assert rel(parts.sum(0).cpu().numpy(), Gx) < (1e-12 if n_users < 262144 else 2e-7)
         n_slice = min(n_users, 200_000)
         Xs = core.get_factors(pkg.SIDE_X, 0, n_slice)
         gs = torch.zeros(k, k, dtype=torch.float64, device=dev)

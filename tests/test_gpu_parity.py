@@ -89,6 +89,30 @@ def test_gramian_known_answer_and_vs_oracle():
         assert np.allclose(G, G.T)
 
 
+@pytest.mark.parametrize("k", [30, 50, 64, 100, 128])
+def test_large_gramian_on_the_f16_pipe_matches_oracle(k):
+    """From 262144 rows on, M^T M runs on v_mfma_f32_16x16x16_f16 with split operands, fp32 sums inside 2048-row
+    slabs and fp64 sums across them: same bar as the fp64 kernel (5e-7 vs the oracle, whose products are rounded
+    to fp32 like MU:232), also with rows of very different magnitudes in one slab."""
+    rng = np.random.default_rng(k)
+    n = 300_001
+    M = rng.standard_normal((n, k)).astype(np.float32)
+    M *= np.exp(rng.standard_normal(n) * 2.0).astype(np.float32)[:, None]     # row norms over ~4 decades
+    M[12345] *= 1.0e3
+    M[200_000:200_016] = 0.0
+    with pkg.ALSCore(k) as core:
+        core.set_factor_rows(pkg.SIDE_X, n)
+        core.set_factors(pkg.SIDE_X, M)
+        G = core.gramian(pkg.SIDE_X, fetch=True)
+        G2 = core.gramian(pkg.SIDE_X, fetch=True)
+    Go = oracle.gramian(M)
+    assert np.array_equal(G, G2)                 # deterministic
+    assert np.allclose(G, G.T, rtol=0, atol=0)
+    assert rel(G, Go) < 5e-7, (k, rel(G, Go))
+    Ge = M.astype(np.float64).T @ M.astype(np.float64)
+    assert rel(G, Ge) < 5e-7, (k, rel(G, Ge))   # against exact arithmetic (a handful of rows dominate G here: no averaging over slabs)
+
+
 # ---- seeded synthetic problems: one half-iteration and full iterations vs the oracle -------------
 @pytest.mark.parametrize("k", [1, 2, 10, 16, 30, 33, 50, 64, 100, 128])
 def test_half_iterations_match_oracle(k):

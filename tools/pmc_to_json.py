@@ -35,7 +35,8 @@ def main():
     rows = sorted(rows, key=lambda n: -out[n].get("GRBM_GUI_ACTIVE", 0.0))[:1]   # the variant that did the work (its fp32 twin returns at once)
     assert len(rows) == 1, rows
     r = out[rows[0]]
-    gram = [n for n in out if "gramian_partial_kernel" in n]
+    gram = sorted([n for n in out if "gramian_partial_kernel" in n or "gramian_split_kernel" in n],
+                  key=lambda n: -out[n].get("GRBM_GUI_ACTIVE", 0.0) * out[n].get("dispatches", 1))
     read_fetch = 2.0 * 1024.0 * r["FETCH_SIZE"]            # KiB, x2: MI355X_MICROARCH.md (gfx950 reports half)
     read_rdreq = 128.0 * r["TCC_EA0_RDREQ_128B"] + 64.0 * r["TCC_EA0_RDREQ_64B"]
     write = 1024.0 * r["WRITE_SIZE"]
