@@ -63,7 +63,9 @@ struct RotateParams {
   int32_t src_stride, dst_stride, dst_cols;
 };
 
-__host__ __device__ constexpr int dual_max_blocks(int T) { return T / 2; }
+// largest row class of the dual path for T feature blocks: the n_u x n_u system must be clearly smaller than the
+// k x k one and its operands must fit the registers next to it (T = 8: TN = 5 spills 268 B and loses, measured)
+__host__ __device__ constexpr int dual_max_blocks(int T) { return T >= 8 ? 4 : (T >= 6 ? 4 : (T >= 4 ? 3 : T / 2)); }
 __host__ __device__ constexpr int dual_waves(int T, int TN) {
   const int regs = 4 * T * TN + 4 * tri(TN) + 72;
   return regs > 168 ? 2 : (regs > 128 ? 3 : (regs > 102 ? 4 : 5));

@@ -707,10 +707,10 @@ int launch_dual_TN(mals_handle h, DualParams dp) {
 }
 template <int T>
 int launch_dual_T(mals_handle h, const DualParams& dp, int tn) {
-  if constexpr (T >= 2) { if (tn == 1) return launch_dual_TN<T, 1>(h, dp); }
-  if constexpr (T >= 4) { if (tn == 2) return launch_dual_TN<T, 2>(h, dp); }
-  if constexpr (T >= 6) { if (tn == 3) return launch_dual_TN<T, 3>(h, dp); }
-  if constexpr (T >= 8) { if (tn == 4) return launch_dual_TN<T, 4>(h, dp); }
+  if constexpr (dual_max_blocks(T) >= 1) { if (tn == 1) return launch_dual_TN<T, 1>(h, dp); }
+  if constexpr (dual_max_blocks(T) >= 2) { if (tn == 2) return launch_dual_TN<T, 2>(h, dp); }
+  if constexpr (dual_max_blocks(T) >= 3) { if (tn == 3) return launch_dual_TN<T, 3>(h, dp); }
+  if constexpr (dual_max_blocks(T) >= 4) { if (tn == 4) return launch_dual_TN<T, 4>(h, dp); }
   return fail(h, MALS_INVALID_ARG, "no dual kernel for this row class");
 }
 int launch_dual(mals_handle h, const DualParams& dp, int tn) {

@@ -21,6 +21,12 @@ def rel(a, b):
                  max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
+def dual_max_len(k):
+    """Largest row the dual path takes at k features: 16 * dual_max_blocks(T) (csrc/dual_kernels.h)."""
+    T = (k + 15) // 16
+    return 16 * (4 if T >= 6 else (3 if T >= 4 else T // 2))
+
+
 def rows_problem(lengths, n_items, k, seed, negatives=0.1, vscale=1.0, unit=True):
     """CSR with the given row lengths (distinct random columns per row), values +-1..5, and M (n_items x k)."""
     rng = np.random.default_rng(seed)
@@ -49,8 +55,7 @@ def solve_x(k, csr, M, **kw):
 
 @pytest.mark.parametrize("k", [33, 48, 50, 64, 80, 96, 100, 112, 127, 128])
 def test_every_row_length_matches_oracle(k):
-    T = (k + 15) // 16
-    nmax = 16 * (T // 2)
+    nmax = dual_max_len(k)
     # every length 0 .. nmax + 8 (the lengths above nmax and the empty rows take the direct kernel), three of each
     lengths = np.repeat(np.arange(0, nmax + 9), 3)
     np.random.default_rng(k).shuffle(lengths)
@@ -74,7 +79,7 @@ def test_every_row_length_matches_oracle(k):
                                               (1.0, 0.1, 1000.0), (1.0, 0.1, 0.001), (0.01, 10.0, 1.0)])
 @pytest.mark.parametrize("k", [64, 128])
 def test_alpha_lambda_and_value_scales(k, alpha, lam, vscale):
-    lengths = np.random.default_rng(5).integers(1, 16 * (k // 32) + 1, size=400)
+    lengths = np.random.default_rng(5).integers(1, dual_max_len(k) + 1, size=400)
     csr, M = rows_problem(lengths, 3000, k, seed=int(alpha * 10 + k), negatives=0.2, vscale=vscale)
     X, st = solve_x(k, csr, M, alpha=alpha, lam=lam)
     Xo = oracle.half_iteration(*csr, M, alpha=alpha, lam=lam, threads=4)
@@ -85,7 +90,7 @@ def test_alpha_lambda_and_value_scales(k, alpha, lam, vscale):
 @pytest.mark.parametrize("k", [64, 128])
 def test_ill_conditioned_gramian(k):
     """Feature scales over six decades (cond(G) ~ 1e12): the rotation is then essential, not cosmetic."""
-    lengths = np.random.default_rng(6).integers(1, 16 * (k // 32) + 1, size=300)
+    lengths = np.random.default_rng(6).integers(1, dual_max_len(k) + 1, size=300)
     csr, M = rows_problem(lengths, 4000, k, seed=11, unit=False)
     M = (M * np.logspace(0, -3, k)[None, :]).astype(np.float32)
     X, st = solve_x(k, csr, M)

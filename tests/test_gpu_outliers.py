@@ -11,14 +11,14 @@ import pytest
 import myrrix_recommender_amd as pkg  # noqa: F401
 from myrrix_recommender_amd import _lib
 from oracle import oracle
-from tests.test_gpu_dual import rel, rows_problem, solve_x
+from tests.test_gpu_dual import dual_max_len, rel, rows_problem, solve_x
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-4
 
 
 def mixed_lengths(k, n_rows, seed):
-    nmax = 16 * (k // 32)
+    nmax = dual_max_len(k)
     rng = np.random.default_rng(seed)
     return np.concatenate([rng.integers(1, nmax + 1, size=n_rows // 2), rng.integers(nmax + 1, 400, size=n_rows - n_rows // 2)])
 
@@ -39,7 +39,7 @@ def test_one_value_x1e5(k):
     lengths = mixed_lengths(k, 2000, 2)
     csr, M = rows_problem(lengths, 3000, k, seed=22)
     v = csr[2].copy()
-    long_row = int(np.argmax(lengths > 16 * (k // 32)))       # a row the direct kernel solves
+    long_row = int(np.argmax(lengths > dual_max_len(k)))      # a row the direct kernel solves
     v[csr[0][long_row] + 3] = 5.0e5
     v[csr[0][0]] = 5.0e5                                       # and one the dual kernel solves
     csr = (csr[0], csr[1], v)
