@@ -250,6 +250,11 @@ int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iter
 int mals_sample_dots(mals_handle h, const int64_t* test_users, int32_t n_test_users, const int64_t* test_items,
                      int32_t n_test_items, double* host_out);
 
+/* The host eigensolver of the dual path (csrc/host_eigen.h; no GPU needed): A = V diag(evals) V^T for a symmetric
+ * row-major n x n matrix (Householder tridiagonalisation + implicit QR; evals in no particular order, column j of
+ * the row-major V is the unit eigenvector of evals[j]).  MALS_INVALID_ARG for a non-finite input or no convergence. */
+int mals_symmetric_eigen(const double* A, int32_t n, double* evals_out, double* V_out);
+
 /* Cooperative cancellation (InterruptedException path, MatrixFactorizer.java:43-44): checked
  * between half-iterations of mals_factorize. */
 int mals_cancel(mals_handle h);

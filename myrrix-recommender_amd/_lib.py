@@ -103,6 +103,7 @@ SYMBOLS = {
     "mals_factorize": (ctypes.c_int, [_H, ctypes.c_double, _I32, _I32, _I32, _P, _I32, _P, _I32,
                                       ctypes.POINTER(_I32), ctypes.POINTER(ctypes.c_double)]),
     "mals_sample_dots": (ctypes.c_int, [_H, _P, _I32, _P, _I32, _P]),
+    "mals_symmetric_eigen": (ctypes.c_int, [_P, _I32, _P, _P]),
     "mals_cancel": (ctypes.c_int, [_H]),
     "mals_recompute_solver": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(_H), ctypes.POINTER(ctypes.c_double)]),
     "mals_solver_create": (ctypes.c_int, [_P, _I32, ctypes.c_double, ctypes.POINTER(_H), ctypes.POINTER(_I32)]),

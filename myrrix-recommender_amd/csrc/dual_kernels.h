@@ -13,7 +13,7 @@
 // -- the SAME x_u (not an approximation), from an n_u x n_u Cholesky instead of a k x k one.  For
 // n_u <= k/2 that is 8x fewer factorization flops and a 4x smaller per-row Gramian (Z Z^T contracts
 // over k, n_u^2 k / 2 products instead of n_u k^2 / 2).  Measured error against the fp64 oracle is on a
-// par with the direct path (tests/test_gpu_dual.py, tools/dual_numerics.py: 2-5e-7 relative, also
+// par with the direct path (tests/test_gpu_dual.py; the algorithm alone, numpy on the CPU: tests/dual_emulation.py; 2-5e-7 relative, also
 // with cond(G) = 1e6 and lambda = 0).
 //
 // Pieces (all launched by mals_api.hip on the handle's stream):

@@ -2060,6 +2060,11 @@ int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_
   return MALS_OK;
 }
 
+int mals_symmetric_eigen(const double* A, int32_t n, double* evals_out, double* V_out) {
+  if (!A || !evals_out || !V_out || n <= 0) return MALS_INVALID_ARG;
+  return mals::symmetric_eigen(A, n, evals_out, V_out) ? MALS_OK : MALS_INVALID_ARG;
+}
+
 int mals_cancel(mals_handle h) {
   if (!h) return MALS_INVALID_ARG;
   h->cancelled.store(1);
