@@ -53,7 +53,7 @@ def solve_x(k, csr, M, **kw):
         return core.get_factors(pkg.SIDE_X), core.stats()
 
 
-@pytest.mark.parametrize("k", [33, 48, 50, 64, 80, 96, 100, 112, 127, 128])
+@pytest.mark.parametrize("k", [20, 32, 33, 48, 50, 64, 80, 96, 100, 112, 127, 128])
 def test_every_row_length_matches_oracle(k):
     nmax = dual_max_len(k)
     # every length 0 .. nmax + 8 (the lengths above nmax and the empty rows take the direct kernel), three of each
