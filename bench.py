@@ -290,7 +290,7 @@ def main():
         # dominant kernel = the one with the most time in the timed region: the fused gather + Gramian +
         # Cholesky kernel over the direct rows (MODE 0; als_persistent_kernel_h is what AUTO selects above
         # k = 32) or the dual kernels of the short rows (als_dual_kernel<T,TN>, all row classes together)
-        split = args.gramian_mode == "split_f16" or (args.gramian_mode == "auto" and k > 32)
+        split = args.gramian_mode == "split_f16" or (args.gramian_mode == "auto" and k > 16)
         T_blocks = (k + 15) // 16
         dom = "dual" if st["dual_ms"] > st["rows_ms"] else "rows"
         if dom == "dual":

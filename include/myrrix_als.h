@@ -85,7 +85,7 @@ typedef struct mals_config {
                                    updates of the factorization use the same operands) -- 2.5x less
                                    matrix-pipe time, rounding error on a par with FP32 (measured
                                    2-4e-7 vs the fp64 reference for both);
-                                   MALS_GRAMIAN_AUTO (default): FP32 for features <= 32 (where the
+                                   MALS_GRAMIAN_AUTO (default): FP32 for features <= 16 (where the
                                    products are not the bottleneck), SPLIT_F16 above            */
   int32_t solve_mode;           /* how a row with FEWER ENTRIES THAN FEATURES is solved (ALS:447-494 is the
                                    same k x k system either way):

@@ -4,7 +4,7 @@
 //     v_mfma_f64_16x16x4_f64 (replaces MatrixUtils.transposeTimesSelf, MU:219-239).
 // K2  gather + per-row weighted Gramian + RHS, one 64-lane wave per row (replaces the inner loop of
 //     AlternatingLeastSquares.Worker.call, ALS:447-492): split-precision on v_mfma_f32_16x16x32_f16
-//     (gather_row_h, the default above k = 32) or fp32 on v_mfma_f32_16x16x4_f32 (gather_row).
+//     (gather_row_h, the default above k = 16) or fp32 on v_mfma_f32_16x16x4_f32 (gather_row).
 // K3  blocked Cholesky + triangular solves on the accumulator tiles, in registers, fused behind K2
 //     (replaces MatrixUtils.getSolver(Wu).solveDToF, ALS:494 -> CMLSS:37-55, CMS:37-44).
 //
