@@ -285,6 +285,7 @@ def main():
     planted_err = None
     if world == 1:
         planted_err = synth.planted_reconstruction_error(prob, als.factors(pkg.SIDE_X), als.factors(pkg.SIDE_Y))
+    out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         # dominant kernel = the one with the most time in the timed region: the fused gather + Gramian +
@@ -376,17 +377,27 @@ def main():
             jvm = jvm_baseline(torch, prob, n_users, n_items, k)
             if jvm is not None:
                 out["cpu_baseline_reference_jvm"] = jvm
-        # the JSON line must be the last thing on stdout: RCCL's banner sits in the C stdio buffer of
-        # this process until exit, so flush that first
+    # The JSON line must be the LAST thing on the job's stdout.  RCCL prints a banner through C stdio, which sits in
+    # every rank's buffer until that process exits -- i.e. after rank 0 has printed.  So: every rank flushes its C
+    # stdio, all ranks meet, rank 0 prints, all ranks meet again and leave without running exit handlers that could
+    # still write.
+    def flush_c_stdio():
         try:
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        sys.stdout.flush()
+
+    flush_c_stdio()
+    if world > 1 or force:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or force:
         dist.barrier()
-        dist.destroy_process_group()
+        flush_c_stdio()
+        os._exit(0)
 
 
 if __name__ == "__main__":

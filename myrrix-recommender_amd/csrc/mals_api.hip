@@ -534,6 +534,9 @@ int launch_persistent(mals_handle h, K kernel, KF fallback, const SolveParams& p
     SolveParams pf = p;
     pf.flags |= 8;
     if (int rc = persistent_grid(h, fallback, p.n_work, &grid)) return rc;
+    // the twin almost always returns at once: a resident-sized grid keeps that at a few microseconds (a full 16x
+    // oversubscribed grid of empty workgroups costs 15-30); when it does run it only loses the oversubscription
+    grid = std::min<unsigned>(grid, (unsigned)h->n_cu * 8u);
     hipLaunchKernelGGL(fallback, dim3(grid), dim3(256), 0, h->stream, pf);
   }
   return end_timed(h, pe);
