@@ -53,7 +53,9 @@ struct SolveParams {
   const int64_t* row_ptr;   // local CSR
   const int32_t* col;
   const float* val;
-  const float* M;           // opposing factor replica (row-major, stride k)
+  const float* M;           // gather table: the opposing factor replica (row-major, stride ldm = k) when k % 16 == 0,
+                            // else its zero-padded copy (stride ldm = 16 T, pad_rows_kernel): every row starts on a
+                            // 64-byte boundary and the last feature block loads like the others
   const float* Gf;          // fp32 image of G in acc layout: [upper tile][lane][reg]
   float* out;               // this side's factor replica + row_offset*k
   const WorkItem* items;    // list A or B (whichever this launch handles), sorted by length (desc)
@@ -62,6 +64,7 @@ struct SolveParams {
   unsigned long long* bad_row; // first (smallest) local row with a non-PD system
   int64_t n_work;           // waves of work in the list this launch handles
   int32_t k;
+  int32_t ldm;              // row stride of M in floats
   int32_t flags;            // bit0 reconstructR, bit1 lossIgnoresUnspecified, bit3 run only if zscale[2] == 0
   float alpha;
   float lambda_alpha;       // lambda*alpha
@@ -462,15 +465,15 @@ __device__ __forceinline__ void chunk_weights(const SolveParams& p, Chunk& e) {
 }
 
 // Gather one factor row: T dword loads, 16 lanes x 4 B = one 64-byte segment per lane group each.
-// No arithmetic may depend on the loaded values here (the loads must stay in flight), so the
-// partial last block (k % 16 != 0) is handled by not loading at all in the lanes past k: their ring
-// slot registers are zero-initialised once and never written.
-template <int T, bool FULL>
-__device__ __forceinline__ void load_rows(const float* __restrict__ M, int k, int col, int c, float (&y)[T]) {
-  const float* p = M + ((uint64_t)(uint32_t)col * (uint32_t)k + (uint32_t)c);  // one v_mad_u64_u32
+// No arithmetic may depend on the loaded values here (the loads must stay in flight).  The table is
+// zero-padded to 16 T floats per row when k % 16 != 0 (SolveParams::M), so the last block needs no
+// predication and no row straddles more 128-byte lines than its length asks for (measured at k = 30 on the
+// unpadded replica, 120-byte rows: 1.6x the algorithmic bytes from HBM, all of it as 128-byte requests).
+template <int T>
+__device__ __forceinline__ void load_rows(const float* __restrict__ M, int ldm, int col, int c, float (&y)[T]) {
+  const float* p = M + ((uint64_t)(uint32_t)col * (uint32_t)ldm + (uint32_t)c);  // one v_mad_u64_u32
 #pragma unroll
-  for (int v = 0; v < T - 1; ++v) y[v] = p[16 * v];
-  if (FULL || 16 * (T - 1) + c < k) y[T - 1] = p[16 * (T - 1)];
+  for (int v = 0; v < T; ++v) y[v] = p[16 * v];
 }
 
 template <int T>
@@ -502,7 +505,7 @@ template <int T, int D, bool FULL>
 __device__ __forceinline__ void prime_row(const SolveParams& p, int lane, Pipe<T, D>& pp) {
   const int c = lane & 15, gb = (lane >> 4) << 2;
 #pragma unroll
-  for (int i = 0; i < D - 1; ++i) load_rows<T, FULL>(p.M, p.k, bperm_i(gb + 16 * i, pp.ch.col), c, pp.y[i]);
+  for (int i = 0; i < D - 1; ++i) load_rows<T>(p.M, p.ldm, bperm_i(gb + 16 * i, pp.ch.col), c, pp.y[i]);
   pp.wcur = bperm(gb, pp.ch.w);
   pp.cbcur = bperm(gb, pp.ch.cb);
   pp.colpf = bperm_i(gb + 16 * (D - 1), pp.ch.col);
@@ -522,7 +525,7 @@ __device__ __forceinline__ void gather_row(const SolveParams& p, int64_t begin, 
       const int s = 16 * q + j;
       if (s < nsteps) {
         // (1) gather the rows of step s+D-1 into the slot step s-1 has just released
-        load_rows<T, FULL>(p.M, p.k, pp.colpf, c, pp.y[(j + D - 1) % D]);
+        load_rows<T>(p.M, p.ldm, pp.colpf, c, pp.y[(j + D - 1) % D]);
         __builtin_amdgcn_sched_barrier(0);
         if (j == 14) chunk_weights(p, chn);  // first use of the next chunk's weights is step 15
         // (2) cross-lane fetches for the next step's weights and the next gather's column
@@ -602,8 +605,8 @@ __device__ __forceinline__ void chunk_weights_h(const SolveParams& p, Chunk& e, 
 // Gather the two entries 4e+g, e = 2*E2 and 2*E2+1, of one super-step: their columns sit in lanes
 // (off/4 + 4e + g) of col_src (off = 4g + 16*E*part of the chunk).  Entries past the end of the row
 // have a clamped column (chunk_issue) and zero weights, so they gather a valid, cached row that
-// contributes nothing: no per-entry predication.  As in load_rows, lanes past k in a partial last
-// block never load and stay zero.
+// contributes nothing: no per-entry predication.  As in load_rows, the features past k of a partial last
+// block are the zero padding of the table.
 template <int T, int E, bool FULL, int E2>
 __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, int off, int lane, float (&raw)[T][E]) {
   const int c = lane & 15;
@@ -618,17 +621,9 @@ __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = 2 * E2 + i;
-    const float* ptr = p.M + ((uint64_t)(uint32_t)col[i] * (uint32_t)p.k + (uint32_t)c);
+    const float* ptr = p.M + ((uint64_t)(uint32_t)col[i] * (uint32_t)p.ldm + (uint32_t)c);
 #pragma unroll
-    for (int v = 0; v < T - 1; ++v) raw[v][e] = ptr[16 * v];
-    if constexpr (FULL) {
-      raw[T - 1][e] = ptr[16 * (T - 1)];
-    } else {
-      // partial last block: no predicated load (the exec-mask juggling cost 36 VGPRs of spills at k = 50): the
-      // lanes past k read the row's LAST valid feature instead and convert_pair_h zeroes them with a 0/1 lane mask
-      const int last = p.k - 1 - 16 * (T - 1);   // index of the last valid lane of the block, 0..14
-      raw[T - 1][e] = ptr[16 * (T - 1) + ((c > last ? last : c) - c)];
-    }
+    for (int v = 0; v < T; ++v) raw[v][e] = ptr[16 * v];
   }
 }
 
@@ -637,17 +632,12 @@ template <int T, int E, bool FULL, int PART, int E2>
 __device__ __forceinline__ void convert_pair_h(const SolveParams& p, const Chunk& ch, int lane, const float (&raw)[T][E], ZOp<E> (&zh)[T],
                                                ZOp<E> (&zl)[T], float (&bpart)[T]) {
   const int gb = (lane >> 4) << 2;
-  const float last_mask = (FULL || 16 * (T - 1) + (lane & 15) < p.k) ? 1.f : 0.f;   // partial last block: see issue_pair_h
   constexpr int o0 = 16 * E * PART + 32 * E2, o1 = o0 + 16;
   float s0, s1, c0, c1;
   bperm2x2<o0, o1>(gb, ch.w, ch.cb, s0, s1, c0, c1);
 #pragma unroll
   for (int v = 0; v < T; ++v) {
-    float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
-    if (!FULL && v == T - 1) {
-      y0 *= last_mask;
-      y1 *= last_mask;
-    }
+    const float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
     const float z0 = y0 * s0, z1 = y1 * s1;
     // zh = the top 11 significand bits (round toward zero straight into f16), zl = what is left: written
     // as an FMA on the widened half so that hipcc emits one v_fma_mix_f32 per value (and folds the
@@ -1500,6 +1490,22 @@ __global__ void sample_dots_kernel(const float* __restrict__ X, const float* __r
   double d = 0.0;
   for (int f = 0; f < k; ++f) d += (double)__fmul_rn(x[f], y[f]);
   out[e] = d;
+}
+
+// Gather table of the rows kernels when k % 16 != 0 (SolveParams::M): dst row r = src row r followed by zeros up to
+// ld = 16 T floats.  One 16-byte store per thread; a streaming copy (n (k + ld) 4 bytes) once per half-iteration.
+__global__ void pad_rows_kernel(const float* __restrict__ src, int64_t n, int k, int ld, float* __restrict__ dst) {
+  const int q = ld >> 2;
+  const int64_t n4 = n * q;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / q;
+    const int f = 4 * (int)(e - r * q);
+    const float* s = src + r * k + f;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = f + i < k ? s[i] : 0.f;
+    reinterpret_cast<f32x4*>(dst)[e] = v;
+  }
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ F, const int64_t* __restrict__ idx, int n, int k,

@@ -83,6 +83,7 @@ struct SideState {
   size_t partial_bytes = 0;
   bool G_valid = false;
   uint64_t G_version = 0;  // bumped whenever G changes (cached operand scale of the split-precision gather)
+  uint64_t F_epoch = 0;    // bumped whenever the library itself writes the replica (uploads, solves, rebinding)
 };
 
 struct PendingEvent {
@@ -101,6 +102,14 @@ struct mals_handle_s {
   // dual path state (dual_kernels.h): rotated copy of the gathered factor matrix, Q / Q^T / eigenvalues
   float* d_Mr = nullptr;
   size_t Mr_cap = 0;          // floats
+  // gather table of the direct kernels when features % 16 != 0: zero-padded copy of the gathered factor matrix
+  // (pad_rows_kernel), rebuilt once per half-iteration
+  float* d_Mp = nullptr;
+  size_t Mp_cap = 0;          // floats
+  int pad_side = -1;          // solved side whose opposite matrix the copy holds, version of that side's G and
+  uint64_t pad_version = 0;   // factor-upload count at the time of the copy
+  uint64_t pad_epoch = 0;
+  std::vector<uint8_t> pad_done;  // chunks solved from the current copy: solving one again starts a new half-iteration
   double* d_Q = nullptr;      // [2][16T][16T]: Q (k x 16T, zero padded) and Q^T
   float* d_Qf = nullptr;      // the same in fp32
   bool rotate_f64 = false;    // this half-iteration's forward rotation runs on the fp64 matrix cores
@@ -1268,6 +1277,7 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_maxabs);
   free_dev(h->d_colrange);
   free_dev(h->d_Mr);
+  free_dev(h->d_Mp);
   free_dev(h->d_Q);
   free_dev(h->d_Qf);
   free_dev(h->d_Bs);
@@ -1312,6 +1322,7 @@ int mals_set_factor_rows(mals_handle h, int side, int64_t n_rows_total) {
   s.F_owned = true;
   s.n_total = n_rows_total;
   s.G_valid = false;
+  ++s.F_epoch;
   return MALS_OK;
 }
 
@@ -1325,6 +1336,7 @@ int mals_bind_factors(mals_handle h, int side, float* device_ptr, int64_t n_rows
   s.F_owned = false;
   s.n_total = n_rows_total;
   s.G_valid = false;
+  ++s.F_epoch;
   return MALS_OK;
 }
 
@@ -1501,6 +1513,7 @@ int mals_set_factors(mals_handle h, int side, int64_t row_begin, int64_t n_rows,
                            h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   s.G_valid = false;
+  ++s.F_epoch;
   return MALS_OK;
 }
 
@@ -1614,6 +1627,40 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.col = s.col;
   p.val = s.val;
   p.M = o.F;
+  p.ldm = k;
+  if (k % 16 != 0) {
+    const int ld = 16 * h->T;
+    const size_t need = (size_t)o.n_total * (size_t)ld;
+    if (need > h->Mp_cap) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      free_dev(h->d_Mp);
+      h->Mp_cap = 0;
+      h->pad_side = -1;
+      HIPCHK(h, hipMalloc(&h->d_Mp, sizeof(float) * need));
+      h->Mp_cap = need;
+    }
+    // the opposite factors do not change while a half-iteration's chunks are solved (in any order): the copy is
+    // refreshed when the side, the opposite Gramian or the opposite uploads changed, or when a chunk comes round again
+    bool stale = h->pad_side != side || h->pad_version != o.G_version || h->pad_epoch != o.F_epoch ||
+                 h->pad_done.size() != s.chunks.size();
+    for (int c = chunk_begin; c < chunk_end && !stale; ++c) stale = h->pad_done[(size_t)c] != 0;
+    if (stale) {
+      PendingEvent pe;
+      if (int rc = begin_timed(h, 5, (double)o.n_total * 4.0 * (k + ld), pe)) return rc;
+      const int64_t n4 = o.n_total * (ld / 4);
+      const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)h->n_cu * 32);
+      hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, h->stream, o.F, o.n_total, k, ld, h->d_Mp);
+      HIPCHK(h, hipGetLastError());
+      if (int rc = end_timed(h, pe)) return rc;
+      h->pad_side = side;
+      h->pad_version = o.G_version;
+      h->pad_epoch = o.F_epoch;
+      h->pad_done.assign(s.chunks.size(), 0);
+    }
+    for (int c = chunk_begin; c < chunk_end; ++c) h->pad_done[(size_t)c] = 1;
+    p.M = h->d_Mp;
+    p.ldm = ld;
+  }
   p.Gf = o.Gf;
   p.out = s.F + s.row_offset * k;
   p.items = nullptr;
@@ -1684,6 +1731,7 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   // this side's factors changed: its Gramian is stale.  (The OPPOSITE side's Gramian stays valid
   // for the remaining chunks of this half-iteration.)
   s.G_valid = false;
+  ++s.F_epoch;
   return MALS_OK;
 }
 

@@ -130,6 +130,60 @@ def test_half_iterations_match_oracle(k):
     assert rel(Y, Yo) < REL_TOL, (k, rel(Y, Yo))
 
 
+@pytest.mark.parametrize("k,mode", [(30, 0), (50, 0), (10, 0), (21, _lib.GRAMIAN_FP32), (100, 0)])
+def test_padded_gather_table_follows_the_opposite_factors(k, mode):
+    """k % 16 != 0: the rows kernels gather from a zero-padded copy of the opposite replica (pad_rows_kernel).
+    The copy must follow every change of that replica: chunks solved in any order, the same side solved twice
+    in a row after new uploads (with and without a new Gramian: lossIgnoresUnspecified on the fp32 path needs
+    none), both sides alternating."""
+    n_users, n_items, nnz = 900, 260, 12000
+    r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, nnz, k, seed=4242 + k, negatives=0.1)
+    rng = np.random.default_rng(k)
+    Y1 = (Y0 + 0.25 * rng.standard_normal(Y0.shape)).astype(np.float32)
+    with pkg.ALSCore(k, chunk_rows=250, gramian_mode=mode) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_matrix(pkg.SIDE_X, *r_csr)
+        core.set_matrix(pkg.SIDE_Y, *c_csr)
+        n_chunks = core.num_chunks(pkg.SIDE_X)
+        assert n_chunks == 4
+        got = []
+        for Yv, order in ((Y0, range(n_chunks - 1, -1, -1)), (Y1, (2, 0, 3, 1))):
+            core.set_factors(pkg.SIDE_Y, Yv)
+            core.gramian(pkg.SIDE_Y)
+            for c in order:
+                core.solve_chunk(pkg.SIDE_X, c)
+            core.check()
+            got.append(core.get_factors(pkg.SIDE_X))
+        core.half_iteration(pkg.SIDE_Y)
+        Y2 = core.get_factors(pkg.SIDE_Y)
+        core.half_iteration(pkg.SIDE_X)
+        X3 = core.get_factors(pkg.SIDE_X)
+    X0o = oracle.half_iteration(*r_csr, Y0, threads=4)
+    X1o = oracle.half_iteration(*r_csr, Y1, threads=4)
+    Y2o = oracle.half_iteration(*c_csr, X1o, threads=4)
+    X3o = oracle.half_iteration(*r_csr, Y2o, threads=4)
+    for a, b in ((got[0], X0o), (got[1], X1o), (Y2, Y2o), (X3, X3o)):
+        assert rel(a, b) < REL_TOL, (k, rel(a, b))
+    if mode == _lib.GRAMIAN_FP32:
+        # W does not start from G: the same side twice with new uploads and NO new Gramian in between
+        flags = pkg.FLAG_LOSS_IGNORES_UNSPECIFIED
+        rp = r_csr[0]
+        keep = np.nonzero(np.diff(rp) > 0)[0]   # an empty row has W = 0 in this mode: singular in the reference too
+        r2 = (np.concatenate([[0], np.cumsum(np.diff(rp)[keep])]).astype(np.int64), r_csr[1], r_csr[2])
+        with pkg.ALSCore(k, flags=flags, gramian_mode=mode) as core:
+            core.set_factor_rows(pkg.SIDE_X, len(keep))
+            core.set_factor_rows(pkg.SIDE_Y, n_items)
+            core.set_matrix(pkg.SIDE_X, *r2)
+            for Yv in (Y0, Y1):
+                core.set_factors(pkg.SIDE_Y, Yv)
+                core.solve_side(pkg.SIDE_X)
+                core.check()
+                X = core.get_factors(pkg.SIDE_X)
+                Xo = oracle.half_iteration(*r2, Yv, flags=flags, threads=4)
+                assert rel(X, Xo) < REL_TOL, rel(X, Xo)
+
+
 @pytest.mark.parametrize("flags", [pkg.FLAG_RECONSTRUCT_R, pkg.FLAG_LOSS_IGNORES_UNSPECIFIED,
                                    pkg.FLAG_RECONSTRUCT_R | pkg.FLAG_LOSS_IGNORES_UNSPECIFIED])
 def test_mode_flags_match_oracle(flags):
