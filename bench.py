@@ -159,6 +159,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MALS_BENCH_ONE_DEVICE=1 (tests only, tests/test_gpu_group_transport.py): every rank on device 0 and torch's own
+    # rendezvous on gloo -- with MALS_RCCL_LIBRARY pointing at the tests' stand-in transport this runs the whole N > 1
+    # flow of this script on a box with one GPU.  The numbers of such a run mean nothing.
+    one_device = os.environ.get("MALS_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local_rank = 0
     if world != args.gpus:
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
@@ -170,7 +176,11 @@ def main():
     if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    red_device = torch.device("cpu") if one_device else device   # where the few scalars of this script are reduced
 
     n_users, n_items, nnz_req, k, desc = WORKLOADS[args.workload]
     t_gen = time.perf_counter()
@@ -275,10 +285,10 @@ def main():
     # untimed quality figure: ReconstructionEvaluator's mean over the observed entries (8(f) row 3)
     rec_sum, rec_cnt = core.reconstruction_error()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        q = torch.tensor([rec_sum, float(rec_cnt)], dtype=torch.float64, device=device)
+        q = torch.tensor([rec_sum, float(rec_cnt)], dtype=torch.float64, device=red_device)
         dist.all_reduce(q)
         rec_sum, rec_cnt = float(q[0].item()), int(q[1].item())
 
@@ -370,6 +380,9 @@ def main():
                                              "planted low-rank part (synth.torch_problem), the only part a factor model can predict",
                                      "planted_part": planted_err},
         }
+        if one_device or os.environ.get("MALS_RCCL_LIBRARY"):
+            out["INVALID_AS_A_MEASUREMENT"] = ("test run: MALS_BENCH_ONE_DEVICE=%s (all ranks on device 0), MALS_RCCL_LIBRARY=%s"
+                                               % (os.environ.get("MALS_BENCH_ONE_DEVICE", "0"), os.environ.get("MALS_RCCL_LIBRARY", "")))
         if world == 1 and not args.no_cpu_baseline:
             X = als.factors(pkg.SIDE_X)
             Y = als.factors(pkg.SIDE_Y)

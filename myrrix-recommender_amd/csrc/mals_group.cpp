@@ -21,6 +21,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -45,9 +46,18 @@ struct Rccl {
   bool load(std::string& err) {
     if (lib) return true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // MALS_RCCL_LIBRARY=<path>: this library and no other (a particular RCCL build; tests/cpp/libmock_rccl.so, the
+    // stand-in transport that lets the tests run N ranks on one device)
+    if (const char* forced = std::getenv("MALS_RCCL_LIBRARY")) {
+      lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+      if (!lib) {
+        err = std::string("MALS_RCCL_LIBRARY=") + forced + " could not be loaded: " + (dlerror() ? dlerror() : "");
+        return false;
+      }
+    }
     for (const char* n : names) {
-      lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // a copy the process already mapped (e.g. PyTorch's) first
       if (lib) break;
+      lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // a copy the process already mapped (e.g. PyTorch's) first
     }
     for (const char* n : names) {
       if (lib) break;

@@ -79,37 +79,54 @@ class GroupALS:
         self._chk(L.mals_group_set_exchange_chunks(g, int(exchange_chunks)))
         return self
 
-    @classmethod
-    def from_torch_distributed(cls, features, device, alpha=1.0, lam=0.1, flags=0, segment_nnz=0, singularity_threshold=1e-5,
-                               gramian_mode=0, solve_mode=0, exchange_chunks=4, world=None, rank=None, one_rank_communicator=False):
-        """One rank per process.  torch.distributed (already initialised unless world == 1) only carries
-        the 128-byte RCCL unique id from rank 0 to the others."""
-        import torch
+    @staticmethod
+    def unique_id():
+        """mals_group_unique_id: the 128-byte RCCL unique id rank 0 creates and hands to the other ranks."""
         L = _lib.load()
-        if world is None:
-            import torch.distributed as dist
-            world, rank = dist.get_world_size(), dist.get_rank()
+        buf = (ctypes.c_uint8 * 128)()
+        rc = L.mals_group_unique_id(buf)
+        if rc != _lib.OK:
+            raise MalsError(rc, "mals_group_unique_id failed (is librccl.so.1 loadable?)")
+        return bytes(buf)
+
+    @classmethod
+    def from_unique_id(cls, features, device, world, rank, uid, alpha=1.0, lam=0.1, flags=0, segment_nnz=0,
+                       singularity_threshold=1e-5, gramian_mode=0, solve_mode=0, exchange_chunks=4):
+        """One rank per process (mals_group_create_rank); `uid` = unique_id() of rank 0, carried by whatever
+        the application has (MPI, a socket, torch.distributed); None with world == 1 = no communicator at all."""
+        L = _lib.load()
         cfg = cls._config(L, features, alpha, lam, flags, device, segment_nnz, singularity_threshold, gramian_mode, solve_mode)
-        uid = None
-        if world > 1 or one_rank_communicator:
-            buf = (ctypes.c_uint8 * 128)()
-            if rank == 0:
-                rc = L.mals_group_unique_id(buf)
-                if rc != _lib.OK:
-                    raise MalsError(rc, "mals_group_unique_id failed (is librccl.so.1 loadable?)")
-            if world > 1:
-                import torch.distributed as dist
-                t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=torch.device("cuda", device))
-                dist.broadcast(t, 0)
-                buf = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
-            uid = buf
+        buf = (ctypes.c_uint8 * 128)(*uid) if uid is not None else None
         g = ctypes.c_void_p()
-        rc = L.mals_group_create_rank(ctypes.byref(cfg), int(world), int(rank), uid, ctypes.byref(g))
+        rc = L.mals_group_create_rank(ctypes.byref(cfg), int(world), int(rank), buf, ctypes.byref(g))
         if rc != _lib.OK:
             raise MalsError(rc, "mals_group_create_rank failed (rank %d of %d)" % (rank, world))
         self = cls(features, g, world)
         self._chk(L.mals_group_set_exchange_chunks(g, int(exchange_chunks)))
         return self
+
+    @classmethod
+    def from_torch_distributed(cls, features, device, alpha=1.0, lam=0.1, flags=0, segment_nnz=0, singularity_threshold=1e-5,
+                               gramian_mode=0, solve_mode=0, exchange_chunks=4, world=None, rank=None, one_rank_communicator=False):
+        """One rank per process.  torch.distributed (already initialised unless world == 1) only carries
+        the 128-byte RCCL unique id from rank 0 to the others."""
+        if world is None:
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(), dist.get_rank()
+        uid = None
+        if world > 1 or one_rank_communicator:
+            uid = cls.unique_id() if rank == 0 else bytes(128)
+            if world > 1:
+                import torch
+                import torch.distributed as dist
+                # a CPU tensor under gloo (single-device test runs), a device tensor under RCCL
+                dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
+                t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+                dist.broadcast(t, 0)
+                uid = bytes(t.cpu().tolist())
+        return cls.from_unique_id(features, device, world, rank, uid, alpha=alpha, lam=lam, flags=flags, segment_nnz=segment_nnz,
+                                  singularity_threshold=singularity_threshold, gramian_mode=gramian_mode, solve_mode=solve_mode,
+                                  exchange_chunks=exchange_chunks)
 
     # -- lifecycle --------------------------------------------------------------------------------
     def close(self):

@@ -1,0 +1,150 @@
+"""The RCCL code path of csrc/mals_group.cpp EXECUTED with N > 1 ranks on the one GPU of the test box.
+
+RCCL refuses two ranks on one device, so these tests point the library at tests/cpp/libmock_rccl.so
+(MALS_RCCL_LIBRARY): a stand-in with RCCL's entry points that moves the bytes with plain copies and turns every
+mismatched call (a send without its receive, different counts, a rank missing from an all-reduce) into an error
+instead of a hang.  What runs is the product's own call sequence -- ncclCommInitAll / ncclCommInitRank, the
+grouped ncclSend + ncclRecv exchange per chunk on the comm streams, the k x k and status all-reduces -- and the
+factors that come out are checked against the oracle and against the single-device result.  The transport is
+loaded once per process, so every case runs in child processes.  The real N-GPU RCCL run is the driver's
+scaling bench (bench.py --gpus N)."""
+import json
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, "tests", "cpp", "libmock_rccl.so")
+REL_TOL = 1e-4
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def _problem(k, seed):
+    from myrrix_recommender_amd import synth
+    return synth.numpy_problem(2600, 720, 32000, k, seed=seed, negatives=0.1)
+
+
+def _in_process(world, k, chunks, q):
+    try:
+        os.environ["MALS_RCCL_LIBRARY"] = MOCK
+        import myrrix_recommender_amd as pkg
+        from myrrix_recommender_amd import _lib
+        r_csr, c_csr, Y0 = _problem(k, 500 + world)
+        n_users, n_items = len(r_csr[0]) - 1, len(c_csr[0]) - 1
+        with pkg.GroupALS.single_process(k, [0] * world, backend=_lib.GROUP_RCCL, exchange_chunks=chunks) as g:
+            g.set_factor_rows(pkg.SIDE_X, n_users)
+            g.set_factor_rows(pkg.SIDE_Y, n_items)
+            g.set_matrix(pkg.SIDE_X, *r_csr)
+            g.set_matrix(pkg.SIDE_Y, *c_csr)
+            g.set_factors(pkg.SIDE_Y, Y0)
+            g.iterate(2)
+            X = g.get_factors(pkg.SIDE_X, 0, n_users)
+            Y = g.get_factors(pkg.SIDE_Y, 0, n_items)
+            same = all(np.array_equal(g.local(i)[0].get_factors(pkg.SIDE_X), X) and np.array_equal(g.local(i)[0].get_factors(pkg.SIDE_Y), Y)
+                       for i in range(world))
+        q.put(("ok", X, Y, same))
+    except Exception as e:  # noqa: BLE001 -- reported to the parent
+        q.put(("error", repr(e)))
+
+
+def _one_rank(rank, world, k, chunks, uid_q, out_q):
+    try:
+        os.environ["MALS_RCCL_LIBRARY"] = MOCK
+        import myrrix_recommender_amd as pkg
+        r_csr, c_csr, Y0 = _problem(k, 600 + world)
+        n_users, n_items = len(r_csr[0]) - 1, len(c_csr[0]) - 1
+        if rank == 0:
+            uid = pkg.GroupALS.unique_id()
+            for _ in range(world - 1):
+                uid_q.put(uid)
+        else:
+            uid = uid_q.get(timeout=120)
+        with pkg.GroupALS.from_unique_id(k, 0, world, rank, uid, exchange_chunks=chunks) as g:
+            g.set_factor_rows(pkg.SIDE_X, n_users)
+            g.set_factor_rows(pkg.SIDE_Y, n_items)
+            g.set_matrix(pkg.SIDE_X, *r_csr)
+            g.set_matrix(pkg.SIDE_Y, *c_csr)
+            g.set_factors(pkg.SIDE_Y, Y0)
+            g.iterate(2)
+            # every rank reads its own replica: all of them must hold all rows
+            X = g.local(0)[0].get_factors(pkg.SIDE_X)
+            Y = g.local(0)[0].get_factors(pkg.SIDE_Y)
+            bounds = g.bounds(pkg.SIDE_X).tolist()
+        out_q.put((rank, "ok", X, Y, bounds))
+    except Exception as e:  # noqa: BLE001
+        out_q.put((rank, "error", repr(e)))
+
+
+def _oracle(k, seed):
+    from oracle import oracle
+    r_csr, c_csr, Y0 = _problem(k, seed)
+    X, Y = None, Y0
+    for _ in range(2):
+        X = oracle.half_iteration(*r_csr, Y, threads=4)
+        Y = oracle.half_iteration(*c_csr, X, threads=4)
+    return X, Y
+
+
+@pytest.mark.parametrize("world,k,chunks", [(2, 64, 1), (3, 64, 4), (4, 30, 3)])
+def test_rccl_backend_members_of_one_process(world, k, chunks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_in_process, args=(world, k, chunks, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(60)
+    assert res[0] == "ok", res
+    _, X, Y, same = res
+    assert same, "the replicas of the members differ after the exchange"
+    Xo, Yo = _oracle(k, 500 + world)
+    assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL, (rel(X, Xo), rel(Y, Yo))
+
+
+@pytest.mark.parametrize("world,k,chunks", [(2, 64, 4), (3, 50, 2)])
+def test_rccl_backend_one_rank_per_process(world, k, chunks):
+    ctx = mp.get_context("spawn")
+    uid_q, out_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_one_rank, args=(r, world, k, chunks, uid_q, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out_q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), [r[:3] for r in res if r[1] != "ok"]
+    res.sort(key=lambda r: r[0])
+    Xo, Yo = _oracle(k, 600 + world)
+    for rank, _, X, Y, bounds in res:
+        assert bounds == res[0][4] and bounds[0] == 0 and bounds[-1] == X.shape[0]
+        assert np.array_equal(X, res[0][2]) and np.array_equal(Y, res[0][3]), "rank %d holds other factors than rank 0" % rank
+        assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL, (rank, rel(X, Xo), rel(Y, Yo))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_script_as_the_driver_launches_it(world):
+    """`python bench.py --gpus N` end to end (self-launch through torch.distributed.run, one rank per process, the
+    group API, the timing bracket, ONE JSON line from rank 0 as the last line of stdout) on the stand-in transport."""
+    env = dict(os.environ, MALS_RCCL_LIBRARY=MOCK, MALS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                        "--workload", "small"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert sum(ln.startswith("{") for ln in lines) == 1, lines[-5:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1
+    assert d["unit"] == "rows/s" and d["value"] > 0 and d["scaling"] == "strong"
+    assert "INVALID_AS_A_MEASUREMENT" in d          # the line says what it is
+    assert "RCCL below the C-ABI" in d["config"]["sharding"]
+    xb = d["config"]["slices"]["x_bounds"]
+    assert len(xb) == world + 1 and xb[0] == 0 and xb[-1] == d["config"]["users"]
+    assert d["all_gather_alone_ms"]["x_ms"] > 0
+    assert 0.0 <= d["reconstruction_error"]["mean"] <= 1.0
