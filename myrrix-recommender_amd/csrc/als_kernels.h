@@ -28,7 +28,7 @@ namespace mals {
 #define MALS_WAVES(T, MODE) ((T) <= 4 ? 4 : ((T) == 5 ? 3 : 2))
 #endif
 #ifndef MALS_WAVES_H
-#define MALS_WAVES_H(T, MODE) ((T) <= 4 ? 3 : 2)
+#define MALS_WAVES_H(T, MODE) ((T) <= 2 ? 5 : ((T) <= 4 ? 3 : 2))
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
