@@ -371,6 +371,7 @@ def main():
                         "mfma_busy_frac": gram_busy,
                         "mfma_busy_source": "profiles/pmc_traffic.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), the Gramian kernel with the most time)" if gram_busy is not None else None},
             "rows_dual_per_step": st["rows_dual"] / args.steps,
+            "rows_refined_per_step": st["rows_refined"] / args.steps,   # ill-conditioned rows re-solved with fp64 residuals
             "eigen_host_ms_per_step": st["eigen_host_ms"] / args.steps,
             "half_iteration_kernel_ms": halves,
             "all_gather_alone_ms": exchange,

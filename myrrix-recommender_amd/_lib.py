@@ -43,7 +43,7 @@ class Stats(ctypes.Structure):
                 ("dual_ms", ctypes.c_double), ("rotate_ms", ctypes.c_double),
                 ("dual_launches", ctypes.c_int64), ("rotate_launches", ctypes.c_int64),
                 ("dual_bytes", ctypes.c_double), ("rotate_bytes", ctypes.c_double),
-                ("rows_dual", ctypes.c_int64), ("eigen_host_ms", ctypes.c_double)]
+                ("rows_dual", ctypes.c_int64), ("eigen_host_ms", ctypes.c_double), ("rows_refined", ctypes.c_int64)]
 
 
 class ModelView(ctypes.Structure):
@@ -97,6 +97,7 @@ SYMBOLS = {
     "mals_solve_chunk": (ctypes.c_int, [_H, ctypes.c_int, _I32]),
     "mals_num_chunks": (ctypes.c_int, [_H, ctypes.c_int, ctypes.POINTER(_I32)]),
     "mals_set_chunk_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64]),
+    "mals_set_refine_limit": (ctypes.c_int, [_H, ctypes.c_double]),
     "mals_check": (ctypes.c_int, [_H]),
     "mals_singular_info": (ctypes.c_int, [_H, ctypes.POINTER(_I32), ctypes.POINTER(_I64), ctypes.POINTER(_I32)]),
     "mals_half_iteration": (ctypes.c_int, [_H, ctypes.c_int]),

@@ -374,6 +374,10 @@ class ALSCore:
                                            len(ti), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def set_refine_limit(self, limit):
+        """mals_set_refine_limit: conditioning estimate above which a row is re-solved with fp64 residuals (0 = never)."""
+        self._chk(self._L.mals_set_refine_limit(self._h, float(limit)))
+
     def stats(self):
         st = _lib.Stats()
         self._chk(self._L.mals_get_stats(self._h, ctypes.byref(st)))

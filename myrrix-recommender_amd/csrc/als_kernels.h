@@ -62,6 +62,10 @@ struct SolveParams {
   const RowC* rowsC;        // list C
   float* scratch;           // segment partials
   unsigned long long* bad_row; // first (smallest) local row with a non-PD system
+  unsigned long long* suspect; // (pivot bits << 32 | local row) of the smallest pivot within 1024x of the threshold:
+                               // mals_check puts that row to the reference's own singularity test (pivoted QR)
+  uint8_t* refine_flag;     // per local row: set to 1 by the solving kernel when (largest entry of W) / (smallest pivot)
+  float refine_limit;       // exceeds refine_limit -- the row is then re-solved with fp64 residuals (als_refine_kernel)
   int64_t n_work;           // waves of work in the list this launch handles
   int32_t k;
   int32_t ldm;              // row stride of M in floats
@@ -777,16 +781,20 @@ __device__ __forceinline__ void add_ridge(const SolveParams& p, f32x4 (&acc)[tri
   float rd[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) rd[r] = (4 * g + r == c) ? ridge : 0.f;
+  float w00 = 1.f;
+  if constexpr (!FULL) w00 = readlane(acc[tidx(T, 0, 0)][0], 0) + ridge;  // lane 0, register 0 of tile (0,0) = W[0][0]
 #pragma unroll
   for (int v = 0; v < T; ++v) {
     if (FULL || v < T - 1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[tidx(T, v, v)][r] += rd[r];
-    } else {  // partial last block: 1 on the diagonal of the padding
+    } else {  // partial last block: the padding features are decoupled from the others (zero rows and columns);
+              // their diagonal gets W[0][0], a value on the scale of the real pivots, so that the smallest pivot and
+              // the conditioning estimate of store_row speak about the real system only
       const int feat = 16 * v + c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (4 * g + r == c) acc[tidx(T, v, v)][r] = feat < p.k ? acc[tidx(T, v, v)][r] + ridge : 1.f;
+        if (4 * g + r == c) acc[tidx(T, v, v)][r] = feat < p.k ? acc[tidx(T, v, v)][r] + ridge : w00;
       }
     }
   }
@@ -795,11 +803,11 @@ __device__ __forceinline__ void add_ridge(const SolveParams& p, f32x4 (&acc)[tri
 // Scale the row's system W x = b by s^2 = 2^(2p) with s * sqrt(max_i W_ii) <= 2^13 (entries of the
 // Cholesky factor of s^2 W are then <= 2^13): exact, and undone by comparing the pivots against
 // threshold * s^2 (the caller multiplies minpiv by the returned 1/s^2) -- x itself is unchanged.
+// bit pattern of the largest |entry| of the diagonal tiles of an SPD matrix = its largest diagonal element = its
+// largest |entry| (no need to pick the diagonal out of the tiles); uniform over the wave.  Non-negative floats order
+// like their bit patterns: integer max (a float max of a DPP / bpermute result costs an extra canonicalising v_max).
 template <int T>
-__device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T], int lane) {
-  // the largest diagonal element of an SPD matrix is its largest |entry|: no need to pick the diagonal
-  // out of the diagonal tiles.  Non-negative floats order like their bit patterns: integer max from here
-  // on (a float max of a DPP / bpermute result costs an extra canonicalising v_max).
+__device__ __forceinline__ int max_entry_bits(const f32x4 (&acc)[tri(T)], int lane) {
   float mf = 0.f;
 #pragma unroll
   for (int v = 0; v < T; ++v) {
@@ -813,6 +821,26 @@ __device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T
   m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x120 + 1, 0xf, 0xf, false));
   m = max(m, bperm_i((lane ^ 16) << 2, m));
   m = max(m, bperm_i((lane ^ 32) << 2, m));
+  return m;
+}
+
+// the same for W minus the Gramian image it started from: the largest entry of the row's own part sum w y y^T
+// (gimg: [tile][lane] float4 image, global or LDS; zeros under lossIgnoresUnspecified)
+template <int T>
+__device__ __forceinline__ float row_part_max(const f32x4 (&acc)[tri(T)], const f32x4* gimg, int lane) {
+  f32x4 d[tri(T)];
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int v = 0; v < T; ++v) d[tidx(T, v, v)] = acc[tidx(T, v, v)] - gimg[tidx(T, v, v) * 64 + lane];
+  return __int_as_float(max_entry_bits<T>(d, lane));
+}
+
+// wmax <- the largest entry of W before the scaling
+template <int T>
+__device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T], int lane, float& wmax) {
+  const int m = max_entry_bits<T>(acc, lane);
+  wmax = __int_as_float(m);
   const int e = ((m >> 23) & 255) - 126;  // largest entry < 2^e
   int p2 = 2 * (13 - ((e + 1) >> 1));
   p2 = p2 < -100 ? -100 : (p2 > 100 ? 100 : p2);
@@ -827,12 +855,22 @@ __device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T
 }
 
 // store x (the cast to fp32 of CMS:40-42 is implicit: all arithmetic here is fp32); flag non-PD rows
+// rmax = the largest entry of the row's own part sum w y y^T of W: rmax / minpiv estimates from below how much the
+// rounding of that fp32 accumulation is amplified in x (the shared Gramian under it is an fp64 sum rounded once and,
+// measured, harmless even where it dominates cond(W)); rows above refine_limit are marked for als_refine_kernel
 template <int T>
-__device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T], float minpiv, int row, int lane) {
+__device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T], float minpiv, float wmax, int row, int lane) {
   if (!(minpiv > p.sing_threshold)) {
     if (lane == 0) atomicMin(p.bad_row, (unsigned long long)row);
 #pragma unroll
     for (int v = 0; v < T; ++v) xcol[v] = 0.f;
+  } else {
+    if (minpiv <= 1024.f * p.sing_threshold && lane == 0) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(minpiv) << 32) | (unsigned)row;
+      // same-address atomics serialise: only rows that lower the minimum issue one
+      if (key < __builtin_nontemporal_load(p.suspect)) atomicMin(p.suspect, key);
+    }
+    if (p.refine_flag && wmax > p.refine_limit * minpiv && lane == 0) p.refine_flag[row] = 1;
   }
   if (lane < 16) {
     float* o = p.out + (int64_t)row * p.k;
@@ -847,13 +885,13 @@ __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T]
 // ridge + factor + solve + store, no prefetch hook (used by the long-row finish kernel)
 template <int T>
 __device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tri(T)], const float (&bcol)[T],
-                                           int n_u, int row, int lane) {
+                                           int n_u, int row, int lane, float rmax = 0.f) {
   add_ridge<T>(p, acc, n_u, lane);
   float minpiv = 3.0e38f;
   float xcol[T];
   cholesky_tiles<T>(acc, lane, minpiv);
   solve_tiles<T>(acc, bcol, xcol, lane);
-  store_row<T>(p, xcol, minpiv, row, lane);
+  store_row<T>(p, xcol, minpiv, rmax, row, lane);
 }
 
 __device__ __forceinline__ WorkItem load_item(const SolveParams& p, int64_t it) {
@@ -930,6 +968,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
     if (prime_next) pp.ch = chunk_issue(p, nxt.begin, nxt.len, 0, lane);
     const WorkItem nxt2 = load_item(p, it + 2 * n_waves);
     if (MODE == 0) {
+      const float wmax = p.refine_flag ? row_part_max<T>(acc, sG, lane) : 0.f;
       add_ridge<T, FULL>(p, acc, cur.len, lane);
       float minpiv = 3.0e38f;
       float xcol[T];
@@ -954,7 +993,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
         }
         solve_tiles<T>(acc, bcol, xcol, lane);
       }
-      store_row<T>(p, xcol, minpiv, cur.id, lane);
+      store_row<T>(p, xcol, minpiv, wmax, cur.id, lane);
 #ifdef MALS_PROFILING
       if (tr) {
         t3 = __builtin_readcyclecounter();
@@ -1045,6 +1084,7 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
       ch = nch;
       if (nxt.len > 0) chunk_weights_h(p, ch, zscale);
       if (MODE == 0) {
+        const float rmax = p.refine_flag ? __int_as_float(max_entry_bits<T>(acc, lane)) * inv_s2 : 0.f;
         // back to the unscaled system (S^2 is a power of two: exact), on top of the shared Gramian
 #pragma unroll
         for (int t = 0; t < tri(T); ++t) {
@@ -1053,10 +1093,10 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
           for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(acc[t][r], inv_s2, g4[r]);
         }
         add_ridge<T, FULL>(p, acc, cur.len, lane);
-        float minpiv = 3.0e38f;
+        float minpiv = 3.0e38f, wmax;
         float xcol[T];
         if constexpr (T >= 2) {  // the rank-16 updates of the factorization on the f16 pipe as well
-          const float inv_s2row = row_scale<T>(acc, bcol, lane);
+          const float inv_s2row = row_scale<T>(acc, bcol, lane, wmax);
           cholesky_tiles<T, true>(acc, lane, minpiv);
           minpiv *= inv_s2row;
         } else {
@@ -1066,7 +1106,7 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
         if (tr) t2 = __builtin_readcyclecounter();
 #endif
         solve_tiles<T>(acc, bcol, xcol, lane);
-        store_row<T>(p, xcol, minpiv, cur.id, lane);
+        store_row<T>(p, xcol, minpiv, rmax, cur.id, lane);
 #ifdef MALS_PROFILING
         if (tr) {
           const unsigned long long t3 = __builtin_readcyclecounter();
@@ -1136,7 +1176,219 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
     for (int v = 0; v < T; ++v) bcol[v] += bp[v];
   }
   const int n_u = uniform((int)(p.row_ptr[rc.row + 1] - p.row_ptr[rc.row]));
-  finish_row<T>(p, acc, bcol, n_u, rc.row, lane);
+  float rmax = 0.f;
+  if (p.refine_flag) {
+    if (p.flags & 2) {
+      rmax = __int_as_float(max_entry_bits<T>(acc, lane));
+    } else {
+      rmax = row_part_max<T>(acc, reinterpret_cast<const f32x4*>(p.Gf), lane);
+    }
+  }
+  finish_row<T>(p, acc, bcol, n_u, rc.row, lane, rmax);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mixed-precision refinement of the rows the solving kernels marked (store_row: largest entry of W over smallest
+// pivot above refine_limit).  The reference solves every row in fp64 (ALS:494, CMLSS:37-55); an fp32 accumulation +
+// factorization loses about cond(W) 6e-8 of x, which passes the 1e-4 bar up to cond(W) ~ 1e3 and not beyond
+// (confidence weights alpha |r| in the thousands against a small lambda).  Per marked row, one wave:
+//   W~, b~ and the Cholesky factor exactly as the fp32 rows kernel builds them, x0 = W~^-1 b~;
+//   then conjugate gradients on the EXACT system W x = b, preconditioned with that factor (in registers):
+//   every product with W is  sum_e w_e (y_e . v) y_e + G v + rho v  in fp64, straight from the entries, the fp32
+//   factor rows and the fp64 Gramian -- one pass over the row's entries per iteration.  With a good factor this is
+//   classical iterative refinement (one or two passes); with a poor one (cond(W) 1e6 and more, where a plain
+//   correction step can make a good x0 WORSE -- measured) it still converges, monotonically in the energy norm.
+//   Stops when a step is below 1e-6 |x| (at most 12 iterations).
+// Rows of any length (a long row is simply gathered by its one wave: this is the slow path), either solve path
+// (a dual row is re-solved in the original basis, after the un-rotation).  Not marked: nothing happens.
+struct RefineParams {
+  SolveParams p;                  // the half-iteration's parameters (gather table, CSR, Gramian image, out, flags)
+  const double* G;                // k x k row-major fp64 Gramian of the gathered side
+  unsigned long long* n_refined;  // statistics
+  int64_t row_begin, row_end;     // local rows of the chunk
+  double alpha, lambda_alpha;
+};
+
+// out = (with_rhs ? b : 0) - W v  for the row's exact system, fp64.  v and out in "col" layout: every lane (g, c)
+// holds features 16 v' + c (all four lane groups the same values).  xs: 16 T doubles of LDS owned by the wave.
+template <int T>
+__device__ __forceinline__ void refine_matvec(const RefineParams& q, int64_t begin, int len, int lane, volatile double* xs,
+                                              const double (&v)[T], bool with_rhs, double (&out)[T]) {
+  const SolveParams& p = q.p;
+  const int g = lane >> 4, c = lane & 15;
+  const double base_w = (p.flags & 2) ? 1.0 : 0.0;
+#pragma unroll
+  for (int u = 0; u < T; ++u) out[u] = 0.0;
+  for (int s4 = 0; s4 < len; s4 += 4) {  // four entries per step, one per lane group
+    const int e = s4 + g;
+    const bool ok = e < len;
+    const int64_t at = begin + (ok ? e : len - 1);
+    const int col = p.col[at];
+    const double r = (double)p.val[at];
+    const float* yp = p.M + ((uint64_t)(uint32_t)col * (uint32_t)p.ldm + (uint32_t)c);
+    double y[T];
+#pragma unroll
+    for (int u = 0; u < T; ++u) y[u] = (double)yp[16 * u];
+    double dot = 0.0;
+#pragma unroll
+    for (int u = 0; u < T; ++u) dot = fma(y[u], v[u], dot);
+    for (int off = 8; off > 0; off >>= 1) dot += __shfl_xor(dot, off);  // over the 16 lanes of the group
+    double wgt, cb;
+    if (p.flags & 1) {  // ALS:466-469
+      wgt = base_w;
+      cb = r;
+    } else {            // ALS:471-482
+      const double ar = q.alpha * fabs(r);
+      wgt = base_w + ar;
+      cb = r > 0.0 ? 1.0 + ar : 0.0;
+    }
+    const double t = ok ? (with_rhs ? cb : 0.0) - wgt * dot : 0.0;
+#pragma unroll
+    for (int u = 0; u < T; ++u) out[u] = fma(t, y[u], out[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < T; ++u) {
+    out[u] += __shfl_xor(out[u], 16);
+    out[u] += __shfl_xor(out[u], 32);
+  }
+  if (!(p.flags & 2)) {  // - G v: v through LDS, row j of the (symmetric) Gramian read along the features
+    if (g == 0) {
+#pragma unroll
+      for (int u = 0; u < T; ++u) xs[16 * u + c] = v[u];
+    }
+    __builtin_amdgcn_wave_barrier();
+    double gv[T];
+#pragma unroll
+    for (int u = 0; u < T; ++u) gv[u] = 0.0;
+    for (int j = g; j < p.k; j += 4) {
+      const double vj = xs[j];
+      const double* gr = q.G + (int64_t)j * p.k;
+#pragma unroll
+      for (int u = 0; u < T; ++u) {
+        const int f = 16 * u + c;
+        gv[u] = fma(f < p.k ? gr[f] : 0.0, vj, gv[u]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < T; ++u) {
+      gv[u] += __shfl_xor(gv[u], 16);
+      gv[u] += __shfl_xor(gv[u], 32);
+      out[u] -= gv[u];
+    }
+  }
+  const double rho = q.lambda_alpha * (double)len;
+#pragma unroll
+  for (int u = 0; u < T; ++u) out[u] -= rho * v[u];
+}
+
+// sum over the features of a[.] b[.] (col layout: 16 lanes x T values), the same in every lane
+template <int T>
+__device__ __forceinline__ double refine_dot(const double (&a)[T], const double (&b)[T]) {
+  double d = 0.0;
+#pragma unroll
+  for (int u = 0; u < T; ++u) d = fma(a[u], b[u], d);
+  for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off);
+  return d;
+}
+
+template <int T>
+__global__ __launch_bounds__(256, T >= 7 ? 1 : 2) void als_refine_kernel(RefineParams q) {
+  const SolveParams& p = q.p;
+  __shared__ double sx[4][16 * T];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, n_waves = (int64_t)gridDim.x * 4;
+  unsigned long long done = 0;
+  // 64 rows per wave and step: one flag byte per lane, then the marked ones of the block one after the other
+  for (int64_t blk = q.row_begin + 64 * wave; blk < q.row_end; blk += 64 * n_waves) {
+    unsigned long long marks = __ballot(blk + lane < q.row_end && p.refine_flag[blk + lane] != 0);
+    while (marks) {
+      const int64_t row = blk + __builtin_ctzll(marks);
+      marks &= marks - 1;
+      const int64_t begin = uniform64(p.row_ptr[row]);
+      const int len = (int)(uniform64(p.row_ptr[row + 1]) - begin);
+      if (len <= 0) continue;
+      // ---- preconditioner: the fp32 system and its factor, as als_persistent_kernel<T, 2, 0> builds them
+      f32x4 acc[tri(T)];
+      init_acc<T>(p, acc, lane);
+      float bpart[T];
+#pragma unroll
+      for (int u = 0; u < T; ++u) bpart[u] = 0.f;
+      {
+        Pipe<T, 2> pp;
+        pp.wcur = pp.cbcur = 0.f;
+        pp.colpf = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int u = 0; u < T; ++u) pp.y[i][u] = 0.f;
+        pp.ch = chunk_issue(p, begin, len, 0, lane);
+        chunk_weights(p, pp.ch);
+        prime_row<T, 2, true>(p, lane, pp);
+        gather_row<T, 2, true>(p, begin, len, lane, pp, acc, bpart);
+      }
+      float bcol[T], xcol[T];
+#pragma unroll
+      for (int u = 0; u < T; ++u) bcol[u] = reduce_groups(bpart[u], lane);
+      add_ridge<T, false>(p, acc, len, lane);
+      float minpiv = 3.0e38f;
+      cholesky_tiles<T>(acc, lane, minpiv);
+      if (!(minpiv > p.sing_threshold)) continue;  // the solving kernel has reported the row
+      solve_tiles<T>(acc, bcol, xcol, lane);
+      // ---- preconditioned conjugate gradients on the exact system, from x0
+      double x[T], r[T], pd[T], wp[T];
+#pragma unroll
+      for (int u = 0; u < T; ++u) x[u] = (double)xcol[u];
+      refine_matvec<T>(q, begin, len, lane, sx[wv], x, true, r);  // r = b - W x0
+      float rf[T], zf[T];
+#pragma unroll
+      for (int u = 0; u < T; ++u) rf[u] = (float)r[u];
+      solve_tiles<T>(acc, rf, zf, lane);
+#pragma unroll
+      for (int u = 0; u < T; ++u) pd[u] = (double)zf[u];
+      double rz = refine_dot<T>(r, pd);
+      for (int it = 0; it < 12 && rz > 0.0; ++it) {
+        refine_matvec<T>(q, begin, len, lane, sx[wv], pd, false, wp);  // wp = -W p
+        const double pwp = -refine_dot<T>(pd, wp);
+        if (!(pwp > 0.0)) break;
+        const double a = rz / pwp;
+        double smax = 0.0, xmax = 0.0;
+#pragma unroll
+        for (int u = 0; u < T; ++u) {
+          x[u] = fma(a, pd[u], x[u]);
+          r[u] = fma(a, wp[u], r[u]);
+          smax = fmax(smax, fabs(a * pd[u]));
+          xmax = fmax(xmax, fabs(x[u]));
+        }
+        for (int off = 8; off > 0; off >>= 1) {
+          smax = fmax(smax, __shfl_xor(smax, off));
+          xmax = fmax(xmax, __shfl_xor(xmax, off));
+        }
+        if (!(smax > 1e-6 * xmax)) break;  // uniform: every lane group holds the same vectors
+#pragma unroll
+        for (int u = 0; u < T; ++u) rf[u] = (float)r[u];
+        solve_tiles<T>(acc, rf, zf, lane);
+        double z[T];
+#pragma unroll
+        for (int u = 0; u < T; ++u) z[u] = (double)zf[u];
+        const double rz2 = refine_dot<T>(r, z);
+        const double beta = rz2 / rz;
+        rz = rz2;
+#pragma unroll
+        for (int u = 0; u < T; ++u) pd[u] = fma(beta, pd[u], z[u]);
+      }
+      if (lane < 16) {
+        float* o = p.out + row * p.k;
+#pragma unroll
+        for (int u = 0; u < T; ++u) {
+          const int feat = 16 * u + lane;
+          if (feat < p.k) o[feat] = (float)x[u];
+        }
+      }
+      ++done;
+    }
+  }
+  if (lane == 0 && done) atomicAdd(q.n_refined, done);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -48,6 +48,8 @@ struct DualParams {
   float lambda_alpha;
   float sqrt_w_max;         // sqrt(alpha * max |r|): bound of C^1/2
   unsigned* xbound;         // bit pattern of the largest |x'| stored so far (operand scale of the un-rotation)
+  uint8_t* refine_flag;     // as in SolveParams: rows whose S = I + Z Z^T is ill-conditioned for fp32 go to als_refine_kernel
+  float refine_limit;
 };
 
 struct RotateParams {
@@ -465,13 +467,14 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
         for (int r = 0; r < 4; ++r)
           acc[tidx(TN, i, j)][r] = i == j ? fmaf(acc[tidx(TN, i, j)][r], inv_sc2, idn[r]) : acc[tidx(TN, i, j)][r] * inv_sc2;
     // (4) S v = q: Cholesky + triangular solves on the TN x TN tiles, in registers
-    float minpiv = 3.0e38f;
+    float minpiv = 3.0e38f, smax;
     float vcol[TN];
     if constexpr (TN >= 2) {
-      const float inv_s2row = row_scale<TN>(acc, qcol, lane);
+      const float inv_s2row = row_scale<TN>(acc, qcol, lane, smax);
       cholesky_tiles<TN, true>(acc, lane, minpiv);
       minpiv *= inv_s2row;
     } else {
+      smax = __int_as_float(max_entry_bits<TN>(acc, lane));
       cholesky_tiles<TN>(acc, lane, minpiv);
     }
     solve_tiles<TN>(acc, qcol, vcol, lane);
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
     }
     const bool bad = !(minpiv > 0.5f);  // S >= I: only a non-finite input gets here
     if (bad && lane == 0) atomicMin(p.bad_row, (unsigned long long)cur.id);
+    if (!bad && p.refine_flag && smax > p.refine_limit * minpiv && lane == 0) p.refine_flag[cur.id] = 1;
     {
       float* o = p.out + (int64_t)cur.id * p.k;
       const float* dc = sD + (n - 1) * KP + c;

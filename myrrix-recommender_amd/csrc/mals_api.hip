@@ -56,6 +56,8 @@ struct SideState {
   RowC* rowsC = nullptr;
   int64_t nC = 0;
   float* scratch = nullptr;
+  uint8_t* refine = nullptr;   // per local row: marked for als_refine_kernel by the kernel that solved it
+  size_t refine_cap = 0;
   int32_t col_min = 0, col_max = -1;  // range of the column indices (checked against the opposite replica)
   float max_abs_val = 0.f;  // bound on |value| used for the operand scale (>= local_max_abs_val)
   float local_max_abs_val = 0.f;  // largest |value| of the shard
@@ -106,6 +108,10 @@ struct mals_handle_s {
   // (pad_rows_kernel), rebuilt once per half-iteration
   float* d_Mp = nullptr;
   size_t Mp_cap = 0;          // floats
+  // mixed-precision refinement of ill-conditioned rows (als_refine_kernel): estimate above which a row is re-solved
+  // (MALS_REFINE_LIMIT / mals_set_refine_limit; 0 = off), rows refined so far (device counter)
+  float refine_limit = 128.f;
+  unsigned long long* d_refined = nullptr;
   int pad_side = -1;          // solved side whose opposite matrix the copy holds, version of that side's G and
   uint64_t pad_version = 0;   // factor-upload count at the time of the copy
   uint64_t pad_epoch = 0;
@@ -134,7 +140,7 @@ struct mals_handle_s {
   SideState side[2];
   hipStream_t stream = nullptr;
   std::string err;
-  unsigned long long* d_bad = nullptr;   // [2] per side
+  unsigned long long* d_bad = nullptr;   // [4]: first non-PD row per side, then the smallest-pivot suspect per side
   unsigned long long* h_bad = nullptr;   // pinned
   int32_t sing_side = -1;
   int64_t sing_row = -1;
@@ -211,6 +217,8 @@ void free_matrix(SideState& s) {
   free_dev(s.itemsB);
   free_dev(s.rowsC);
   free_dev(s.scratch);
+  free_dev(s.refine);
+  s.refine_cap = 0;
   s.nA = s.nB = s.nC = 0;
   s.nnzA = s.nnzB = 0;
   s.chunks.clear();
@@ -618,6 +626,31 @@ int launch_solve(mals_handle h, SideState& s, const SolveParams& p, int chunk, i
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
 }
 
+// ---- refinement of the rows the solving kernels marked (als_refine_kernel) -------------------------
+template <int T>
+int launch_refine_T(mals_handle h, const RefineParams& q) {
+  // reads the marks on the device: no host round trip.  A resident-sized grid; a chunk without marked rows costs
+  // one pass over its flag bytes.
+  const int64_t rows = q.row_end - q.row_begin;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows + 255) / 256, (int64_t)h->n_cu * 8));
+  hipLaunchKernelGGL((als_refine_kernel<T>), dim3(grid), dim3(256), 0, h->stream, q);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+int launch_refine(mals_handle h, const RefineParams& q) {
+  switch (h->T) {
+    case 1: return launch_refine_T<1>(h, q);
+    case 2: return launch_refine_T<2>(h, q);
+    case 3: return launch_refine_T<3>(h, q);
+    case 4: return launch_refine_T<4>(h, q);
+    case 5: return launch_refine_T<5>(h, q);
+    case 6: return launch_refine_T<6>(h, q);
+    case 7: return launch_refine_T<7>(h, q);
+    case 8: return launch_refine_T<8>(h, q);
+  }
+  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
 // ---- dual path (dual_kernels.h) ------------------------------------------------------------------
 template <int T, bool LISTED, bool F64>
 int launch_rotate_T(mals_handle h, const RotateParams& rp) {
@@ -864,6 +897,8 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
   dp.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);
   dp.sqrt_w_max = (float)std::sqrt(std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
   dp.xbound = h->d_zbound + 1;
+  dp.refine_flag = h->refine_limit > 0.f ? s.refine : nullptr;
+  dp.refine_limit = h->refine_limit;
   const WorkItem* base = s.itemsA + cr.offA + cr.nA;
   int64_t off = 0;
   PendingEvent pe;
@@ -1222,14 +1257,17 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   }
   std::memset(&h->stats, 0, sizeof(h->stats));
   h->stats.struct_size = (int32_t)sizeof(mals_stats);
-  if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc(&h->h_bad, 2 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipSetDevice(cfg->device) != hipSuccess || hipMalloc(&h->d_bad, 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc(&h->h_bad, 4 * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&h->d_zscale, 4 * sizeof(float)) != hipSuccess || hipMalloc(&h->d_maxabs, 4 * sizeof(unsigned)) != hipSuccess ||
       hipMalloc(&h->d_colrange, 2 * sizeof(int)) != hipSuccess ||
-      hipMemset(h->d_bad, 0xff, 2 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc(&h->d_refined, sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(h->d_refined, 0, sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(h->d_bad, 0xff, 4 * sizeof(unsigned long long)) != hipSuccess) {
     delete h;
     return MALS_HIP_ERROR;
   }
+  if (const char* e = std::getenv("MALS_REFINE_LIMIT")) h->refine_limit = std::max(0.f, (float)std::atof(e));
 #ifdef MALS_PROFILING
   if (std::getenv("MALS_DEBUG_TRACE")) {
     (void)hipMalloc(&h->d_trace, 64 * 64 * 6 * sizeof(unsigned long long));
@@ -1273,6 +1311,7 @@ int mals_destroy(mals_handle h) {
     free_dev(s.partials);
   }
   free_dev(h->d_bad);
+  free_dev(h->d_refined);
   free_dev(h->d_zscale);
   free_dev(h->d_maxabs);
   free_dev(h->d_colrange);
@@ -1667,6 +1706,19 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.rowsC = s.rowsC;
   p.scratch = s.scratch;
   p.bad_row = h->d_bad + side;
+  p.suspect = h->d_bad + 2 + side;
+  p.refine_flag = nullptr;
+  p.refine_limit = h->refine_limit;
+  if (h->refine_limit > 0.f) {
+    if (s.refine_cap < (size_t)s.n_local) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      free_dev(s.refine);
+      s.refine_cap = 0;
+      HIPCHK(h, hipMalloc(&s.refine, (size_t)s.n_local));
+      s.refine_cap = (size_t)s.n_local;
+    }
+    p.refine_flag = s.refine;
+  }
   p.n_work = 0;
   p.trace = h->d_trace;
   p.trace_start = 0;
@@ -1707,8 +1759,13 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
     HIPCHK(h, hipMemcpyAsync(h->h_G, o.G, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_G, h->stream));
   }
+  const int64_t want_chunk_rows = s.chunk_rows_override >= 0 ? s.chunk_rows_override : h->cfg.chunk_rows;
+  const int64_t rows_per_chunk = want_chunk_rows > 0 ? want_chunk_rows : std::max<int64_t>(s.n_local, 1);  // as build_work_lists
   for (int c = chunk_begin; c < chunk_end; ++c) {
     const SideState::ChunkRange& cr = s.chunks[(size_t)c];
+    const int64_t row0 = std::min<int64_t>(s.n_local, (int64_t)c * rows_per_chunk);
+    const int64_t row1 = std::min<int64_t>(s.n_local, (int64_t)(c + 1) * rows_per_chunk);
+    if (p.refine_flag && row1 > row0) HIPCHK(h, hipMemsetAsync(s.refine + row0, 0, (size_t)(row1 - row0), h->stream));
     bool dual_now = want_dual && !dual_stale && h->dual_ok;
     if (want_dual && dual_stale && c == chunk_begin) {
       if (int rc = launch_solve(h, s, p, c, LISTS_OWN)) return rc;  // direct lists first ...
@@ -1723,6 +1780,17 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
       if (int rc = launch_solve(h, s, p, c, dual_now ? LISTS_OWN : (LISTS_OWN | LISTS_DUAL_ROWS))) return rc;
       if (dual_now && cr.n_dual())
         if (int rc = launch_dual_chunk(h, side, c)) return rc;
+    }
+    if (p.refine_flag && row1 > row0) {  // behind every kernel of the chunk (the un-rotation of the dual rows included)
+      RefineParams q;
+      q.p = p;
+      q.G = o.G;
+      q.n_refined = h->d_refined;
+      q.row_begin = row0;
+      q.row_end = row1;
+      q.alpha = h->cfg.alpha;
+      q.lambda_alpha = h->cfg.lambda * h->cfg.alpha;
+      if (int rc = launch_refine(h, q)) return rc;
     }
     h->stats.rows_solved += cr.nA + cr.nC + cr.n_dual() + cr.nZ;
     h->stats.nnz_gathered += cr.nnzA + cr.nnzB + cr.nnz_dual();
@@ -1764,27 +1832,28 @@ namespace {
 // The reference's SingularMatrixSolverException carries RRQR's getRank(0.01) of the failing row's
 // system (CMLSS:47).  Error path only: rebuild that one k x k system on the host in fp64 from the
 // row's entries, the current opposite factors and their Gramian (ALS:450-492).  0 = unknown.
-int apparent_rank_of_row(mals_handle h, int side, int64_t local_row) {
+// the row's k x k system in fp64 (ALS:450-492); false = could not be rebuilt
+bool build_row_system(mals_handle h, int side, int64_t local_row, std::vector<double>& W) {
   SideState& s = h->side[side];
   SideState& o = h->side[1 - side];
   const int k = h->cfg.features;
-  if (!s.has_matrix || local_row < 0 || local_row >= s.n_local || !o.F) return 0;
+  if (!s.has_matrix || local_row < 0 || local_row >= s.n_local || !o.F) return false;
   const int64_t e0 = s.h_row_ptr[local_row], n_u = s.h_row_ptr[local_row + 1] - e0;
   std::vector<int32_t> col((size_t)n_u);
   std::vector<float> val((size_t)n_u);
   std::vector<int64_t> idx((size_t)n_u);
   std::vector<float> rows((size_t)n_u * k);
-  std::vector<double> W((size_t)k * k, 0.0);
+  W.assign((size_t)k * k, 0.0);
   if (n_u > 0) {
-    if (n_u > (int64_t)INT32_MAX) return 0;
-    if (hipMemcpy(col.data(), s.col + e0, sizeof(int32_t) * (size_t)n_u, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    if (hipMemcpy(val.data(), s.val + e0, sizeof(float) * (size_t)n_u, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (n_u > (int64_t)INT32_MAX) return false;
+    if (hipMemcpy(col.data(), s.col + e0, sizeof(int32_t) * (size_t)n_u, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(val.data(), s.val + e0, sizeof(float) * (size_t)n_u, hipMemcpyDeviceToHost) != hipSuccess) return false;
     for (int64_t e = 0; e < n_u; ++e) idx[e] = col[e];
-    if (mals_get_rows(h, 1 - side, idx.data(), (int32_t)n_u, rows.data()) != MALS_OK) return 0;
+    if (mals_get_rows(h, 1 - side, idx.data(), (int32_t)n_u, rows.data()) != MALS_OK) return false;
   }
   const bool reconstruct = h->cfg.flags & MALS_FLAG_RECONSTRUCT_R;
   if (!(h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED)) {
-    if (!o.G || hipMemcpy(W.data(), o.G, sizeof(double) * W.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (!o.G || hipMemcpy(W.data(), o.G, sizeof(double) * W.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
   }
   for (int64_t e = 0; e < n_u; ++e) {
     const float* y = rows.data() + (size_t)e * k;
@@ -1795,7 +1864,13 @@ int apparent_rank_of_row(mals_handle h, int side, int64_t local_row) {
       for (int c = 0; c < k; ++c) W[(size_t)r * k + c] += w * (double)y[r] * (double)y[c];
   }
   for (int d = 0; d < k; ++d) W[(size_t)d * k + d] += h->cfg.lambda * h->cfg.alpha * (double)n_u;  // ALS:488
-  return mals::PivotedQR(W.data(), k, h->cfg.singularity_threshold).rank(0.01);
+  return true;
+}
+
+int apparent_rank_of_row(mals_handle h, int side, int64_t local_row) {
+  std::vector<double> W;
+  if (!build_row_system(h, side, local_row, W)) return 0;
+  return mals::PivotedQR(W.data(), h->cfg.features, h->cfg.singularity_threshold).rank(0.01);
 }
 
 }  // namespace
@@ -1803,8 +1878,24 @@ int apparent_rank_of_row(mals_handle h, int side, int64_t local_row) {
 int mals_check(mals_handle h) {
   if (!h) return MALS_INVALID_ARG;
   if (int rc = use_device(h)) return rc;
-  HIPCHK(h, hipMemcpyAsync(h->h_bad, h->d_bad, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->h_bad, h->d_bad, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  // The kernels' verdict is "a Cholesky pivot <= threshold"; the reference's is "a diagonal element of R of the
+  // column-pivoted QR <= threshold" (CMLSS:43-54), which can already hold when the smallest (unpivoted) Cholesky
+  // pivot is still 100x the threshold (measured: 63 x 63 Gramian of 63 rows, pivot 5e-5, |R_dd| 2e-6).  So the row with
+  // the smallest pivot within 1024x of the threshold is put to the reference's own test here, in fp64 on the host.
+  for (int sd = 0; sd < 2; ++sd) {
+    const unsigned long long key = h->h_bad[2 + sd];
+    if (h->h_bad[sd] != ~0ull || key == ~0ull) continue;
+    const int64_t row = (int64_t)(key & 0xffffffffull);
+    SideState& s = h->side[sd];
+    std::vector<double> W;
+    if (row < s.n_local && s.h_row_ptr[(size_t)row + 1] - s.h_row_ptr[(size_t)row] <= 200000 && build_row_system(h, sd, row, W) &&
+        !mals::PivotedQR(W.data(), h->cfg.features, h->cfg.singularity_threshold).non_singular())
+      h->h_bad[sd] = (unsigned long long)row;
+  }
+  if (h->h_bad[2] != ~0ull || h->h_bad[3] != ~0ull)
+    HIPCHK(h, hipMemsetAsync(h->d_bad + 2, 0xff, 2 * sizeof(unsigned long long), h->stream));
   for (int sd = 0; sd < 2; ++sd) {
     if (h->h_bad[sd] != ~0ull) {
       h->sing_side = sd;
@@ -2134,6 +2225,7 @@ int mals_reset_stats(mals_handle h) {
   if (int rc = drain_events(h)) return rc;
   std::memset(&h->stats, 0, sizeof(h->stats));
   h->stats.struct_size = (int32_t)sizeof(mals_stats);
+  HIPCHK(h, hipMemsetAsync(h->d_refined, 0, sizeof(unsigned long long), h->stream));
   return MALS_OK;
 }
 
@@ -2141,7 +2233,17 @@ int mals_get_stats(mals_handle h, mals_stats* out) {
   if (!h || !out) return MALS_INVALID_ARG;
   if (int rc = use_device(h)) return rc;
   if (int rc = drain_events(h)) return rc;
+  unsigned long long refined = 0;
+  HIPCHK(h, hipMemcpyAsync(&refined, h->d_refined, sizeof(refined), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->stats.rows_refined = (int64_t)refined;
   *out = h->stats;
+  return MALS_OK;
+}
+
+int mals_set_refine_limit(mals_handle h, double limit) {
+  if (!h || !(limit >= 0.0)) return h ? fail(h, MALS_INVALID_ARG, "refine limit must be >= 0") : MALS_INVALID_ARG;
+  h->refine_limit = (float)limit;
   return MALS_OK;
 }
 

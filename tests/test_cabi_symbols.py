@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     # mals_config: 2 x int32, 3 x double, 6 x int32 ; mals_stats (ABI 2): 2 x int32, 4 x double, 4 x int64, 4 x double,
     # 2 x int64, then 2 x double, 2 x int64, 2 x double, int64, double
     assert ctypes.sizeof(_lib.Config) == 56
-    assert ctypes.sizeof(_lib.Stats) == 184
+    assert ctypes.sizeof(_lib.Stats) == 192
     cfg = _lib.Config()
     assert _lib.load().mals_default_config(ctypes.byref(cfg)) == _lib.OK
     assert cfg.struct_size == 56 and cfg.features == 30            # MatrixFactorizer.java:34
@@ -92,3 +92,4 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.mals_group_world(None) == 0
     assert L.mals_plan_shards(None, 0, 2, -1.0, 64, None) == _lib.INVALID_ARG
     assert L.mals_set_chunk_rows(None, 0, 10) == _lib.INVALID_ARG
+    assert L.mals_set_refine_limit(None, 1024.0) == _lib.INVALID_ARG

@@ -41,9 +41,11 @@ def rows_problem(lengths, n_items, k, seed, negatives=0.1, vscale=1.0, unit=True
     return (row_ptr, col, val), M
 
 
-def solve_x(k, csr, M, **kw):
+def solve_x(k, csr, M, refine_limit=None, **kw):
     n_rows = len(csr[0]) - 1
     with pkg.ALSCore(k, **kw) as core:
+        if refine_limit is not None:
+            core.set_refine_limit(refine_limit)
         core.set_factor_rows(pkg.SIDE_X, n_rows)
         core.set_factor_rows(pkg.SIDE_Y, M.shape[0])
         core.set_matrix(pkg.SIDE_X, *csr)

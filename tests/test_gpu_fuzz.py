@@ -1,0 +1,115 @@
+"""Seeded sweep over the configuration space of one half-iteration pair, HIP path (through the C-ABI) vs the oracle.
+
+Every case draws its own features, shape, density, row-length profile (empty rows, rows shorter than the feature
+count -- the dual path --, rows longer than segment_nnz -- the segment path --), hyper-parameters, mode flags,
+arithmetic mode, solve mode, chunking and stale-row count from a seeded generator, so the sweep is the same on every
+run.  Bar: 1e-4 relative Frobenius on both factor matrices (north_star)."""
+import numpy as np
+import pytest
+
+import myrrix_recommender_amd as pkg
+from myrrix_recommender_amd import _lib
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def draw_case(seed):
+    rng = np.random.default_rng(100_000 + seed)
+    k = int(rng.choice([1, 2, 3, 5, 8, 10, 15, 16, 17, 20, 24, 30, 31, 32, 33, 40, 47, 48, 49, 50, 63, 64, 65, 72, 80, 96, 97, 100,
+                        111, 112, 113, 120, 127, 128]))
+    n_users = int(rng.integers(40, 900))
+    n_items = int(rng.integers(30, 500))
+    # row-length profile of the user side: a mix of empty, short, medium and a few very long rows
+    lens = np.zeros(n_users, dtype=np.int64)
+    kind = rng.random(n_users)
+    short = kind < 0.45
+    lens[short] = rng.integers(1, max(2, min(k + 8, n_items)), size=int(short.sum()))
+    mid = (kind >= 0.45) & (kind < 0.9)
+    lens[mid] = rng.integers(1, max(2, min(3 * k + 16, n_items)), size=int(mid.sum()))
+    longr = kind >= 0.97
+    lens[longr] = rng.integers(max(1, n_items // 2), n_items + 1, size=int(longr.sum()))
+    lens = np.minimum(lens, n_items)
+    flags = int(rng.choice([0, 0, 0, pkg.FLAG_RECONSTRUCT_R, pkg.FLAG_LOSS_IGNORES_UNSPECIFIED,
+                            pkg.FLAG_RECONSTRUCT_R | pkg.FLAG_LOSS_IGNORES_UNSPECIFIED]))
+    if flags & pkg.FLAG_LOSS_IGNORES_UNSPECIFIED:
+        lens = np.maximum(lens, 1)   # W does not start from G there: an empty row is singular in the reference too (own test)
+    rows = np.repeat(np.arange(n_users), lens)
+    cols = np.concatenate([rng.choice(n_items, size=int(n), replace=False) for n in lens] + [np.zeros(0, dtype=np.int64)])
+    if flags & pkg.FLAG_LOSS_IGNORES_UNSPECIFIED:
+        missing = np.setdiff1d(np.arange(n_items), cols)
+        rows = np.concatenate([rows, rng.integers(0, n_users, size=len(missing))])
+        cols = np.concatenate([cols, missing])
+    scale = float(rng.choice([1.0, 1.0, 1.0, 0.01, 30.0]))
+    vals = (rng.integers(1, 6, size=len(cols)) * scale).astype(np.float32)
+    neg = rng.random(len(cols)) < float(rng.choice([0.0, 0.1, 0.4]))
+    vals = np.where(neg, -vals, vals).astype(np.float32)
+
+    def csr(r, c, v, n):
+        order = np.lexsort((c, r))
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(ptr, r.astype(np.int64) + 1, 1)
+        return np.cumsum(ptr).astype(np.int64), c[order].astype(np.int32), v[order].astype(np.float32)
+
+    r_csr = csr(rows, cols, vals, n_users)
+    c_csr = csr(cols, rows, vals, n_items)
+    n_stale = int(rng.choice([0, 0, 3]))
+    Y0 = rng.standard_normal((n_items + n_stale, k)).astype(np.float32)
+    Y0 /= np.maximum(np.linalg.norm(Y0, axis=1, keepdims=True), 1e-6).astype(np.float32)
+    Y0 *= np.float32(rng.choice([1.0, 1.0, 0.2, 3.0]))
+    cfg = dict(alpha=float(rng.choice([1.0, 1.0, 0.5, 40.0])), lam=float(rng.choice([0.1, 0.1, 0.01, 1.0])), flags=flags,
+               segment_nnz=int(rng.choice([0, 0, 64, 128])), chunk_rows=int(rng.choice([0, 0, 97, 256])),
+               gramian_mode=int(rng.choice([0, 0, _lib.GRAMIAN_FP32, _lib.GRAMIAN_SPLIT_F16])),
+               solve_mode=int(rng.choice([0, 0, _lib.SOLVE_DIRECT, _lib.SOLVE_DUAL])))
+    return k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_seeded_configuration_sweep(seed):
+    k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg = draw_case(seed)
+    kw = dict(alpha=cfg["alpha"], lam=cfg["lam"], flags=cfg["flags"], threads=4)
+    # the oracle's verdicts first: with fewer rows than features on the other side G is rank deficient and an EMPTY
+    # row's system (W = G) is singular in the reference (SingularMatrixSolverException) -- the HIP path must say so too
+    try:
+        Xo = oracle.half_iteration(*r_csr, Y0, **kw)
+    except oracle.SingularMatrix:
+        Xo = None
+    Yo = None
+    if Xo is not None:
+        try:
+            Yo = oracle.half_iteration(*c_csr, Xo, **kw)
+        except oracle.SingularMatrix:
+            pass
+    with pkg.ALSCore(k, **cfg) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items + n_stale)
+        core.set_matrix(pkg.SIDE_X, *r_csr)
+        core.set_matrix(pkg.SIDE_Y, *c_csr)
+        core.set_factors(pkg.SIDE_Y, Y0)
+        if Xo is None:
+            with pytest.raises(pkg.SingularSystem):
+                core.half_iteration(pkg.SIDE_X)
+                core.check()
+            return
+        core.half_iteration(pkg.SIDE_X)
+        core.check()
+        X = core.get_factors(pkg.SIDE_X)
+        assert np.all(np.isfinite(X))
+        assert rel(X, Xo) < REL_TOL, (seed, k, cfg, rel(X, Xo))
+        if Yo is None:
+            with pytest.raises(pkg.SingularSystem):
+                core.half_iteration(pkg.SIDE_Y)
+                core.check()
+            return
+        core.half_iteration(pkg.SIDE_Y)
+        core.check()
+        Y = core.get_factors(pkg.SIDE_Y)
+    assert np.all(np.isfinite(Y))
+    assert rel(Y[:n_items], Yo) < REL_TOL, (seed, k, cfg, rel(Y[:n_items], Yo))
+    if n_stale:
+        assert np.array_equal(Y[n_items:], Y0[n_items:])   # stale rows are never re-solved (ALS:304-308)
