@@ -855,13 +855,24 @@ __device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T
 }
 
 // store x (the cast to fp32 of CMS:40-42 is implicit: all arithmetic here is fp32); flag non-PD rows
-// rmax = the largest entry of the row's own part sum w y y^T of W: rmax / minpiv estimates from below how much the
-// rounding of that fp32 accumulation is amplified in x (the shared Gramian under it is an fp64 sum rounded once and,
-// measured, harmless even where it dominates cond(W)); rows above refine_limit are marked for als_refine_kernel
+// wmax = max(largest entry of the row's own part sum w y y^T, a quarter of the largest entry of W): wmax / minpiv
+// estimates from below how much the fp32 roundings are amplified in x.  The row's own part is an fp32 accumulation
+// (measured 2-5e-7 of x per unit of the ratio); the shared Gramian under it is an fp64 sum rounded once and only
+// suffers the factorization's rounding (measured 1e-7 per unit, on rows of the C5 shape whose W is all Gramian) --
+// but it must count: with reconstructR there is no row part at all, and G + rho I with fewer factor rows than
+// features is as ill-conditioned as anything (sweep cases 2145, 2550).  Rows above refine_limit are marked.
 template <int T>
 __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T], float minpiv, float wmax, int row, int lane) {
   if (!(minpiv > p.sing_threshold)) {
-    if (lane == 0) atomicMin(p.bad_row, (unsigned long long)row);
+    // an fp32 pivot at the threshold is rounding noise once cond(W) passes ~1e7: the verdict belongs to the fp64
+    // restatement (als_exact_kernel, mark 2); without a mark array this kernel's word is final
+    if (lane == 0) {
+      if (p.refine_flag) {
+        p.refine_flag[row] = 2;
+      } else {
+        atomicMin(p.bad_row, (unsigned long long)row);
+      }
+    }
 #pragma unroll
     for (int v = 0; v < T; ++v) xcol[v] = 0.f;
   } else {
@@ -870,7 +881,7 @@ __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T]
       // same-address atomics serialise: only rows that lower the minimum issue one
       if (key < __builtin_nontemporal_load(p.suspect)) atomicMin(p.suspect, key);
     }
-    if (p.refine_flag && wmax > p.refine_limit * minpiv && lane == 0) p.refine_flag[row] = 1;
+    if (p.refine_flag && p.refine_limit > 0.f && wmax > p.refine_limit * minpiv && lane == 0) p.refine_flag[row] = 1;
   }
   if (lane < 16) {
     float* o = p.out + (int64_t)row * p.k;
@@ -889,9 +900,10 @@ __device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tr
   add_ridge<T>(p, acc, n_u, lane);
   float minpiv = 3.0e38f;
   float xcol[T];
+  const float wmax = fmaxf(rmax, 0.25f * __int_as_float(max_entry_bits<T>(acc, lane)));
   cholesky_tiles<T>(acc, lane, minpiv);
   solve_tiles<T>(acc, bcol, xcol, lane);
-  store_row<T>(p, xcol, minpiv, rmax, row, lane);
+  store_row<T>(p, xcol, minpiv, wmax, row, lane);
 }
 
 __device__ __forceinline__ WorkItem load_item(const SolveParams& p, int64_t it) {
@@ -968,7 +980,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
     if (prime_next) pp.ch = chunk_issue(p, nxt.begin, nxt.len, 0, lane);
     const WorkItem nxt2 = load_item(p, it + 2 * n_waves);
     if (MODE == 0) {
-      const float wmax = p.refine_flag ? row_part_max<T>(acc, sG, lane) : 0.f;
+      const float wmax = p.refine_flag ? fmaxf(row_part_max<T>(acc, sG, lane), 0.25f * __int_as_float(max_entry_bits<T>(acc, lane))) : 0.f;
       add_ridge<T, FULL>(p, acc, cur.len, lane);
       float minpiv = 3.0e38f;
       float xcol[T];
@@ -1100,13 +1112,14 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
           cholesky_tiles<T, true>(acc, lane, minpiv);
           minpiv *= inv_s2row;
         } else {
+          wmax = __int_as_float(max_entry_bits<T>(acc, lane));
           cholesky_tiles<T>(acc, lane, minpiv);
         }
 #ifdef MALS_PROFILING
         if (tr) t2 = __builtin_readcyclecounter();
 #endif
         solve_tiles<T>(acc, bcol, xcol, lane);
-        store_row<T>(p, xcol, minpiv, rmax, cur.id, lane);
+        store_row<T>(p, xcol, minpiv, fmaxf(rmax, 0.25f * wmax), cur.id, lane);
 #ifdef MALS_PROFILING
         if (tr) {
           const unsigned long long t3 = __builtin_readcyclecounter();
@@ -1301,7 +1314,7 @@ __global__ __launch_bounds__(256, T >= 7 ? 1 : 2) void als_refine_kernel(RefineP
   unsigned long long done = 0;
   // 64 rows per wave and step: one flag byte per lane, then the marked ones of the block one after the other
   for (int64_t blk = q.row_begin + 64 * wave; blk < q.row_end; blk += 64 * n_waves) {
-    unsigned long long marks = __ballot(blk + lane < q.row_end && p.refine_flag[blk + lane] != 0);
+    unsigned long long marks = __ballot(blk + lane < q.row_end && p.refine_flag[blk + lane] == 1);
     while (marks) {
       const int64_t row = blk + __builtin_ctzll(marks);
       marks &= marks - 1;
@@ -1333,7 +1346,10 @@ __global__ __launch_bounds__(256, T >= 7 ? 1 : 2) void als_refine_kernel(RefineP
       add_ridge<T, false>(p, acc, len, lane);
       float minpiv = 3.0e38f;
       cholesky_tiles<T>(acc, lane, minpiv);
-      if (!(minpiv > p.sing_threshold)) continue;  // the solving kernel has reported the row
+      if (!(minpiv > p.sing_threshold)) {  // no usable fp32 factor: the fp64 restatement takes the row
+        if (lane == 0) p.refine_flag[row] = 2;
+        continue;
+      }
       solve_tiles<T>(acc, bcol, xcol, lane);
       // ---- preconditioned conjugate gradients on the exact system, from x0
       double x[T], r[T], pd[T], wp[T];
@@ -1347,6 +1363,7 @@ __global__ __launch_bounds__(256, T >= 7 ? 1 : 2) void als_refine_kernel(RefineP
 #pragma unroll
       for (int u = 0; u < T; ++u) pd[u] = (double)zf[u];
       double rz = refine_dot<T>(r, pd);
+      bool converged = !(rz > 0.0);
       for (int it = 0; it < 12 && rz > 0.0; ++it) {
         refine_matvec<T>(q, begin, len, lane, sx[wv], pd, false, wp);  // wp = -W p
         const double pwp = -refine_dot<T>(pd, wp);
@@ -1364,7 +1381,10 @@ __global__ __launch_bounds__(256, T >= 7 ? 1 : 2) void als_refine_kernel(RefineP
           smax = fmax(smax, __shfl_xor(smax, off));
           xmax = fmax(xmax, __shfl_xor(xmax, off));
         }
-        if (!(smax > 1e-6 * xmax)) break;  // uniform: every lane group holds the same vectors
+        if (!(smax > 1e-6 * xmax)) {  // uniform: every lane group holds the same vectors
+          converged = true;
+          break;
+        }
 #pragma unroll
         for (int u = 0; u < T; ++u) rf[u] = (float)r[u];
         solve_tiles<T>(acc, rf, zf, lane);
@@ -1377,6 +1397,7 @@ __global__ __launch_bounds__(256, T >= 7 ? 1 : 2) void als_refine_kernel(RefineP
 #pragma unroll
         for (int u = 0; u < T; ++u) pd[u] = fma(beta, pd[u], z[u]);
       }
+      if (!converged && lane == 0) p.refine_flag[row] = 2;  // the factor is no preconditioner: fp64 restatement
       if (lane < 16) {
         float* o = p.out + row * p.k;
 #pragma unroll
@@ -1389,6 +1410,127 @@ __global__ __launch_bounds__(256, T >= 7 ? 1 : 2) void als_refine_kernel(RefineP
     }
   }
   if (lane == 0 && done) atomicAdd(q.n_refined, done);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Last resort: the reference's arithmetic, restated on the device in fp64, one workgroup per row with the k x k
+// system in LDS (k = 128: 132 KB of the CU's 160).  For the rows on which the fp32 factorization gives no usable
+// answer at all -- a pivot at or below the singularity threshold, which at cond(W) ~ 1e7 and beyond is rounding
+// noise and not a verdict (measured: lossIgnoresUnspecified with lambda = 0.01 and factor rows of norm 30, the
+// reference solves such rows, fp32 calls them singular) -- and, under lossIgnoresUnspecified, for every marked
+// row: there W starts from the row's own sum of (float)(y_r y_c) (ALS:524-539 rounds each product to fp32, like
+// MU:232), which conjugate gradients on the exact system cannot reproduce and this kernel does, product for
+// product.  Then W += (y_r (c_u - 1)) y_c in fp64 in the reference's order (ALS:474-477), the ridge (ALS:488),
+// an LDL^T in fp64 -- the verdict "singular" is given HERE (pivot <= threshold), or by mals_check's pivoted QR
+// for the smallest-pivot suspect -- and x cast to fp32 (CMS:40-42).  Slow (tens of microseconds per row and CU);
+// rows of level `level` and above in refine_flag: 1 = marked ill-conditioned, 2 = no usable fp32 factor.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void als_exact_kernel(RefineParams q, int level) {
+  const SolveParams& p = q.p;
+  extern __shared__ double lds[];
+  const int k = p.k, ld = k + 1;
+  double* W = lds;                       // k x (k + 1)
+  double* bv = W + (size_t)k * ld;       // k
+  double* yd = bv + k;                   // k: the entry's factor row, widened
+  float* yf = reinterpret_cast<float*>(yd + k);   // k: the same in fp32
+  int* list = reinterpret_cast<int*>(yf + k);     // up to 256 marked rows of the block + count
+  __shared__ int n_marked;
+  __shared__ double s_piv, s_minpiv;
+  const int tid = threadIdx.x;
+  unsigned long long done = 0;
+  for (int64_t blk = q.row_begin + 256 * (int64_t)blockIdx.x; blk < q.row_end; blk += 256 * (int64_t)gridDim.x) {
+    if (tid == 0) n_marked = 0;
+    __syncthreads();
+    if (blk + tid < q.row_end && p.refine_flag[blk + tid] >= level) list[atomicAdd(&n_marked, 1)] = tid;
+    __syncthreads();
+    const int nm = n_marked;
+    for (int mi = 0; mi < nm; ++mi) {
+      const int64_t row = blk + list[mi];   // arrival order: the rows are independent
+      const int64_t begin = p.row_ptr[row];
+      const int64_t len = p.row_ptr[row + 1] - begin;
+      for (int e = tid; e < k * k; e += 256) {
+        const int r = e / k, c = e - r * k;
+        W[r * ld + c] = (p.flags & 2) ? 0.0 : q.G[(int64_t)r * k + c];   // ALS:447-450
+      }
+      if (tid < k) bv[tid] = 0.0;
+      __syncthreads();
+      for (int64_t en = 0; en < len; ++en) {
+        const int col = p.col[begin + en];
+        const double xu = (double)p.val[begin + en];
+        if (tid < k) {
+          const float y = p.M[(uint64_t)(uint32_t)col * (uint32_t)p.ldm + (uint32_t)tid];
+          yf[tid] = y;
+          yd[tid] = (double)y;
+        }
+        __syncthreads();
+        const double cu1 = (p.flags & 1) ? 0.0 : q.alpha * fabs(xu);   // c_u - 1 (ALS:471)
+        for (int e = tid; e < k * k; e += 256) {
+          const int r = e / k, c = e - r * k;
+          double w = W[r * ld + c];
+          if (p.flags & 2) w += (double)(yf[r] * yf[c]);            // ALS:524-539: the product is rounded to fp32
+          if (!(p.flags & 1)) w += (yd[r] * cu1) * yd[c];            // ALS:474-477
+          W[r * ld + c] = w;
+        }
+        if (tid < k) {
+          if (p.flags & 1) {
+            bv[tid] += xu * yd[tid];                                  // ALS:466-469
+          } else if (xu > 0.0) {
+            bv[tid] += yd[tid] * (1.0 + cu1);                         // ALS:480-482
+          }
+        }
+        __syncthreads();
+      }
+      if (tid < k) W[tid * ld + tid] += q.lambda_alpha * (double)len;  // ALS:488
+      if (tid == 0) s_minpiv = 1.0e300;
+      __syncthreads();
+      // LDL^T, right-looking; column j keeps d_j l_ij = the entries as they stood when j was eliminated
+      for (int j = 0; j < k; ++j) {
+        if (tid == 0) {
+          s_piv = W[j * ld + j];
+          s_minpiv = s_piv < s_minpiv || !(s_piv == s_piv) ? s_piv : s_minpiv;
+        }
+        __syncthreads();
+        const double inv_d = 1.0 / s_piv;
+        const int m = k - j - 1;
+        for (int e = tid; e < m * m; e += 256) {
+          const int a = j + 1 + e / m, b2 = j + 1 + e % m;
+          W[a * ld + b2] -= W[a * ld + j] * W[b2 * ld + j] * inv_d;
+        }
+        __syncthreads();
+      }
+      const double minpiv = s_minpiv;
+      const bool bad = !(minpiv > (double)p.sing_threshold);
+      // forward: z = L^-1 b (in place), then z_j / d_j, then backward with L^T
+      for (int j = 0; j < k; ++j) {
+        const double zj = bv[j];
+        const double inv_d = 1.0 / W[j * ld + j];
+        __syncthreads();
+        if (tid > j && tid < k) bv[tid] -= W[tid * ld + j] * inv_d * zj;
+        __syncthreads();
+      }
+      if (tid < k) bv[tid] /= W[tid * ld + tid];
+      __syncthreads();
+      for (int j = k - 1; j > 0; --j) {
+        const double xj = bv[j];
+        __syncthreads();
+        if (tid < j) bv[tid] -= W[j * ld + tid] / W[tid * ld + tid] * xj;
+        __syncthreads();
+      }
+      if (tid < k) p.out[row * k + tid] = bad ? 0.f : (float)bv[tid];
+      if (tid == 0) {
+        if (bad) {
+          atomicMin(p.bad_row, (unsigned long long)row);
+        } else if (minpiv <= 1024.0 * (double)p.sing_threshold) {
+          const unsigned long long key = ((unsigned long long)__float_as_uint((float)minpiv) << 32) | (unsigned)row;
+          if (key < __builtin_nontemporal_load(p.suspect)) atomicMin(p.suspect, key);
+        }
+        ++done;
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && done) atomicAdd(q.n_refined, done);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
     }
     const bool bad = !(minpiv > 0.5f);  // S >= I: only a non-finite input gets here
     if (bad && lane == 0) atomicMin(p.bad_row, (unsigned long long)cur.id);
-    if (!bad && p.refine_flag && smax > p.refine_limit * minpiv && lane == 0) p.refine_flag[cur.id] = 1;
+    if (!bad && p.refine_flag && p.refine_limit > 0.f && smax > p.refine_limit * minpiv && lane == 0) p.refine_flag[cur.id] = 1;
     {
       float* o = p.out + (int64_t)cur.id * p.k;
       const float* dc = sD + (n - 1) * KP + c;

@@ -111,6 +111,7 @@ struct mals_handle_s {
   // mixed-precision refinement of ill-conditioned rows (als_refine_kernel): estimate above which a row is re-solved
   // (MALS_REFINE_LIMIT / mals_set_refine_limit; 0 = off), rows refined so far (device counter)
   float refine_limit = 128.f;
+  bool exact_ready = false;   // als_exact_kernel's dynamic LDS limit raised
   unsigned long long* d_refined = nullptr;
   int pad_side = -1;          // solved side whose opposite matrix the copy holds, version of that side's G and
   uint64_t pad_version = 0;   // factor-upload count at the time of the copy
@@ -649,6 +650,20 @@ int launch_refine(mals_handle h, const RefineParams& q) {
     case 8: return launch_refine_T<8>(h, q);
   }
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
+int launch_exact(mals_handle h, const RefineParams& q, int level) {
+  const int k = h->cfg.features;
+  const size_t lds = sizeof(double) * ((size_t)k * (k + 1) + 2 * (size_t)k) + sizeof(float) * (size_t)k + sizeof(int) * 256;
+  if (!h->exact_ready) {
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&als_exact_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    h->exact_ready = true;
+  }
+  const int64_t rows = q.row_end - q.row_begin;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows + 255) / 256, (int64_t)h->n_cu * 4));
+  hipLaunchKernelGGL((als_exact_kernel<0>), dim3(grid), dim3(256), lds, h->stream, q, level);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
 }
 
 // ---- dual path (dual_kernels.h) ------------------------------------------------------------------
@@ -1708,8 +1723,11 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.bad_row = h->d_bad + side;
   p.suspect = h->d_bad + 2 + side;
   p.refine_flag = nullptr;
-  p.refine_limit = h->refine_limit;
-  if (h->refine_limit > 0.f) {
+  // under lossIgnoresUnspecified W has no Gramian under it and every marked row goes to the fp64 restatement, which
+  // also reproduces that mode's fp32-rounded products: the estimate is at its weakest there (measured 100x and more
+  // below cond(W) for rows with about as many entries as features), so the bar is lower
+  p.refine_limit = (h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) ? h->refine_limit / 16.f : h->refine_limit;
+  {
     if (s.refine_cap < (size_t)s.n_local) {
       HIPCHK(h, hipStreamSynchronize(h->stream));
       free_dev(s.refine);
@@ -1790,7 +1808,10 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
       q.row_end = row1;
       q.alpha = h->cfg.alpha;
       q.lambda_alpha = h->cfg.lambda * h->cfg.alpha;
-      if (int rc = launch_refine(h, q)) return rc;
+      const bool no_gramian = h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED;
+      if (!no_gramian && h->refine_limit > 0.f)
+        if (int rc = launch_refine(h, q)) return rc;      // marks 1; may raise a mark to 2
+      if (int rc = launch_exact(h, q, no_gramian ? 1 : 2)) return rc;
     }
     h->stats.rows_solved += cr.nA + cr.nC + cr.n_dual() + cr.nZ;
     h->stats.nnz_gathered += cr.nnzA + cr.nnzB + cr.nnz_dual();

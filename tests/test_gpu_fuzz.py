@@ -3,7 +3,17 @@
 Every case draws its own features, shape, density, row-length profile (empty rows, rows shorter than the feature
 count -- the dual path --, rows longer than segment_nnz -- the segment path --), hyper-parameters, mode flags,
 arithmetic mode, solve mode, chunking and stale-row count from a seeded generator, so the sweep is the same on every
-run.  Bar: 1e-4 relative Frobenius on both factor matrices (north_star)."""
+run.  Bar: 1e-4 relative Frobenius on both factor matrices (north_star); where the oracle throws
+SingularMatrix the HIP path must raise SingularSystem.
+
+What the sweep has found so far (each fixed and pinned in tests/test_gpu_outliers.py): ill-conditioned rows beyond
+what fp32 can solve (marks + als_refine_kernel), fp32 pivots that are noise (als_exact_kernel), a singularity
+verdict that needs the reference's pivoted QR (mals_check), a padding pivot that polluted the estimate.  One known
+gap at MALS_FUZZ_SEEDS=3000: seed 2550 (reconstructR, 44 factor rows against 97 features, cond(W) ~ 1e7) ends
+2.5e-4 from the oracle -- the reference rounds every product of M^T M to fp32 (MU:232), which moves ITS answer by
+more than 1e-4 on such a system; matching it takes a Gramian kernel with the same rounding."""
+import os
+
 import numpy as np
 import pytest
 
@@ -69,7 +79,7 @@ def draw_case(seed):
     return k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg
 
 
-@pytest.mark.parametrize("seed", range(240))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MALS_FUZZ_SEEDS", "240"))))   # MALS_FUZZ_SEEDS=2000: a longer hunt
 def test_seeded_configuration_sweep(seed):
     k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg = draw_case(seed)
     kw = dict(alpha=cfg["alpha"], lam=cfg["lam"], flags=cfg["flags"], threads=4)
@@ -101,6 +111,10 @@ def test_seeded_configuration_sweep(seed):
         X = core.get_factors(pkg.SIDE_X)
         assert np.all(np.isfinite(X))
         assert rel(X, Xo) < REL_TOL, (seed, k, cfg, rel(X, Xo))
+        # the second half from the SAME input as the oracle's: some of these item systems have cond(W) ~ 1e7, where
+        # the 4e-7 by which X differs from Xo moves Y by 1e-2 -- in the reference just as here (its own answer is
+        # 1e-2 away from exact arithmetic on seed 1085); parity is a statement about one half-iteration
+        core.set_factors(pkg.SIDE_X, Xo)
         if Yo is None:
             with pytest.raises(pkg.SingularSystem):
                 core.half_iteration(pkg.SIDE_Y)
