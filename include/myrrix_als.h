@@ -483,11 +483,14 @@ int mals_group_synchronize(mals_group g);
 /* Accuracy on ill-conditioned rows.  The reference solves every row's k x k system in fp64 (ALS:494 ->
  * CMLSS:37-55); the kernels here accumulate and factor it in fp32, which costs about cond(W) 6e-8 of x -- inside the
  * 1e-4 bar up to cond(W) ~ 1e3, not beyond (confidence weights alpha|r| in the thousands against a small lambda).
- * Every solving kernel therefore estimates cond(W) from below as (largest entry of W) / (smallest pivot), and a row
- * above `limit` is solved again by als_refine_kernel: the same fp32 factor as preconditioner, residuals of the exact
- * system in fp64 straight from the entries, the factor rows and the fp64 Gramian, until what is left is below
- * 1e-6 |x|.  Default 128 (environment MALS_REFINE_LIMIT overrides it at mals_create); 0 = never.  The estimate runs
- * 10-30x below cond(W); measured, the fp32 path loses 2-5e-7 of x per unit of it. */
+ * Every solving kernel therefore estimates cond(W) from below -- max(largest entry of the row's own sum w y y^T,
+ * a quarter of the largest entry of W) / (smallest pivot) -- and a row above `limit` is solved again
+ * (als_refine_kernel): the same fp32 factor as preconditioner, conjugate gradients on the exact system with every
+ * product in fp64 straight from the entries, the factor rows and the fp64 Gramian, until a step is below 1e-6 |x|.
+ * Default 128 (environment MALS_REFINE_LIMIT overrides it at mals_create; a sixteenth of it applies under
+ * MALS_FLAG_LOSS_IGNORES_UNSPECIFIED); 0 = never.  Independently of the limit, a row whose fp32 factorization
+ * breaks down (pivot <= singularity_threshold) is re-done in fp64 with the reference's own roundings
+ * (als_exact_kernel) before it is called singular.  mals_stats.rows_refined counts both. */
 int mals_set_refine_limit(mals_handle h, double limit);
 
 int mals_enable_timing(mals_handle h, int32_t on);
