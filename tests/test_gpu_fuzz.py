@@ -127,3 +127,88 @@ def test_seeded_configuration_sweep(seed):
     assert rel(Y[:n_items], Yo) < REL_TOL, (seed, k, cfg, rel(Y[:n_items], Yo))
     if n_stale:
         assert np.array_equal(Y[n_items:], Y0[n_items:])   # stale rows are never re-solved (ALS:304-308)
+
+
+# ---- call() (ALS:176-262): iteration count, convergence value and factors over several iterations ---------------------
+def well_posed_case(seed):
+    """A case of the sweep above restricted to what several chained iterations can be compared on: the reference's
+    default mode or reconstructR, moderate weights, more rows than features on both sides (no near-singular systems
+    whose sensitivity would swamp the comparison after a few iterations)."""
+    rng = np.random.default_rng(500_000 + seed)
+    k = int(rng.choice([2, 5, 10, 16, 24, 30, 33, 48, 50, 64, 80, 100, 128]))
+    n_users = int(rng.integers(2 * k + 50, 2 * k + 700))
+    n_items = int(rng.integers(2 * k + 30, 2 * k + 400))
+    lens = np.minimum(rng.integers(0, max(3, min(2 * k + 10, n_items)), size=n_users), n_items)
+    lens[rng.random(n_users) < 0.02] = n_items // 2
+    rows = np.repeat(np.arange(n_users), lens)
+    cols = np.concatenate([rng.choice(n_items, size=int(n), replace=False) for n in lens] + [np.zeros(0, dtype=np.int64)])
+    vals = rng.integers(1, 6, size=len(cols)).astype(np.float32)
+    vals = np.where(rng.random(len(cols)) < 0.1, -vals, vals).astype(np.float32)
+
+    def csr(r, c, v, n):
+        order = np.lexsort((c, r))
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(ptr, r.astype(np.int64) + 1, 1)
+        return np.cumsum(ptr).astype(np.int64), c[order].astype(np.int32), v[order].astype(np.float32)
+
+    Y0 = rng.standard_normal((n_items, k)).astype(np.float32)
+    Y0 /= np.linalg.norm(Y0, axis=1, keepdims=True).astype(np.float32)
+    cfg = dict(alpha=float(rng.choice([1.0, 1.0, 5.0])), lam=float(rng.choice([0.1, 0.1, 1.0])),
+               flags=int(rng.choice([0, 0, pkg.FLAG_RECONSTRUCT_R])), segment_nnz=int(rng.choice([0, 64])),
+               chunk_rows=int(rng.choice([0, 131])), gramian_mode=int(rng.choice([0, 0, _lib.GRAMIAN_FP32])),
+               solve_mode=int(rng.choice([0, 0, _lib.SOLVE_DIRECT, _lib.SOLVE_DUAL])))
+    tu = np.sort(rng.choice(n_users, size=int(rng.integers(1, min(n_users, 200))), replace=False)).astype(np.int64)
+    ti = np.sort(rng.choice(n_items, size=int(rng.integers(1, min(n_items, 200))), replace=False)).astype(np.int64)
+    return k, n_users, n_items, csr(rows, cols, vals, n_users), csr(cols, rows, vals, n_items), Y0, cfg, tu, ti, int(rng.integers(2, 7))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_full_call_sweep(seed):
+    k, n_users, n_items, r_csr, c_csr, Y0, cfg, tu, ti, max_it = well_posed_case(seed)
+    try:
+        Xo, Yo, it_o, conv_o = oracle.als_call(r_csr, c_csr, n_users, n_items, Y0, k, alpha=cfg["alpha"], lam=cfg["lam"],
+                                               flags=cfg["flags"], conv_threshold=0.001, max_iterations=max_it, test_users=tu,
+                                               test_items=ti, threads=4)
+    except oracle.SingularMatrix:
+        Xo = None   # e.g. an item nobody touched under reconstructR after X collapsed: the reference throws
+    with pkg.ALSCore(k, **cfg) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_matrix(pkg.SIDE_X, *r_csr)
+        core.set_matrix(pkg.SIDE_Y, *c_csr)
+        core.set_factors(pkg.SIDE_Y, Y0)
+        if Xo is None:
+            with pytest.raises(pkg.SingularSystem):
+                core.factorize(0.001, max_it, False, tu, ti)
+            return
+        it, conv = core.factorize(0.001, max_it, False, tu, ti)
+        X, Y = core.get_factors(pkg.SIDE_X), core.get_factors(pkg.SIDE_Y)
+    assert it == it_o, (seed, k, cfg, it, it_o)
+    assert abs(conv - conv_o) <= 1e-3 * max(abs(conv_o), 1e-6), (conv, conv_o)
+    assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL, (seed, k, cfg, rel(X, Xo), rel(Y, Yo))
+
+
+@pytest.mark.parametrize("seed", range(40, 64))
+def test_group_sweep(seed):
+    """The same through the group API: N members on device 0 (peer-copy backend), cost-balanced slices, chunked
+    exchange -- the factors must not depend on any of it."""
+    k, n_users, n_items, r_csr, c_csr, Y0, cfg, tu, ti, max_it = well_posed_case(seed)
+    rng = np.random.default_rng(seed)
+    world, chunks = int(rng.integers(2, 5)), int(rng.integers(1, 5))
+    Xo, Yo = None, Y0
+    kw = dict(alpha=cfg["alpha"], lam=cfg["lam"], flags=cfg["flags"], threads=4)
+    for _ in range(2):
+        Xo = oracle.half_iteration(*r_csr, Yo, **kw)
+        Yo = oracle.half_iteration(*c_csr, Xo, **kw)
+    with pkg.GroupALS.single_process(k, [0] * world, backend=_lib.GROUP_PEER_COPY, exchange_chunks=chunks, alpha=cfg["alpha"],
+                                     lam=cfg["lam"], flags=cfg["flags"], segment_nnz=cfg["segment_nnz"],
+                                     gramian_mode=cfg["gramian_mode"], solve_mode=cfg["solve_mode"]) as g:
+        g.set_factor_rows(pkg.SIDE_X, n_users)
+        g.set_factor_rows(pkg.SIDE_Y, n_items)
+        g.set_matrix(pkg.SIDE_X, *r_csr)
+        g.set_matrix(pkg.SIDE_Y, *c_csr)
+        g.set_factors(pkg.SIDE_Y, Y0)
+        g.iterate(2)
+        X = g.get_factors(pkg.SIDE_X, 0, n_users)
+        Y = g.get_factors(pkg.SIDE_Y, 0, n_items)
+    assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL, (seed, world, chunks, k, cfg, rel(X, Xo), rel(Y, Yo))
