@@ -15,12 +15,12 @@
 #include <limits>
 #include <map>
 #include <memory>
-#include <random>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../myrrix_als.h"
+#include "random.hpp"
 
 namespace myrrix {
 
@@ -149,7 +149,7 @@ class AlternatingLeastSquares final : public MatrixFactorizer {
   void call() override {  // ALS:176-262
     const int k = features_;
     const bool randomY = previousY_ == nullptr || previousY_->empty();  // ALS:181
-    std::mt19937_64 rng(std::stoull(System::getProperty("model.test.seed", "1234567890")));  // RandomManager.java:52
+    MersenneTwister rng(std::stoll(System::getProperty("model.test.seed", "1234567890")));  // RandomManager.java:52,63-73
     FastByIDMap<FloatVector> Y0 = constructInitialY(rng);                                      // ALS:182
     std::vector<int64_t> userIDs, itemIDs, yIDs;
     for (auto& e : RbyRow_) userIDs.push_back(e.first);
@@ -250,18 +250,17 @@ class AlternatingLeastSquares final : public MatrixFactorizer {
     for (float& f : v) f /= n;
   }
 
-  // RandomUtils.randomUnitVectorFarFrom (RandomUtils.java:110-140).  Same acceptance rule; the
-  // random stream is std::mt19937_64, not commons-math's generator, so values differ from the JVM's
-  // (the reference's own tests always supply previousY, as do the parity tests here).
-  static FloatVector randomUnitVectorFarFrom(int k, const std::vector<const FloatVector*>& farFrom, std::mt19937_64& rng) {
-    std::normal_distribution<double> gauss(0.0, 1.0);
-    std::uniform_real_distribution<double> uni(0.0, 1.0);
+  // RandomUtils.randomUnitVectorFarFrom (RandomUtils.java:110-140) on the reference's own random stream
+  // (random.hpp: commons-math3's MersenneTwister as RandomManager seeds it), drawn in the reference's order: the
+  // Gaussians of doRandomUnitVector (RU:88-100), one nextInt(size) per sampled earlier vector when there are more
+  // than 100 (RU:124), one nextDouble() for the acceptance (RU:136).
+  static FloatVector randomUnitVectorFarFrom(int k, const std::vector<const FloatVector*>& farFrom, MersenneTwister& rng) {
     const size_t size = farFrom.size(), numSamples = std::min<size_t>(100, size);
     for (;;) {
       FloatVector v(k);
       double total = 0.0;
       for (int i = 0; i < k; ++i) {
-        const double d = gauss(rng);
+        const double d = rng.nextGaussian();
         v[i] = (float)d;
         total += d * d;
       }
@@ -269,31 +268,30 @@ class AlternatingLeastSquares final : public MatrixFactorizer {
       for (float& f : v) f /= nrm;
       double smallest = std::numeric_limits<double>::infinity();
       for (size_t s = 0; s < numSamples; ++s) {
-        const FloatVector& other = *farFrom[size == numSamples ? s : (size_t)(uni(rng) * size) % size];
+        const FloatVector& other = *farFrom[size == numSamples ? s : (size_t)rng.nextInt((int32_t)size)];
         const double d2 = 2.0 - 2.0 * MatrixUtils::dot(v, other);
         if (std::isfinite(d2) && d2 < smallest) smallest = d2;
       }
       if (std::isfinite(smallest) && !(k == 1 && smallest == 0.0)) {
-        if (uni(rng) < smallest / 4.0) return v;
+        if (rng.nextDouble() < smallest / 4.0) return v;
       } else {
         return v;
       }
     }
   }
 
-  FastByIDMap<FloatVector> constructInitialY(std::mt19937_64& rng) {  // ALS:264-335
+  FastByIDMap<FloatVector> constructInitialY(MersenneTwister& rng) {  // ALS:264-335
     const int k = features_;
     FastByIDMap<FloatVector> Y;
     if (previousY_ && !previousY_->empty()) {
       const size_t oldK = previousY_->begin()->second.size();
-      std::normal_distribution<double> gauss(0.0, 1.0);
       for (auto& e : *previousY_) {
         FloatVector v(k, 0.f);
         for (size_t i = 0; i < std::min<size_t>(oldK, (size_t)k); ++i) v[i] = e.second[i];
         if (oldK > (size_t)k) {  // ALS:277-287
           normalize(v);
         } else if (oldK < (size_t)k) {  // ALS:289-302
-          for (size_t i = oldK; i < (size_t)k; ++i) v[i] = (float)gauss(rng);
+          for (size_t i = oldK; i < (size_t)k; ++i) v[i] = (float)rng.nextGaussian();   // ALS:297-299
           normalize(v);
         }
         Y[e.first] = v;
@@ -313,16 +311,24 @@ class AlternatingLeastSquares final : public MatrixFactorizer {
     return Y;
   }
 
-  // RandomUtils.chooseAboutNFromStream (RandomUtils.java:202-217): everything when n >= size, else
-  // geometric-skip sampling at rate n/size; returns dense indices
-  static std::vector<int64_t> chooseAboutN(int n, size_t size, std::mt19937_64& rng) {
+  // RandomUtils.chooseAboutNFromStream (RandomUtils.java:202-217): everything when n >= size, else what
+  // SamplingLongPrimitiveIterator keeps: it skips PascalDistribution(random, 1, rate).sample() elements, which in
+  // commons-math3 is inverseCumulativeProbability(random.nextDouble()) = floor(log(1-u) / log(1-rate)) -- one
+  // nextDouble() per skip, the JVM's value except for a u within rounding of a step of the CDF.  Dense indices.
+  static std::vector<int64_t> chooseAboutN(int n, size_t size, MersenneTwister& rng) {
     std::vector<int64_t> out;
     if ((size_t)n >= size) {
       for (size_t i = 0; i < size; ++i) out.push_back((int64_t)i);
       return out;
     }
-    std::geometric_distribution<int64_t> geo((double)n / (double)size);  // failures before a success
-    for (int64_t pos = geo(rng); (size_t)pos < size; pos += 1 + geo(rng)) out.push_back(pos);
+    const double rate = (double)n / (double)size;
+    int64_t pos = -1;
+    for (;;) {
+      const double u = rng.nextDouble();
+      pos += 1 + (int64_t)std::floor(std::log1p(-u) / std::log1p(-rate));
+      if ((size_t)pos >= size) break;
+      out.push_back(pos);
+    }
     return out;
   }
 

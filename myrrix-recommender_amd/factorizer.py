@@ -14,6 +14,7 @@ import math
 import numpy as np
 
 from . import _lib
+from .random_mt import MersenneTwister
 from .core import ALSCore, Cancelled, MalsError, SingularSystem
 
 
@@ -120,24 +121,30 @@ class MatrixFactorizer:
 
 
 def _random_unit_vector_far_from(k, far_from, rng):
-    """RandomUtils.randomUnitVectorFarFrom (common/src/.../random/RandomUtils.java:110-140).
-    Same acceptance rule; the random stream is numpy's, not commons-math's MersenneTwister, so the
-    values differ from the JVM's (parity tests always supply previousY, like the reference's)."""
+    """RandomUtils.randomUnitVectorFarFrom (common/src/.../random/RandomUtils.java:110-140) on the reference's own
+    random stream (random_mt.MersenneTwister = commons-math3's generator as RandomManager seeds it): the Gaussians of
+    doRandomUnitVector (RU:88-100), then per sampled earlier vector one nextInt(size) (RU:124, only when there are more
+    than 100 of them), then one nextDouble() for the acceptance (RU:136) -- in that order, so that the stream stays
+    aligned with the JVM's."""
     size = len(far_from)
     num_samples = min(100, size)
     while True:
-        d = rng.standard_normal(k)
+        d = rng.nextGaussians(k)                                   # RU:91-95
         v = d.astype(np.float32)
-        v /= np.float32(math.sqrt(float(np.sum(d * d))))
+        total = 0.0
+        for x in d:                                                # total += d * d in that order (RU:94)
+            total += x * x
+        v /= np.float32(math.sqrt(total))                          # RU:96-98: float divisor
         smallest = math.inf
-        for s in range(num_samples):
-            other = far_from[s if size == num_samples else int(rng.integers(size))]
-            dot = float(np.sum((v * other).astype(np.float32).astype(np.float64)))
+        picks = range(num_samples) if size == num_samples else rng.nextInts(num_samples, size)
+        for s in picks:
+            other = far_from[int(s)]
+            dot = float(np.sum((v * other).astype(np.float32).astype(np.float64)))   # SimpleVectorMath.dot: float products
             dist2 = 2.0 - 2.0 * dot
             if math.isfinite(dist2) and dist2 < smallest:
                 smallest = dist2
         if math.isfinite(smallest) and not (k == 1 and smallest == 0.0):
-            if rng.random() < smallest / 4.0:
+            if rng.nextDouble() < smallest / 4.0:
                 return v
         else:
             return v
@@ -149,10 +156,16 @@ def _choose_about_n(n, ids, rng):
     size = len(ids)
     if n >= size:
         return list(range(size))
+    # SamplingLongPrimitiveIterator.doNext skips PascalDistribution(random, 1, rate).sample() elements, which in
+    # commons-math3 is inverseCumulativeProbability(random.nextDouble()): the smallest x with 1 - (1-rate)^(x+1) >= u,
+    # i.e. floor(log(1-u) / log(1-rate)) -- one nextDouble() per skip, the same value as the JVM's numerical inverse
+    # except for a u within rounding of a step of the CDF
     rate = n / size
     out, pos = [], -1
     while True:
-        pos += 1 + int(rng.geometric(rate)) - 1
+        u = rng.nextDouble()
+        skip = int(math.floor(math.log1p(-u) / math.log1p(-rate))) if u < 1.0 else 0
+        pos += 1 + skip
         if pos >= size:
             break
         out.append(pos)
@@ -227,7 +240,7 @@ class AlternatingLeastSquares(MatrixFactorizer):
                 for id_, vec in prev.items():
                     v = np.zeros(k, dtype=np.float32)
                     v[:old_k] = vec
-                    v[old_k:] = rng.standard_normal(k - old_k).astype(np.float32)
+                    v[old_k:] = rng.nextGaussians(k - old_k).astype(np.float32)   # ALS:297-299
                     nrm = np.float32(math.sqrt(float(np.sum((v * v).astype(np.float64)))))
                     Y[id_] = v / nrm
             else:              # ALS:304-308 same feature count: use as is
@@ -269,7 +282,7 @@ class AlternatingLeastSquares(MatrixFactorizer):
         iterate = str(System.getProperty("model.als.iterate", "true")).lower() == "true"  # ALS:196
         sing = float(System.getProperty("common.matrix.singularityThreshold", 1.0e-5))
         seed = int(System.getProperty("model.test.seed", 1234567890))   # RandomManager.java:52
-        rng = np.random.default_rng(seed)
+        rng = MersenneTwister(seed)                                      # RM:63-73: commons-math3 MersenneTwister
 
         random_y = not self.previousY                                    # ALS:181
         Y0 = self._construct_initial_y(rng)                              # ALS:182

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <random>
 
 #include "../../include/myrrix/factorizer.hpp"
 #include "../../include/myrrix/generation.hpp"

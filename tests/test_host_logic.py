@@ -42,7 +42,7 @@ def test_constructor_preconditions():
 
 
 def test_initial_y_reuse_project_pad_and_new_items():
-    rng = np.random.default_rng(0)
+    rng = factorizer.MersenneTwister(0)
     byCol = {10: {1: 1.0}, 11: {1: 1.0}, 12: {2: 1.0}}
     prev = {10: np.array([3.0, 4.0, 0.0], np.float32), 99: np.array([0.0, 0.0, 2.0], np.float32)}
     als = pkg.AlternatingLeastSquares({}, byCol, 3, 0.001, 1)
@@ -64,7 +64,7 @@ def test_initial_y_reuse_project_pad_and_new_items():
 
 
 def test_choose_about_n():
-    rng = np.random.default_rng(1)
+    rng = factorizer.MersenneTwister(1)
     assert factorizer._choose_about_n(100, list(range(50)), rng) == list(range(50))
     picks = [len(factorizer._choose_about_n(100, list(range(100000)), rng)) for _ in range(20)]
     assert 60 < np.mean(picks) < 140
