@@ -64,6 +64,7 @@ struct SolveParams {
   unsigned long long* bad_row; // first (smallest) local row with a non-PD system
   unsigned long long* suspect; // (pivot bits << 32 | local row) of the smallest pivot within 1024x of the threshold:
                                // mals_check puts that row to the reference's own singularity test (pivoted QR)
+  int* any_marked;          // set to 1 with the first mark of a half-iteration (gramian_ref_kernel waits for it)
   uint8_t* refine_flag;     // per local row: set to 1 by the solving kernel when (largest entry of W) / (smallest pivot)
   float refine_limit;       // exceeds refine_limit -- the row is then re-solved with fp64 residuals (als_refine_kernel)
   int64_t n_work;           // waves of work in the list this launch handles
@@ -869,6 +870,7 @@ __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T]
     if (lane == 0) {
       if (p.refine_flag) {
         p.refine_flag[row] = 2;
+        *p.any_marked = 1;
       } else {
         atomicMin(p.bad_row, (unsigned long long)row);
       }
@@ -881,7 +883,10 @@ __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T]
       // same-address atomics serialise: only rows that lower the minimum issue one
       if (key < __builtin_nontemporal_load(p.suspect)) atomicMin(p.suspect, key);
     }
-    if (p.refine_flag && p.refine_limit > 0.f && wmax > p.refine_limit * minpiv && lane == 0) p.refine_flag[row] = 1;
+    if (p.refine_flag && p.refine_limit > 0.f && wmax > p.refine_limit * minpiv && lane == 0) {
+      p.refine_flag[row] = 1;
+      *p.any_marked = 1;
+    }
   }
   if (lane < 16) {
     float* o = p.out + (int64_t)row * p.k;
@@ -1216,7 +1221,9 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
 // (a dual row is re-solved in the original basis, after the un-rotation).  Not marked: nothing happens.
 struct RefineParams {
   SolveParams p;                  // the half-iteration's parameters (gather table, CSR, Gramian image, out, flags)
-  const double* G;                // k x k row-major fp64 Gramian of the gathered side
+  const double* G;                // k x k row-major fp64 Gramian of the gathered side (exact products)
+  const double* Gref;             // the same with every product rounded to fp32 first, as the reference forms it
+  const int* gref_state;          // [1] != 0: Gref is there (gramian_ref_kernel)
   unsigned long long* n_refined;  // statistics
   int64_t row_begin, row_end;     // local rows of the chunk
   double alpha, lambda_alpha;
@@ -1273,9 +1280,10 @@ __device__ __forceinline__ void refine_matvec(const RefineParams& q, int64_t beg
     double gv[T];
 #pragma unroll
     for (int u = 0; u < T; ++u) gv[u] = 0.0;
+    const double* G = q.gref_state[1] ? q.Gref : q.G;
     for (int j = g; j < p.k; j += 4) {
       const double vj = xs[j];
-      const double* gr = q.G + (int64_t)j * p.k;
+      const double* gr = G + (int64_t)j * p.k;
 #pragma unroll
       for (int u = 0; u < T; ++u) {
         const int f = 16 * u + c;
@@ -1448,9 +1456,10 @@ __global__ __launch_bounds__(256) void als_exact_kernel(RefineParams q, int leve
       const int64_t row = blk + list[mi];   // arrival order: the rows are independent
       const int64_t begin = p.row_ptr[row];
       const int64_t len = p.row_ptr[row + 1] - begin;
+      const double* G = q.gref_state[1] ? q.Gref : q.G;
       for (int e = tid; e < k * k; e += 256) {
         const int r = e / k, c = e - r * k;
-        W[r * ld + c] = (p.flags & 2) ? 0.0 : q.G[(int64_t)r * k + c];   // ALS:447-450
+        W[r * ld + c] = (p.flags & 2) ? 0.0 : G[(int64_t)r * k + c];   // ALS:447-450
       }
       if (tid < k) bv[tid] = 0.0;
       __syncthreads();
@@ -1631,6 +1640,64 @@ __global__ __launch_bounds__(256) void gramian_finalize_kernel(const double* __r
     const int lr = row - 16 * i, lc = col - 16 * j;
     Gf[(t * 64 + 16 * (lr >> 2) + lc) * 4 + (lr & 3)] = f;
     if (i == j) Gf[(t * 64 + 16 * (lc >> 2) + lr) * 4 + (lc & 3)] = f;
+  }
+}
+
+// K1 as the reference rounds it: G[r][c] = sum_i (double)(float)(M[i][r] M[i][c]) (MU:219-239: the product of two
+// floats is a float in Java, widened afterwards).  VALU work (a multiply, a conversion and an fp64 add per product:
+// ~4 ms for 10M x 64), so it runs only where it can matter: when a row of the half-iteration has been marked
+// ill-conditioned (state[0], set by the solving kernels) and the matrix is not there yet (state[1]).  Those rows'
+// answers move by more than 1e-4 with the rounding of these products (cond(W) ~ 1e7; sweep case 2550), and parity is
+// with the reference's arithmetic.  Per-workgroup partial sums, combined in workgroup order by the last to arrive.
+template <int T>
+__global__ __launch_bounds__(256) void gramian_ref_kernel(const float* __restrict__ M, int64_t n_rows, int k, int* state,
+                                                          double* __restrict__ part, double* __restrict__ Gref) {
+  if (state[0] == 0 || state[1] != 0) return;
+  constexpr int KP = 16 * T, NE = T * T;   // KP^2 / 256 entries per thread
+  __shared__ float srow[8][KP];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  double acc[NE];
+#pragma unroll
+  for (int j = 0; j < NE; ++j) acc[j] = 0.0;
+  const int64_t per = (n_rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = per * blockIdx.x, r1 = r0 + per < n_rows ? r0 + per : n_rows;
+  for (int64_t base = r0; base < r1; base += 8) {
+    __syncthreads();
+    for (int e = tid; e < 8 * KP; e += 256) {
+      const int i = e / KP, f = e - i * KP;
+      srow[i][f] = (base + i < r1 && f < k) ? M[(base + i) * k + f] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < NE; ++j) {
+        const int e = tid + 256 * j, r = e / KP, c = e - r * KP;
+        acc[j] += (double)__fmul_rn(srow[i][r], srow[i][c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NE; ++j) part[(size_t)blockIdx.x * (KP * KP) + tid + 256 * j] = acc[j];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&state[2], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    const int e = tid + 256 * j, r = e / KP, c = e - r * KP;
+    double sum = 0.0;
+    for (unsigned w = 0; w < gridDim.x; ++w) sum += part[(size_t)w * (KP * KP) + e];
+    if (r < k && c < k) Gref[(int64_t)r * k + c] = sum;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    state[2] = 0;
+    state[1] = 1;
   }
 }
 

@@ -48,6 +48,7 @@ struct DualParams {
   float lambda_alpha;
   float sqrt_w_max;         // sqrt(alpha * max |r|): bound of C^1/2
   unsigned* xbound;         // bit pattern of the largest |x'| stored so far (operand scale of the un-rotation)
+  int* any_marked;          // as in SolveParams
   uint8_t* refine_flag;     // as in SolveParams: rows whose S = I + Z Z^T is ill-conditioned for fp32 go to als_refine_kernel
   float refine_limit;
 };
@@ -504,7 +505,10 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
     }
     const bool bad = !(minpiv > 0.5f);  // S >= I: only a non-finite input gets here
     if (bad && lane == 0) atomicMin(p.bad_row, (unsigned long long)cur.id);
-    if (!bad && p.refine_flag && p.refine_limit > 0.f && smax > p.refine_limit * minpiv && lane == 0) p.refine_flag[cur.id] = 1;
+    if (!bad && p.refine_flag && p.refine_limit > 0.f && smax > p.refine_limit * minpiv && lane == 0) {
+      p.refine_flag[cur.id] = 1;
+      *p.any_marked = 1;
+    }
     {
       float* o = p.out + (int64_t)cur.id * p.k;
       const float* dc = sD + (n - 1) * KP + c;

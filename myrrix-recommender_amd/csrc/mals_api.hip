@@ -112,6 +112,9 @@ struct mals_handle_s {
   // (MALS_REFINE_LIMIT / mals_set_refine_limit; 0 = off), rows refined so far (device counter)
   float refine_limit = 128.f;
   bool exact_ready = false;   // als_exact_kernel's dynamic LDS limit raised
+  int* d_gref_state = nullptr;   // {a row was marked in this half-iteration, Gref is valid, arrival ticket}
+  double* d_Gref = nullptr;      // the reference-rounded Gramian of the gathered side (gramian_ref_kernel), on demand
+  double* d_gref_part = nullptr;
   unsigned long long* d_refined = nullptr;
   int pad_side = -1;          // solved side whose opposite matrix the copy holds, version of that side's G and
   uint64_t pad_version = 0;   // factor-upload count at the time of the copy
@@ -652,6 +655,30 @@ int launch_refine(mals_handle h, const RefineParams& q) {
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
 }
 
+// The reference's M^T M (MU:219-239 rounds every product to fp32) for the refinement of marked rows; the kernel
+// returns at once unless a row has been marked in this half-iteration and the matrix is not there yet.
+template <int T>
+int launch_gramian_ref_T(mals_handle h, const SideState& o) {
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((o.n_total + 63) / 64, (int64_t)h->n_cu * 2));
+  hipLaunchKernelGGL((gramian_ref_kernel<T>), dim3(grid), dim3(256), 0, h->stream, o.F, o.n_total, h->cfg.features, h->d_gref_state,
+                     h->d_gref_part, h->d_Gref);
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+int launch_gramian_ref(mals_handle h, const SideState& o) {
+  switch (h->T) {
+    case 1: return launch_gramian_ref_T<1>(h, o);
+    case 2: return launch_gramian_ref_T<2>(h, o);
+    case 3: return launch_gramian_ref_T<3>(h, o);
+    case 4: return launch_gramian_ref_T<4>(h, o);
+    case 5: return launch_gramian_ref_T<5>(h, o);
+    case 6: return launch_gramian_ref_T<6>(h, o);
+    case 7: return launch_gramian_ref_T<7>(h, o);
+    case 8: return launch_gramian_ref_T<8>(h, o);
+  }
+  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
+}
+
 int launch_exact(mals_handle h, const RefineParams& q, int level) {
   const int k = h->cfg.features;
   const size_t lds = sizeof(double) * ((size_t)k * (k + 1) + 2 * (size_t)k) + sizeof(float) * (size_t)k + sizeof(int) * 256;
@@ -912,6 +939,7 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
   dp.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);
   dp.sqrt_w_max = (float)std::sqrt(std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
   dp.xbound = h->d_zbound + 1;
+  dp.any_marked = h->d_gref_state;
   dp.refine_flag = h->refine_limit > 0.f ? s.refine : nullptr;
   dp.refine_limit = h->refine_limit;
   const WorkItem* base = s.itemsA + cr.offA + cr.nA;
@@ -1277,6 +1305,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
       hipMalloc(&h->d_zscale, 4 * sizeof(float)) != hipSuccess || hipMalloc(&h->d_maxabs, 4 * sizeof(unsigned)) != hipSuccess ||
       hipMalloc(&h->d_colrange, 2 * sizeof(int)) != hipSuccess ||
       hipMalloc(&h->d_refined, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&h->d_gref_state, 4 * sizeof(int)) != hipSuccess || hipMemset(h->d_gref_state, 0, 4 * sizeof(int)) != hipSuccess ||
       hipMemset(h->d_refined, 0, sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(h->d_bad, 0xff, 4 * sizeof(unsigned long long)) != hipSuccess) {
     delete h;
@@ -1327,6 +1356,9 @@ int mals_destroy(mals_handle h) {
   }
   free_dev(h->d_bad);
   free_dev(h->d_refined);
+  free_dev(h->d_gref_state);
+  free_dev(h->d_Gref);
+  free_dev(h->d_gref_part);
   free_dev(h->d_zscale);
   free_dev(h->d_maxabs);
   free_dev(h->d_colrange);
@@ -1682,6 +1714,20 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.val = s.val;
   p.M = o.F;
   p.ldm = k;
+  // A new half-iteration?  The opposite factors do not change while a half-iteration's chunks are solved (in any
+  // order): "new" = the side, the opposite Gramian or the opposite uploads changed, or a chunk comes round again.
+  bool new_half = h->pad_side != side || h->pad_version != o.G_version || h->pad_epoch != o.F_epoch ||
+                  h->pad_done.size() != s.chunks.size();
+  for (int c = chunk_begin; c < chunk_end && !new_half; ++c) new_half = h->pad_done[(size_t)c] != 0;
+  if (new_half) {
+    h->pad_side = side;
+    h->pad_version = o.G_version;
+    h->pad_epoch = o.F_epoch;
+    h->pad_done.assign(s.chunks.size(), 0);
+    // nothing marked yet, no reference-rounded Gramian yet (gramian_ref_kernel)
+    HIPCHK(h, hipMemsetAsync(h->d_gref_state, 0, 2 * sizeof(int), h->stream));
+  }
+  for (int c = chunk_begin; c < chunk_end; ++c) h->pad_done[(size_t)c] = 1;
   if (k % 16 != 0) {
     const int ld = 16 * h->T;
     const size_t need = (size_t)o.n_total * (size_t)ld;
@@ -1689,16 +1735,11 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
       HIPCHK(h, hipStreamSynchronize(h->stream));
       free_dev(h->d_Mp);
       h->Mp_cap = 0;
-      h->pad_side = -1;
+      new_half = true;   // the copy is gone
       HIPCHK(h, hipMalloc(&h->d_Mp, sizeof(float) * need));
       h->Mp_cap = need;
     }
-    // the opposite factors do not change while a half-iteration's chunks are solved (in any order): the copy is
-    // refreshed when the side, the opposite Gramian or the opposite uploads changed, or when a chunk comes round again
-    bool stale = h->pad_side != side || h->pad_version != o.G_version || h->pad_epoch != o.F_epoch ||
-                 h->pad_done.size() != s.chunks.size();
-    for (int c = chunk_begin; c < chunk_end && !stale; ++c) stale = h->pad_done[(size_t)c] != 0;
-    if (stale) {
+    if (new_half) {
       PendingEvent pe;
       if (int rc = begin_timed(h, 5, (double)o.n_total * 4.0 * (k + ld), pe)) return rc;
       const int64_t n4 = o.n_total * (ld / 4);
@@ -1706,12 +1747,7 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
       hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, h->stream, o.F, o.n_total, k, ld, h->d_Mp);
       HIPCHK(h, hipGetLastError());
       if (int rc = end_timed(h, pe)) return rc;
-      h->pad_side = side;
-      h->pad_version = o.G_version;
-      h->pad_epoch = o.F_epoch;
-      h->pad_done.assign(s.chunks.size(), 0);
     }
-    for (int c = chunk_begin; c < chunk_end; ++c) h->pad_done[(size_t)c] = 1;
     p.M = h->d_Mp;
     p.ldm = ld;
   }
@@ -1722,6 +1758,7 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.scratch = s.scratch;
   p.bad_row = h->d_bad + side;
   p.suspect = h->d_bad + 2 + side;
+  p.any_marked = h->d_gref_state;
   p.refine_flag = nullptr;
   // under lossIgnoresUnspecified W has no Gramian under it and every marked row goes to the fp64 restatement, which
   // also reproduces that mode's fp32-rounded products: the estimate is at its weakest there (measured 100x and more
@@ -1800,15 +1837,24 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
         if (int rc = launch_dual_chunk(h, side, c)) return rc;
     }
     if (p.refine_flag && row1 > row0) {  // behind every kernel of the chunk (the un-rotation of the dual rows included)
+      if (!h->d_Gref) {   // before the parameter block below takes the pointers
+        const size_t kp2 = (size_t)(16 * h->T) * (size_t)(16 * h->T);
+        HIPCHK(h, hipMalloc(&h->d_Gref, sizeof(double) * kp2));
+        HIPCHK(h, hipMalloc(&h->d_gref_part, sizeof(double) * kp2 * (size_t)h->n_cu * 2));
+      }
       RefineParams q;
       q.p = p;
       q.G = o.G;
+      q.Gref = h->d_Gref;
+      q.gref_state = h->d_gref_state;
       q.n_refined = h->d_refined;
       q.row_begin = row0;
       q.row_end = row1;
       q.alpha = h->cfg.alpha;
       q.lambda_alpha = h->cfg.lambda * h->cfg.alpha;
       const bool no_gramian = h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED;
+      if (!no_gramian)   // something marked in this half-iteration: M^T M once more, rounded like the reference's
+        if (int rc = launch_gramian_ref(h, o)) return rc;
       if (!no_gramian && h->refine_limit > 0.f)
         if (int rc = launch_refine(h, q)) return rc;      // marks 1; may raise a mark to 2
       if (int rc = launch_exact(h, q, no_gramian ? 1 : 2)) return rc;

@@ -8,10 +8,9 @@ SingularMatrix the HIP path must raise SingularSystem.
 
 What the sweep has found so far (each fixed and pinned in tests/test_gpu_outliers.py): ill-conditioned rows beyond
 what fp32 can solve (marks + als_refine_kernel), fp32 pivots that are noise (als_exact_kernel), a singularity
-verdict that needs the reference's pivoted QR (mals_check), a padding pivot that polluted the estimate.  One known
-gap at MALS_FUZZ_SEEDS=3000: seed 2550 (reconstructR, 44 factor rows against 97 features, cond(W) ~ 1e7) ends
-2.5e-4 from the oracle -- the reference rounds every product of M^T M to fp32 (MU:232), which moves ITS answer by
-more than 1e-4 on such a system; matching it takes a Gramian kernel with the same rounding."""
+verdict that needs the reference's pivoted QR (mals_check), a padding pivot that polluted the estimate, answers
+that depend on the reference rounding every product of M^T M to fp32 (gramian_ref_kernel).  MALS_FUZZ_SEEDS=3000
+passes in full."""
 import os
 
 import numpy as np

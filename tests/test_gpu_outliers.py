@@ -156,9 +156,9 @@ def test_systems_the_fp32_path_alone_gets_wrong(seed, solve_mode, gramian_mode):
     assert err[None][0] < 1e-5 and err[None][1] > 0, err
 
 
-# 2145: reconstructR on a Gramian of 98 factor rows against 112 features -- refined to the exact system, 8e-5 from the
-# reference, whose M^T M rounds every product to fp32 (MU:232); inside the bar, not bit-faithful like the others
-@pytest.mark.parametrize("seed,bar", [(573, 1e-5), (1085, 1e-5), (1492, 1e-5), (2145, 1e-4)])
+# 2145, 2550: reconstructR on a Gramian of fewer factor rows than features -- the reference's M^T M rounds every product
+# to fp32 (MU:232), which moves its answer by 8e-5 / 2.5e-4 there; gramian_ref_kernel forms that matrix for the marked rows
+@pytest.mark.parametrize("seed,bar", [(573, 1e-5), (1085, 1e-5), (1492, 1e-5), (2145, 1e-5), (2550, 1e-5)])
 def test_rows_without_a_usable_fp32_factor_take_the_fp64_restatement(seed, bar):
     """Sweep cases (MALS_FUZZ_SEEDS=3000) with cond(W) of 1e7 and more: lossIgnoresUnspecified / reconstructR with
     lambda = 0.01 and factor rows of norm 30, or a Gramian of fewer factor rows than features.  fp32 pivots are noise
