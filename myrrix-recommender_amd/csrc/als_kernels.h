@@ -67,6 +67,8 @@ struct SolveParams {
   int* any_marked;          // set to 1 with the first mark of a half-iteration (gramian_ref_kernel waits for it)
   uint8_t* refine_flag;     // per local row: set to 1 by the solving kernel when (largest entry of W) / (smallest pivot)
   float refine_limit;       // exceeds refine_limit -- the row is then re-solved with fp64 residuals (als_refine_kernel)
+  float gramian_weight;     // what the largest entry of all of W counts for in that estimate: 1/4 normally (store_row),
+                            // 1 under reconstructR, where W IS the Gramian plus the ridge
   int64_t n_work;           // waves of work in the list this launch handles
   int32_t k;
   int32_t ldm;              // row stride of M in floats
@@ -861,7 +863,9 @@ __device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T
 // (measured 2-5e-7 of x per unit of the ratio); the shared Gramian under it is an fp64 sum rounded once and only
 // suffers the factorization's rounding (measured 1e-7 per unit, on rows of the C5 shape whose W is all Gramian) --
 // but it must count: with reconstructR there is no row part at all, and G + rho I with fewer factor rows than
-// features is as ill-conditioned as anything (sweep cases 2145, 2550).  Rows above refine_limit are marked.
+// features is as ill-conditioned as anything (sweep cases 2145, 2550) and loses ~1e-6 per unit on the split-f16
+// factorization (case 3047): there the whole of W counts in full and the limit is a quarter (host).  Rows above
+// refine_limit are marked.
 template <int T>
 __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T], float minpiv, float wmax, int row, int lane) {
   if (!(minpiv > p.sing_threshold)) {
@@ -905,7 +909,7 @@ __device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tr
   add_ridge<T>(p, acc, n_u, lane);
   float minpiv = 3.0e38f;
   float xcol[T];
-  const float wmax = fmaxf(rmax, 0.25f * __int_as_float(max_entry_bits<T>(acc, lane)));
+  const float wmax = fmaxf(rmax, p.gramian_weight * __int_as_float(max_entry_bits<T>(acc, lane)));
   cholesky_tiles<T>(acc, lane, minpiv);
   solve_tiles<T>(acc, bcol, xcol, lane);
   store_row<T>(p, xcol, minpiv, wmax, row, lane);
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
     if (prime_next) pp.ch = chunk_issue(p, nxt.begin, nxt.len, 0, lane);
     const WorkItem nxt2 = load_item(p, it + 2 * n_waves);
     if (MODE == 0) {
-      const float wmax = p.refine_flag ? fmaxf(row_part_max<T>(acc, sG, lane), 0.25f * __int_as_float(max_entry_bits<T>(acc, lane))) : 0.f;
+      const float wmax = p.refine_flag ? fmaxf(row_part_max<T>(acc, sG, lane), p.gramian_weight * __int_as_float(max_entry_bits<T>(acc, lane))) : 0.f;
       add_ridge<T, FULL>(p, acc, cur.len, lane);
       float minpiv = 3.0e38f;
       float xcol[T];
@@ -1124,7 +1128,7 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
         if (tr) t2 = __builtin_readcyclecounter();
 #endif
         solve_tiles<T>(acc, bcol, xcol, lane);
-        store_row<T>(p, xcol, minpiv, fmaxf(rmax, 0.25f * wmax), cur.id, lane);
+        store_row<T>(p, xcol, minpiv, fmaxf(rmax, p.gramian_weight * wmax), cur.id, lane);
 #ifdef MALS_PROFILING
         if (tr) {
           const unsigned long long t3 = __builtin_readcyclecounter();

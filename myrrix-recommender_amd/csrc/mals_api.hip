@@ -1764,6 +1764,11 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   // also reproduces that mode's fp32-rounded products: the estimate is at its weakest there (measured 100x and more
   // below cond(W) for rows with about as many entries as features), so the bar is lower
   p.refine_limit = (h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) ? h->refine_limit / 16.f : h->refine_limit;
+  p.gramian_weight = 0.25f;
+  if (h->cfg.flags & MALS_FLAG_RECONSTRUCT_R) {   // no confidence weights: W = G + rho I (or the plain sum of y y^T)
+    p.gramian_weight = 1.f;
+    p.refine_limit *= 0.25f;
+  }
   {
     if (s.refine_cap < (size_t)s.n_local) {
       HIPCHK(h, hipStreamSynchronize(h->stream));

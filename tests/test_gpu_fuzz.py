@@ -9,8 +9,8 @@ SingularMatrix the HIP path must raise SingularSystem.
 What the sweep has found so far (each fixed and pinned in tests/test_gpu_outliers.py): ill-conditioned rows beyond
 what fp32 can solve (marks + als_refine_kernel), fp32 pivots that are noise (als_exact_kernel), a singularity
 verdict that needs the reference's pivoted QR (mals_check), a padding pivot that polluted the estimate, answers
-that depend on the reference rounding every product of M^T M to fp32 (gramian_ref_kernel).  MALS_FUZZ_SEEDS=3000
-passes in full."""
+that depend on the reference rounding every product of M^T M to fp32 (gramian_ref_kernel), a reconstructR case
+whose whole W is the Gramian (its entries count in full there).  MALS_FUZZ_SEEDS=10000 passes in full."""
 import os
 
 import numpy as np
@@ -78,7 +78,10 @@ def draw_case(seed):
     return k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MALS_FUZZ_SEEDS", "240"))))   # MALS_FUZZ_SEEDS=2000: a longer hunt
+_FIRST = int(os.environ.get("MALS_FUZZ_FIRST", "0"))   # MALS_FUZZ_FIRST=3000 MALS_FUZZ_SEEDS=6000: seeds 3000 .. 8999
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + int(os.environ.get("MALS_FUZZ_SEEDS", "240"))))   # MALS_FUZZ_SEEDS=3000: a longer hunt
 def test_seeded_configuration_sweep(seed):
     k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg = draw_case(seed)
     kw = dict(alpha=cfg["alpha"], lam=cfg["lam"], flags=cfg["flags"], threads=4)
