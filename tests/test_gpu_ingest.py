@@ -153,3 +153,21 @@ def test_large_stream_properties():
     assert np.array_equal(col[a], crow) and np.array_equal(rows[a], ccol) and np.array_equal(val[a], cval)
     print("ingest 2e8 records: %.1f ms, %.0f M records/s, %d radix passes, %.0f GB/s algorithmic" %
           (st["finish_ms"], n / st["finish_ms"] / 1e3, st["radix_passes"], st["bytes_moved"] / st["finish_ms"] / 1e6))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_seeded_stream_sweep(seed):
+    """Random record streams over the whole shape space (sizes around the sort's tile boundaries, few or many ids,
+    wide and negative ids, removal and cancellation rates, value sets that cancel exactly, thresholds) -- bit-exact
+    against the oracle's replay of MatrixUtils.addTo / remove."""
+    rng = np.random.default_rng(31_000 + seed)
+    n = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 1023, 4096, 4097, 10000, 65536, 65537, 150000]))
+    n_users = int(rng.choice([1, 2, 7, 100, 5000, 100000]))
+    n_items = int(rng.choice([1, 3, 50, 3000, 80000]))
+    id_scale = int(rng.choice([1, 1, 7919, -3, 2**40 + 11]))
+    values = [None, None, [1.0, -1.0, 0.5, 2.0, 0.00003, 1e-5], [1.0, -1.0], [0.0, 1e-7, -1e-7, 3.0]][int(rng.integers(0, 5))]
+    u, i, v = random_stream(rng, n, n_users, n_items, float(rng.choice([0.0, 0.02, 0.3, 0.9])), id_scale, values)
+    if rng.random() < 0.2:   # sorted input, as a log replay would deliver it
+        order = np.lexsort((i, u))
+        u, i, v = u[order], i[order], v[order]
+    check(u, i, v, thr=float(rng.choice([1.0e-4, 1.0e-4, 0.0, 0.5])))

@@ -23,15 +23,17 @@ def make(k, n_users, n_items, nnz, seed):
     return core, r_csr, core.get_factors(pkg.SIDE_X), core.get_factors(pkg.SIDE_Y)
 
 
-def same_ranking(idx, sc, oidx, osc):
+def same_ranking(idx, sc, oidx, osc, atol=1e-12):
     """Scores equal (the fp64 sum may be taken in another order: at most the last bit of the fp32 cast);
-    the same items, except where neighbours are that close."""
+    the same items, except where neighbours are that close.  atol: the reference rounds every product x_f y_f to
+    fp32 before adding it (SimpleVectorMath.dot, SVM:34-41), the device adds exact products -- a score that is a
+    small difference of large terms differs by up to 6e-8 sum |x_f y_f| (the sweep passes that bound)."""
     n = len(oidx)
     assert np.all(idx[n:] == -1)
-    assert np.allclose(sc[:n], osc, rtol=2e-7, atol=1e-12)
+    assert np.allclose(sc[:n], osc, rtol=2e-7, atol=atol), (sc[:n], osc)
     if not np.array_equal(idx[:n], oidx):
         for j in np.flatnonzero(idx[:n] != oidx):
-            near = np.isclose(osc, osc[j], rtol=4e-7, atol=1e-12)
+            near = np.isclose(osc, osc[j], rtol=4e-7, atol=2 * atol)
             assert idx[j] in oidx[near], (j, idx[j], oidx[j])
 
 
@@ -155,3 +157,46 @@ def test_filter_path_with_massive_ties_and_exclusions():
         for j in range(2):
             oidx, osc = to.recommend(Y, q[j], 12, excl[j])
             assert np.array_equal(idx[j], oidx) and np.array_equal(sc[j], osc)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_seeded_recommend_sweep(seed):
+    """Random feature counts, catalogue sizes (below and above the filter path's threshold), result counts, query
+    batches, known-item handling and score structures (ties, negative scores, fewer candidates than results) against
+    the oracle's RecommendIterator + TopN."""
+    rng = np.random.default_rng(77_000 + seed)
+    k = int(rng.choice([1, 2, 7, 16, 30, 33, 64, 100, 128]))
+    n_items = int(rng.choice([1, 5, 63, 64, 65, 1000, 4097, 30000, 70000]))
+    n_users = int(rng.integers(1, 200))
+    how_many = int(rng.choice([1, 2, 10, 64, 300]))
+    X = rng.standard_normal((n_users, k)).astype(np.float32)
+    Y = rng.standard_normal((n_items, k)).astype(np.float32)
+    mode = int(rng.integers(0, 4))
+    if mode == 1:      # massive ties: a handful of distinct item vectors
+        Y = Y[rng.integers(0, min(n_items, 4), size=n_items)]
+    elif mode == 2:    # all scores negative for half of the users
+        Y = np.abs(Y)
+        X[::2] = -np.abs(X[::2])
+    elif mode == 3:    # quantised scores
+        X, Y = np.round(X), np.round(Y)
+    lens = np.minimum(rng.integers(0, max(2, min(n_items, 40)), size=n_users), n_items)
+    if rng.random() < 0.3:
+        lens[rng.integers(0, n_users)] = n_items          # a user who knows every item
+    row_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = np.concatenate([np.sort(rng.choice(n_items, size=int(n), replace=False)) for n in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    val = np.ones(len(col), dtype=np.float32)
+    with pkg.ALSCore(k) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_matrix(pkg.SIDE_X, row_ptr, col, val)
+        core.set_factors(pkg.SIDE_X, X)
+        core.set_factors(pkg.SIDE_Y, Y)
+        users = np.sort(rng.choice(n_users, size=min(n_users, int(rng.choice([1, 3, 64, 65, 130]))), replace=False)).astype(np.int64)
+        for consider_known in (False, True):
+            idx, sc, cnt = core.recommend(users, how_many, consider_known_items=consider_known)
+            for q, u in enumerate(users):
+                known = None if consider_known else col[row_ptr[u]:row_ptr[u + 1]]
+                oidx, osc = to.recommend(Y, X[u], how_many, known)
+                assert cnt[q] == len(oidx), (seed, q, cnt[q], len(oidx))
+                bound = 1.2e-7 * float(np.max(np.abs(Y) @ np.abs(X[u]))) + 1e-12
+                same_ranking(idx[q], sc[q], oidx, osc, atol=bound)
