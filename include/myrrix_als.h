@@ -442,6 +442,7 @@ int mals_group_world(mals_group g);
  * and its rank -- for per-GPU calls such as mals_get_stats, mals_recommend, mals_reconstruction_error */
 int mals_group_local(mals_group g, int32_t i, mals_handle* handle_out, int32_t* rank_out);
 int mals_group_set_exchange_chunks(mals_group g, int32_t n_chunks); /* default 4 */
+int mals_group_set_refine_limit(mals_group g, double limit);        /* mals_set_refine_limit on every local member */
 
 /* Replicas: n_rows_total rows per side on every rank (>= the matrix rows: stale Y rows, ALS:304-308). */
 int mals_group_set_factor_rows(mals_group g, int side, int64_t n_rows_total);

@@ -559,6 +559,13 @@ int mals_group_set_exchange_chunks(mals_group g, int32_t n_chunks) {
   return MALS_OK;
 }
 
+int mals_group_set_refine_limit(mals_group g, double limit) {
+  if (!g) return MALS_INVALID_ARG;
+  for (Member& mb : g->m)
+    if (int rc = mals_set_refine_limit(mb.h, limit)) return mfail(g, mb, rc);
+  return MALS_OK;
+}
+
 int mals_group_set_factor_rows(mals_group g, int side, int64_t n_rows_total) {
   GSIDE(g, side);
   for (Member& mb : g->m)

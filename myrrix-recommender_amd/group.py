@@ -159,6 +159,10 @@ class GroupALS:
             raise Cancelled(rc, msg)
         raise MalsError(rc, msg)
 
+    def set_refine_limit(self, limit):
+        """mals_group_set_refine_limit: see mals_set_refine_limit (every local member)."""
+        self._chk(self._L.mals_group_set_refine_limit(self._g, float(limit)))
+
     def local(self, i=0):
         """(ALSCore view, rank) of local member i -- stats, top-N, reconstruction error per GPU."""
         h, r = ctypes.c_void_p(), ctypes.c_int32()
