@@ -803,20 +803,10 @@ __device__ __forceinline__ void add_ridge(const SolveParams& p, f32x4 (&acc)[tri
   }
 }
 
-// Scale the row's system W x = b by s^2 = 2^(2p) with s * sqrt(max_i W_ii) <= 2^13 (entries of the
-// Cholesky factor of s^2 W are then <= 2^13): exact, and undone by comparing the pivots against
-// threshold * s^2 (the caller multiplies minpiv by the returned 1/s^2) -- x itself is unchanged.
 // bit pattern of the largest |entry| of the diagonal tiles of an SPD matrix = its largest diagonal element = its
 // largest |entry| (no need to pick the diagonal out of the tiles); uniform over the wave.  Non-negative floats order
 // like their bit patterns: integer max (a float max of a DPP / bpermute result costs an extra canonicalising v_max).
-template <int T>
-__device__ __forceinline__ int max_entry_bits(const f32x4 (&acc)[tri(T)], int lane) {
-  float mf = 0.f;
-#pragma unroll
-  for (int v = 0; v < T; ++v) {
-    const f32x4& d = acc[tidx(T, v, v)];
-    mf = fmaxf(mf, fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3]))));
-  }
+__device__ __forceinline__ int wave_max_bits(float mf, int lane) {
   int m = __float_as_int(mf);
   m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x120 + 8, 0xf, 0xf, false));
   m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x120 + 4, 0xf, 0xf, false));
@@ -826,19 +816,33 @@ __device__ __forceinline__ int max_entry_bits(const f32x4 (&acc)[tri(T)], int la
   m = max(m, bperm_i((lane ^ 32) << 2, m));
   return m;
 }
+template <int T>
+__device__ __forceinline__ int max_entry_bits(const f32x4 (&acc)[tri(T)], int lane) {
+  float mf = 0.f;
+#pragma unroll
+  for (int v = 0; v < T; ++v) {
+    const f32x4& d = acc[tidx(T, v, v)];
+    mf = fmaxf(mf, fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3]))));
+  }
+  return wave_max_bits(mf, lane);
+}
 
 // the same for W minus the Gramian image it started from: the largest entry of the row's own part sum w y y^T
 // (gimg: [tile][lane] float4 image, global or LDS; zeros under lossIgnoresUnspecified)
 template <int T>
 __device__ __forceinline__ float row_part_max(const f32x4 (&acc)[tri(T)], const f32x4* gimg, int lane) {
-  f32x4 d[tri(T)];
+  float mf = 0.f;
 #pragma unroll
-  for (int t = 0; t < tri(T); ++t) d[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int v = 0; v < T; ++v) d[tidx(T, v, v)] = acc[tidx(T, v, v)] - gimg[tidx(T, v, v) * 64 + lane];
-  return __int_as_float(max_entry_bits<T>(d, lane));
+  for (int v = 0; v < T; ++v) {
+    const f32x4 d = acc[tidx(T, v, v)] - gimg[tidx(T, v, v) * 64 + lane];
+    mf = fmaxf(mf, fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3]))));
+  }
+  return __int_as_float(wave_max_bits(mf, lane));
 }
 
+// Scale the row's system W x = b by s^2 = 2^(2p) with s * sqrt(max_i W_ii) <= 2^13 (entries of the
+// Cholesky factor of s^2 W are then <= 2^13): exact, and undone by comparing the pivots against
+// threshold * s^2 (the caller multiplies minpiv by the returned 1/s^2) -- x itself is unchanged.
 // wmax <- the largest entry of W before the scaling
 template <int T>
 __device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T], int lane, float& wmax) {
@@ -1179,7 +1183,8 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
   rc.row = uniform(rc.row);
   rc.nseg = uniform(rc.nseg);
   f32x4 acc[tri(T)];
-  init_acc<T>(p, acc, lane);
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bcol[T];
 #pragma unroll
   for (int v = 0; v < T; ++v) bcol[v] = 0.f;
@@ -1198,13 +1203,12 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
     for (int v = 0; v < T; ++v) bcol[v] += bp[v];
   }
   const int n_u = uniform((int)(p.row_ptr[rc.row + 1] - p.row_ptr[rc.row]));
-  float rmax = 0.f;
-  if (p.refine_flag) {
-    if (p.flags & 2) {
-      rmax = __int_as_float(max_entry_bits<T>(acc, lane));
-    } else {
-      rmax = row_part_max<T>(acc, reinterpret_cast<const f32x4*>(p.Gf), lane);
-    }
+  // the row's own part first (its largest entry feeds the conditioning estimate), then the shared Gramian under it
+  const float rmax = p.refine_flag ? __int_as_float(max_entry_bits<T>(acc, lane)) : 0.f;
+  if (!(p.flags & 2)) {
+    const f32x4* G4 = reinterpret_cast<const f32x4*>(p.Gf) + lane;
+#pragma unroll
+    for (int t = 0; t < tri(T); ++t) acc[t] += G4[t * 64];
   }
   finish_row<T>(p, acc, bcol, n_u, rc.row, lane, rmax);
 }
