@@ -32,8 +32,9 @@ def draw_case(seed):
     rng = np.random.default_rng(100_000 + seed)
     k = int(rng.choice([1, 2, 3, 5, 8, 10, 15, 16, 17, 20, 24, 30, 31, 32, 33, 40, 47, 48, 49, 50, 63, 64, 65, 72, 80, 96, 97, 100,
                         111, 112, 113, 120, 127, 128]))
-    n_users = int(rng.integers(40, 900))
-    n_items = int(rng.integers(30, 500))
+    scale = int(os.environ.get("MALS_FUZZ_SCALE", "1"))   # MALS_FUZZ_SCALE=4: the same sweep on 4x larger shapes
+    n_users = int(rng.integers(40, 900 * scale))
+    n_items = int(rng.integers(30, 500 * scale))
     # row-length profile of the user side: a mix of empty, short, medium and a few very long rows
     lens = np.zeros(n_users, dtype=np.int64)
     kind = rng.random(n_users)
