@@ -75,6 +75,7 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
                                           int flags, int[] devices, boolean peerCopy);
   private static native void nativeDestroy(long group);
   private static native String nativeLastError(long group);
+  private static native int nativeSetRefineLimit(long group, double limit);
   private static native int nativeSetFactorRows(long group, int side, long nRowsTotal);
   private static native int nativeBeginMatrix(long group, int side, long nRows, long[] rowPtr);
   private static native int nativeAppendRows(long group, int side, long nRows, int[] colIdx, float[] val, int nEntries);
@@ -214,6 +215,12 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
           "mals_group_create failed: a HIP device is required, there is no CPU fallback"));
     }
     try {
+      // rows whose system is too ill-conditioned for fp32 are solved again with fp64 residuals: the conditioning
+      // estimate above which that happens (include/myrrix_als.h, mals_set_refine_limit); unset = the library's default
+      String refineLimit = System.getProperty("model.als.gpu.refineLimit");
+      if (refineLimit != null) {
+        check(group, nativeSetRefineLimit(group, Double.parseDouble(refineLimit)));
+      }
       check(group, nativeSetFactorRows(group, SIDE_X, Math.max(1, userIDs.length)));
       check(group, nativeSetFactorRows(group, SIDE_Y, Math.max(1, itemIDs.length)));
       streamRows(group, SIDE_X, RbyRow, userIDs, userIDs.length, itemIndex);

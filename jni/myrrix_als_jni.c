@@ -67,6 +67,13 @@ JNIEXPORT jstring JNICALL JNI_FN(nativeLastError)(JNIEnv* env, jclass cls, jlong
   return (*env)->NewStringUTF(env, group ? mals_group_last_error(as_group(group)) : "null group");
 }
 
+/* mals_group_set_refine_limit: the conditioning estimate above which a row is solved again with fp64 residuals */
+JNIEXPORT jint JNICALL JNI_FN(nativeSetRefineLimit)(JNIEnv* env, jclass cls, jlong group, jdouble limit) {
+  (void)env;
+  (void)cls;
+  return mals_group_set_refine_limit(as_group(group), limit);
+}
+
 JNIEXPORT jint JNICALL JNI_FN(nativeSetFactorRows)(JNIEnv* env, jclass cls, jlong group, jint side, jlong n_rows_total) {
   (void)env;
   (void)cls;

@@ -2,7 +2,7 @@
 // jni/myrrix_als_jni.c issues for one HipAlternatingLeastSquares.call()
 // (java/net/myrrix/online/factorizer/als/HipAlternatingLeastSquares.java):
 //   mals_default_config, mals_group_create(devices, n)
-//   mals_group_set_factor_rows(X), (Y)
+//   mals_group_set_refine_limit (optional), mals_group_set_factor_rows(X), (Y)
 //   mals_group_begin_matrix / mals_group_append_rows (pieces of whole rows) / mals_group_end_matrix, for R and R^T
 //   mals_group_set_factors(Y, pieces)                      setPreviousY / initial Y
 //   mals_group_factorize                                    call()
@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
     std::printf("mals_group_create failed: a HIP device is required, there is no CPU fallback\n");
     return 3;
   }
+  REQUIRE_OK(mals_group_set_refine_limit(g, 128.0));   // -Dmodel.als.gpu.refineLimit, when set
   REQUIRE_OK(mals_group_set_factor_rows(g, MALS_SIDE_X, n_users));
   REQUIRE_OK(mals_group_set_factor_rows(g, MALS_SIDE_Y, n_items));
   std::vector<int64_t> row_ptr;
