@@ -7,6 +7,11 @@
 //     (gather_row_h, the default above k = 16) or fp32 on v_mfma_f32_16x16x4_f32 (gather_row).
 // K3  blocked Cholesky + triangular solves on the accumulator tiles, in registers, fused behind K2
 //     (replaces MatrixUtils.getSolver(Wu).solveDToF, ALS:494 -> CMLSS:37-55, CMS:37-44).
+// K4  the rows fp32 cannot solve as the reference's fp64 does (marked by K3's conditioning estimate):
+//     als_refine_kernel (CG on the exact system, K3's factor as preconditioner), als_exact_kernel (the reference's
+//     arithmetic in fp64, roundings included), gramian_ref_kernel (MU:232's fp32-rounded products, on demand).
+//     K1 also has a split-f16 variant for large matrices (gramian_split_kernel); pad_rows_kernel makes the
+//     64-byte-aligned gather table when k % 16 != 0.
 //
 // Fragment layouts (cdna_hip_programming.md section 3):
 //   v_mfma_f32_16x16x4_f32  : lane l supplies A[i=l&15][kk=l>>4], B[kk=l>>4][j=l&15];
