@@ -488,7 +488,7 @@ int mals_group_synchronize(mals_group g);
  * a quarter of the largest entry of W) / (smallest pivot) -- and a row above `limit` is solved again
  * (als_refine_kernel): the same fp32 factor as preconditioner, conjugate gradients on the exact system with every
  * product in fp64 straight from the entries, the factor rows and the fp64 Gramian, until a step is below 1e-6 |x|.
- * Default 128 (environment MALS_REFINE_LIMIT overrides it at mals_create; a sixteenth of it applies under
+ * Default 64 (environment MALS_REFINE_LIMIT overrides it at mals_create; a sixteenth of it applies under
  * MALS_FLAG_LOSS_IGNORES_UNSPECIFIED); 0 = never.  Independently of the limit, a row whose fp32 factorization
  * breaks down (pivot <= singularity_threshold) is re-done in fp64 with the reference's own roundings
  * (als_exact_kernel) before it is called singular.  mals_stats.rows_refined counts both. */

@@ -110,7 +110,7 @@ struct mals_handle_s {
   size_t Mp_cap = 0;          // floats
   // mixed-precision refinement of ill-conditioned rows (als_refine_kernel): estimate above which a row is re-solved
   // (MALS_REFINE_LIMIT / mals_set_refine_limit; 0 = off), rows refined so far (device counter)
-  float refine_limit = 128.f;
+  float refine_limit = 64.f;
   bool exact_ready = false;   // als_exact_kernel's dynamic LDS limit raised
   int* d_gref_state = nullptr;   // {a row was marked in this half-iteration, Gref is valid, arrival ticket}
   double* d_Gref = nullptr;      // the reference-rounded Gramian of the gathered side (gramian_ref_kernel), on demand
