@@ -71,3 +71,28 @@ def test_marked_rows_refined_by_preconditioned_cg_reach_the_reference():
     assert marked > n_items // 2
     assert rel(fast) > 1e-4              # what fp32 alone does to these systems
     assert rel(refined) < 2e-6           # the marks + CG against the exact system
+
+
+def test_fp64_restatement_with_the_reference_roundings_reaches_the_reference_where_exact_arithmetic_does_not():
+    """als_exact_kernel's arithmetic on case 1085 (reconstructR + lossIgnoresUnspecified, lambda = 0.01, cond(W) ~ 1e7):
+    W = sum over the row's entries of (double)(float)(y_r y_c) (ALS:524-539), b = sum r y, an fp64 LDL^T.  With the
+    products rounded like the reference's the answer is the oracle's; with exact products it is 1e-2 away."""
+    k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg = draw_case(1085)
+    assert cfg["flags"] == 3
+    kw = dict(alpha=cfg["alpha"], lam=cfg["lam"], flags=3, threads=4)
+    Xo = oracle.half_iteration(*r_csr, Y0, **kw)
+    Yo = oracle.half_iteration(*c_csr, Xo, **kw)
+    rp, col, val = c_csr
+    rounded, exact = np.zeros_like(Yo), np.zeros_like(Yo)
+    for r in range(n_items):
+        a, b = rp[r], rp[r + 1]
+        y32 = Xo[col[a:b]].astype(np.float32)
+        rhs = y32.astype(np.float64).T @ val[a:b].astype(np.float64)                        # ALS:466-469
+        ridge = cfg["lam"] * cfg["alpha"] * (b - a) * np.eye(k)
+        W_ref = np.einsum("er,ec->erc", y32, y32).astype(np.float32).astype(np.float64).sum(0) + ridge   # float products
+        W_exact = y32.astype(np.float64).T @ y32.astype(np.float64) + ridge
+        rounded[r] = np.linalg.solve(W_ref, rhs)
+        exact[r] = np.linalg.solve(W_exact, rhs)
+    rel = lambda a: float(np.linalg.norm(a.astype(np.float64) - Yo) / np.linalg.norm(Yo))   # noqa: E731
+    assert rel(rounded) < 1e-6
+    assert rel(exact) > 1e-3
