@@ -28,6 +28,11 @@ WORKLOADS = {
     "c3": (480_189, 17_770, 100_480_507, 100, "C3 Netflix shape 480189 x 17770, 100M interactions requested, k=100"),
     "c4shard8": (1_250_000, 1_000_000, 125_000_000, 64, "one rank's user rows of C4 at 8 GPUs (1.25M x 1M, 125M interactions requested), k=64"),
     "c5shard8": (12_500_000, 10_000_000, 625_000_000, 128, "one rank's user rows of C5 at 8 GPUs (12.5M x 10M, 625M interactions requested), k=128"),
+    # one rank of C5 at 8 GPUs at the shape it really has: BOTH slices of the rank, each gathering from the FULL opposite
+    # replica -- 12.5M user rows (625M entries) against the 10M x 128 Y, 1.25M item rows (625M entries, ~500 per row)
+    # against the 100M x 128 X (51.2 GB).  (users, items) below = the rows this rank solves per iteration.
+    "c5rank": (12_500_000, 1_250_000, 1_250_000_000, 128, "one rank of C5 at 8 GPUs, both slices at true shape: 12.5M user rows x 10M items (625M entries) "
+               "+ 1.25M item rows x 100M users (625M entries) gathering from the full 100M x 128 X replica (51.2 GB), k=128"),
     "k128long": (1_000_000, 100_000, 400_000_000, 128, "k=128 with long rows (1M x 100K, 400M interactions requested)"),
     "k112": (2_000_000, 200_000, 200_000_000, 112, "k=112 (2M x 200K, 200M interactions requested)"),
     "k30": (10_000_000, 1_000_000, 1_000_000_000, 30, "the reference's default feature count on the C4 shape (10M x 1M, 1e9 interactions requested, k=30)"),
@@ -120,6 +125,79 @@ def jvm_baseline(torch, prob, n_users, n_items, k, sample_users=20000):
             "sample": "the real net.myrrix AlternatingLeastSquares on %d sampled users x the items they touch (%d entries), JVM on this host" % (len(users), n)}
 
 
+def rank_problem(torch, synth, n_users, n_items, nnz_side, k, device, world_emulated=8, rank=3, planted=0.3):
+    """Both slices of ONE rank of a `world_emulated`-GPU run, each against the FULL opposite side (the rank's shape of
+    SURVEY.md 8(e) / App. C): user rows [u_off, u_off + n_users) of R over all n_items * world items, item rows
+    [i_off, i_off + n_items) of R^T over all n_users * world users."""
+    n_users_total, n_items_total = n_users * world_emulated, n_items * world_emulated
+    p = synth.torch_problem(n_users, n_items_total, nnz_side, k, device, planted=planted)
+    r_csr, Y0, planted_desc = p["r_csr"], p["Y0"], p["planted"]
+    del p
+    torch.cuda.empty_cache()
+    c_csr = synth.torch_slice(n_items, n_users_total, nnz_side, device, rows="items")
+    g = torch.Generator(device=device)
+    g.manual_seed(synth.SEED + 2)
+    # the X replica as the other ranks' all-gathers would have left it: rows of the size a solved user row has
+    X0 = torch.randn(n_users_total, k, generator=g, device=device, dtype=torch.float32)
+    X0 *= 0.3 / k ** 0.5
+    return {"r_csr": r_csr, "c_csr": c_csr, "Y0": Y0, "X0": X0, "nnz": int(r_csr[1].numel() + c_csr[1].numel()), "planted": None,
+            "planted_user_slice": planted_desc, "rank": rank, "u_off": rank * n_users, "i_off": rank * n_items,
+            "n_users_total": n_users_total, "n_items_total": n_items_total}
+
+
+class RankDriver:
+    """One rank of a group without its peers: the rank's own slices are solved for real, the rows of the other ranks
+    stay what they were (as if their all-gathers had delivered them), and the shared Gramian is the rank's partial over
+    its own 1/world of the rows + the (constant) sum of the others' partials -- what the k x k all-reduce would deliver.
+    No exchange is timed: this prices the COMPUTE of a C5 rank at its true shape."""
+
+    def __init__(self, torch, pkg, core, prob, k, device):
+        self.torch, self.pkg, self.core, self.k = torch, pkg, core, k
+        self.off = {pkg.SIDE_X: prob["u_off"], pkg.SIDE_Y: prob["i_off"]}
+        self.n = {pkg.SIDE_X: prob["r_csr"][0].numel() - 1, pkg.SIDE_Y: prob["c_csr"][0].numel() - 1}
+        self.tot = {pkg.SIDE_X: prob["n_users_total"], pkg.SIDE_Y: prob["n_items_total"]}
+        self.F = {pkg.SIDE_X: prob["X0"], pkg.SIDE_Y: torch.zeros(self.tot[pkg.SIDE_Y], k, dtype=torch.float32, device=device)}
+        self.F[pkg.SIDE_Y][:prob["Y0"].shape[0]].copy_(prob["Y0"])
+        for side in (pkg.SIDE_X, pkg.SIDE_Y):
+            core.bind_factors(side, self.F[side])
+        core.set_matrix(pkg.SIDE_X, *prob["r_csr"], row_offset=self.off[pkg.SIDE_X])
+        core.set_matrix(pkg.SIDE_Y, *prob["c_csr"], row_offset=self.off[pkg.SIDE_Y])
+        self.per = self.n
+        self._gp = torch.zeros(k, k, dtype=torch.float64, device=device)
+        self._g = torch.zeros(k, k, dtype=torch.float64, device=device)
+        self.rest = {}
+        for side in (pkg.SIDE_X, pkg.SIDE_Y):      # the other ranks' partial Gramians: constant here
+            acc = torch.zeros(k, k, dtype=torch.float64, device=device)
+            for lo, hi in ((0, self.off[side]), (self.off[side] + self.n[side], self.tot[side])):
+                if hi > lo:
+                    core.gramian_partial(side, lo, hi - lo, self._gp)
+                    torch.cuda.synchronize()
+                    acc += self._gp
+            self.rest[side] = acc
+
+    def _gramian(self, side):
+        self.core.gramian_partial(side, self.off[side], self.n[side], self._gp)
+        self.torch.add(self._gp, self.rest[side], out=self._g)
+        self.core.set_gramian(side, self._g)
+
+    def half_iteration(self, side):
+        self._gramian(1 - side)
+        self.core.solve_side(side)
+
+    def iterate(self, n=1, check=True):
+        for _ in range(n):
+            for side in (self.pkg.SIDE_X, self.pkg.SIDE_Y):
+                self.half_iteration(side)
+                if check:
+                    self.core.check()
+
+    def _all_gather(self, side):
+        pass
+
+    def factors(self, side):
+        return self.F[side]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +213,9 @@ def main():
     ap.add_argument("--exchange", default="group", choices=["group", "torch"],
                     help="N>1: 'group' = the library's own RCCL exchange below the C-ABI (mals_group_*, cost-balanced slices); "
                          "'torch' = equal-row slices exchanged with torch.distributed collectives (sharded.py)")
+    ap.add_argument("--planted", type=float, default=0.3,
+                    help="fraction of the interactions planted on the 2048 core items (synth.torch_problem); 0 = the plain SURVEY 8(d) workload "
+                         "(power-law item popularity, log-normal user activity, values 1..5, nothing planted)")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N>1: solve each slice in this many row chunks and all-gather a finished chunk while the next is solved")
     args = ap.parse_args()
@@ -183,8 +264,14 @@ def main():
     red_device = torch.device("cpu") if one_device else device   # where the few scalars of this script are reduced
 
     n_users, n_items, nnz_req, k, desc = WORKLOADS[args.workload]
+    rank_shape = args.workload == "c5rank"
+    if rank_shape:
+        assert world == 1 and not force, "c5rank emulates ONE rank of an 8-GPU group on one GPU"
     t_gen = time.perf_counter()
-    prob = synth.torch_problem(n_users, n_items, nnz_req, k, device)
+    if rank_shape:
+        prob = rank_problem(torch, synth, n_users, n_items, nnz_req // 2, k, device, world_emulated=8, planted=args.planted)
+    else:
+        prob = synth.torch_problem(n_users, n_items, nnz_req, k, device, planted=args.planted)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
@@ -192,7 +279,14 @@ def main():
     gmode = {"auto": 0, "fp32": 1, "split_f16": 2}[args.gramian_mode]
     smode = {"auto": 0, "direct": 1, "dual": 2}[args.solve_mode]
     use_group = (world > 1 or force) and args.exchange == "group"
-    if use_group:
+    if rank_shape:
+        core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, gramian_mode=gmode, solve_mode=smode)
+        core.set_stream(torch.cuda.current_stream().cuda_stream)
+        als = RankDriver(torch, pkg, core, prob, k, device)
+        slice_info = {"emulated_rank": prob["rank"], "emulated_world": 8, "x_rows": [prob["u_off"], prob["u_off"] + n_users], "y_rows": [prob["i_off"], prob["i_off"] + n_items],
+                      "replica_rows": {"x": prob["n_users_total"], "y": prob["n_items_total"]},
+                      "hbm_GB_after_setup": round(torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9, 1)}
+    elif use_group:
         # one rank per process; torch.distributed only carried the RCCL unique id (and the barriers of the
         # timing bracket): slices, partial Gramians, all-reduce and the chunked exchange are the library's
         grp = pkg.GroupALS.from_torch_distributed(k, local_rank, alpha=1.0, lam=0.1, segment_nnz=args.segment_nnz, gramian_mode=gmode,
@@ -384,7 +478,7 @@ def main():
         if one_device or os.environ.get("MALS_RCCL_LIBRARY"):
             out["INVALID_AS_A_MEASUREMENT"] = ("test run: MALS_BENCH_ONE_DEVICE=%s (all ranks on device 0), MALS_RCCL_LIBRARY=%s"
                                                % (os.environ.get("MALS_BENCH_ONE_DEVICE", "0"), os.environ.get("MALS_RCCL_LIBRARY", "")))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not rank_shape:
             X = als.factors(pkg.SIDE_X)
             Y = als.factors(pkg.SIDE_Y)
             out["cpu_baseline"] = cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k)

@@ -119,6 +119,63 @@ def torch_problem(n_users, n_items, nnz, k, device, seed=SEED, chunk=1 << 27, pl
             "planted": {"fraction": planted, "clusters": PLANT_CLUSTERS, "core_items": PLANT_CORE} if planted > 0 else None}
 
 
+def torch_slice(n_rows, n_cols, nnz, device, rows="items", seed=SEED + 1, chunk=1 << 27):
+    """One rank's slice of a matrix side as CSR: `n_rows` contiguous rows of R (rows="users": log-normal
+    activity over the rows, power-law popularity over the n_cols item columns) or of R^T (rows="items":
+    popularity over the rows, activity over the n_cols user columns), exactly `nnz` stored entries, column
+    indices over the WHOLE opposite side -- the shape a rank of an 8-GPU C5 run holds (SURVEY.md App. C:
+    1.25M item rows x ~500 entries whose columns index a 100M-row X replica).  The activity CDF is kept
+    and searched in fp64: at 1e8 columns an fp32 CDF would leave most of them without an entry and shrink
+    the set of rows the gather touches.  Returns (row_ptr int64, col int32, val fp32) on `device`."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n_act, n_pop = (n_rows, n_cols) if rows == "users" else (n_cols, n_rows)
+    act = torch.exp(torch.randn(n_act, generator=g, device=device, dtype=torch.float32)).double()
+    cdf = torch.cumsum(act, 0)
+    cdf /= cdf[-1].clone()
+    del act
+    perm = torch.randperm(n_pop, generator=g, device=device)
+
+    def draw(m):
+        a = torch.searchsorted(cdf, torch.rand(m, generator=g, device=device, dtype=torch.float64)).clamp_(max=n_act - 1)
+        p = (n_pop * torch.rand(m, generator=g, device=device, dtype=torch.float64) ** 3).long().clamp_(max=n_pop - 1)
+        p = perm[p]
+        return (a * n_cols + p) if rows == "users" else (p * n_cols + a)
+
+    target = min(nnz, n_rows * n_cols)
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    want = target
+    for _ in range(64):
+        parts = [keys]
+        done = 0
+        while done < want:
+            m = min(chunk, want - done)
+            parts.append(draw(m))
+            done += m
+        keys = torch.unique(torch.cat(parts))     # sorted by (row, column)
+        del parts
+        if keys.numel() >= target:
+            break
+        want = int((target - keys.numel()) * 1.1) + 1024
+    if keys.numel() > target:
+        drop = torch.randperm(keys.numel(), generator=g, device=device)[:keys.numel() - target]
+        mask = torch.ones(keys.numel(), dtype=torch.bool, device=device)
+        mask[drop] = False
+        keys = keys[mask]
+        del mask, drop
+    del cdf, perm
+    r = torch.div(keys, n_cols, rounding_mode="floor")
+    c = (keys - r * n_cols).int()
+    del keys
+    counts = torch.bincount(r, minlength=n_rows)
+    del r
+    rp = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
+    torch.cumsum(counts, 0, out=rp[1:])
+    vals = torch.randint(1, 6, (c.numel(),), generator=g, device=device).float()
+    return rp, c, vals
+
+
 def planted_reconstruction_error(prob, X, Y, sample=4_000_000):
     """Mean of max(0, 1 - x_u . y_i) over (a sample of) the stored entries of the planted part: core items
     of the user's own cluster.  torch on the device; diagnostics only."""

@@ -35,15 +35,23 @@ def sub_csr(csr, rows, torch):
     return sub_rp.cpu().numpy(), csr[1][ent].cpu().numpy(), csr[2][ent].cpu().numpy()
 
 
-def check_half(core, side, csr, M_host, G, n_rows, rng, torch, n_sample=300, n_long=8):
-    """Compare sampled + longest rows of `side` against the oracle."""
+def check_half(core, side, csr, M, G, n_rows, rng, torch, n_sample=300, n_long=8, row_offset=0):
+    """Compare sampled + longest rows of `side` against the oracle.  M: the opposite factors, a host array or --
+    when the replica is too large to copy (C5's X: 51 GB) -- a device tensor, of which only the rows the sample
+    touches are fetched (columns renumbered; a row's system only depends on the rows it references and on G)."""
     lens = (csr[0][1:] - csr[0][:-1])
     longest = torch.topk(lens, n_long).indices.cpu().numpy()
     sample = rng.choice(n_rows, size=n_sample, replace=False)
     rows = np.unique(np.concatenate([sample, longest])).astype(np.int64)
     rp, col, val = sub_csr(csr, rows, torch)
+    if isinstance(M, np.ndarray):
+        M_host = M
+    else:
+        used, col = np.unique(col, return_inverse=True)
+        col = col.astype(np.int32)
+        M_host = M[torch.as_tensor(used, device=M.device).long()].cpu().numpy()
     expect = oracle.solve_rows(rp, col, val, M_host, G, threads=8)
-    got = core.get_rows(side, rows)
+    got = core.get_rows(side, rows + row_offset)
     assert np.all(np.isfinite(got))
     err = rel(got, expect)
     assert err < REL_TOL, (side, err)
@@ -85,10 +93,11 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
             torch.cuda.synchronize()
             assert rel(gs.cpu().numpy(), oracle.gramian(Y0[12_345:1_012_345])) < 5e-7
         core.reset_stats()
-        # --- X half
+        # --- X half (the oracle gets ITS OWN Gramian of the same Y0 wherever it can compute one in test time)
         core.solve_side(pkg.SIDE_X)
         core.check()
-        max_len_x = check_half(core, pkg.SIDE_X, prob["r_csr"], Y0, Gy, n_users, rng, torch)
+        G_for_oracle = oracle.gramian(Y0) if n_items <= 1_000_000 else Gy
+        max_len_x = check_half(core, pkg.SIDE_X, prob["r_csr"], Y0, G_for_oracle, n_users, rng, torch)
 
         # --- Gramian of X: linearity over row ranges (what the k x k all-reduce relies on) + oracle on a slice
         Gx = core.gramian(pkg.SIDE_X, fetch=True)
@@ -113,7 +122,8 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
         assert np.all(np.isfinite(X))
         core.solve_side(pkg.SIDE_Y)
         core.check()
-        max_len_y = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, Gx, n_items, rng, torch)
+        G_for_oracle = oracle.gramian(X) if n_users <= 1_000_000 else Gx
+        max_len_y = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, G_for_oracle, n_items, rng, torch)
         if "C4" in name or "C3" in name:
             assert max_len_y > 4096, "C3 / C4 must exercise the long-row (segments) path"
         st = core.stats()
@@ -125,3 +135,61 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
         # a solved factor matrix is not degenerate
         assert np.linalg.norm(Y) > 0 and np.linalg.norm(X) > 0
         del max_len_x
+
+
+def test_c5_rank_at_its_true_shape():
+    """BOTH slices of one rank of C5 at 8 GPUs (ALS:340-389): 12.5M user rows against the 10M x 128 Y
+    AND 1.25M item rows (~500 entries each) whose columns index the FULL 100M x 128 X replica (51.2 GB, 200x the
+    Infinity Cache) -- the half `c5shard8` never had.  The replicas are allocated at their real size (the HBM budget
+    of DESIGN section 3), the rank's rows sit at their real offsets inside them, sampled + longest rows of both halves
+    are recomputed by the oracle, and the rows of the other ranks must come out untouched."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1234567890)
+    n_users, n_items, nnz_side, k = 12_500_000, 1_250_000, 625_000_000, 128
+    prob = bench.rank_problem(torch, synth, n_users, n_items, nnz_side, k, dev, world_emulated=8)
+    u_off, i_off = prob["u_off"], prob["i_off"]
+    assert prob["X0"].shape == (100_000_000, k) and prob["Y0"].shape == (10_000_000, k)
+    assert prob["c_csr"][1].numel() == nnz_side and prob["r_csr"][1].numel() == nnz_side
+    assert int(prob["c_csr"][1].max()) > 99_000_000, "item rows must reference the whole 100M-row replica"
+    with pkg.ALSCore(k, device=0) as core:
+        drv = bench.RankDriver(torch, pkg, core, prob, k, dev)
+        X, Y = drv.F[pkg.SIDE_X], drv.F[pkg.SIDE_Y]
+        guard_x = (X[u_off - 1].clone(), X[u_off + n_users].clone())
+        guard_y = (Y[i_off - 1].clone(), Y[i_off + n_items].clone())
+        core.reset_stats()
+
+        # --- user half: rows [u_off, u_off + 12.5M) of X from the 10M-row Y
+        drv.half_iteration(pkg.SIDE_X)
+        core.check()
+        Gy = drv._g.cpu().numpy().copy()
+        gs = torch.zeros(k, k, dtype=torch.float64, device=dev)
+        core.gramian_partial(pkg.SIDE_Y, 12_345, 1_000_000, gs)
+        torch.cuda.synchronize()
+        assert rel(gs.cpu().numpy(), oracle.gramian(Y[12_345:1_012_345].cpu().numpy())) < 5e-7
+        check_half(core, pkg.SIDE_X, prob["r_csr"], Y, Gy, n_users, rng, torch, row_offset=u_off)
+
+        # --- item half: rows [i_off, i_off + 1.25M) of Y from the 100M-row X (the freshly solved user rows included)
+        drv.half_iteration(pkg.SIDE_Y)
+        core.check()
+        Gx = drv._g.cpu().numpy().copy()
+        # the Gramian the rank installed = its own partial + the others' (the all-reduce): against the full kernel
+        assert rel(Gx, core.gramian(pkg.SIDE_X, fetch=True)) < 2e-7
+        core.gramian_partial(pkg.SIDE_X, u_off + 777, 200_000, gs)
+        torch.cuda.synchronize()
+        assert rel(gs.cpu().numpy(), oracle.gramian(X[u_off + 777:u_off + 200_777].cpu().numpy())) < 5e-7
+        max_len = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, Gx, n_items, rng, torch, row_offset=i_off)
+        assert max_len > 4096, "the popular items of the slice go through the long-row (segments) path"
+
+        st = core.stats()
+        assert st["rows_solved"] == n_users + n_items
+        assert st["nnz_gathered"] == 2 * nnz_side
+        assert st["rows_dual"] > 0
+        # nothing outside the rank's slices was written
+        assert torch.equal(X[u_off - 1], guard_x[0]) and torch.equal(X[u_off + n_users], guard_x[1])
+        assert torch.equal(Y[i_off - 1], guard_y[0]) and torch.equal(Y[i_off + n_items], guard_y[1])
+        assert bool(torch.isfinite(Y[i_off:i_off + n_items]).all()) and bool(torch.isfinite(X[u_off:u_off + n_users]).all())
+        # HBM budget of a C5 rank (DESIGN section 3): replicas 56.3 GB + both CSR slices 10 GB + scratch, inside 288 GB
+        free, total = torch.cuda.mem_get_info()
+        assert (total - free) < 200e9, (total - free)
