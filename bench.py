@@ -198,6 +198,45 @@ class RankDriver:
         return self.F[side]
 
 
+def unplanted_leg(torch, pkg, sharded, synth, n_users, n_items, nnz_req, k, args, gmode, smode, local_rank, device):
+    """The same measurement on the plain SURVEY 8(d) workload (power-law item popularity, log-normal user activity, values
+    1..5, NOTHING planted), beside the headline: the planted part makes 30 % of the X-half's gathers hit 2048 hot item rows
+    and moves ~110M entries onto the long-row kernel.  One GPU, same build, same steps."""
+    prob = synth.torch_problem(n_users, n_items, nnz_req, k, device, planted=0.0)
+    core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, gramian_mode=gmode, solve_mode=smode)
+    core.set_stream(torch.cuda.current_stream().cuda_stream)
+    als = sharded.ShardedALS(core, n_users, n_items, k, rank=0, world=1, device=device)
+    als.set_matrix_from_full(pkg.SIDE_X, *prob["r_csr"])
+    als.set_matrix_from_full(pkg.SIDE_Y, *prob["c_csr"])
+    als.set_factors(pkg.SIDE_Y, prob["Y0"])
+    als.iterate(args.warmup, check=True)
+    core.enable_timing(True)
+    core.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    als.iterate(args.steps, check=False)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    core.check()
+    st = core.stats()
+    core.enable_timing(False)
+    n_launch = max(st["rows_launches"], 1)
+    avg_ms = st["rows_ms"] / n_launch
+    achieved = st["rows_bytes"] / n_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    it_bytes = (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps
+    ms = 1e3 * elapsed / args.steps
+    out = {"workload": "the same shape with nothing planted (SURVEY.md 8(d) as written)", "nnz": int(prob["nnz"]),
+           "ms_per_step": ms, "value": (n_users + n_items) / (elapsed / args.steps), "unit": "rows/s",
+           "kernel": "rows kernel (als_persistent_kernel_h, MODE 0)", "avg_launch_ms": avg_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
+           "frac": achieved / HBM_PEAK_GBS, "iteration_frac": it_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian", "dual", "rotate")},
+           "rows_refined_per_step": st["rows_refined"] / args.steps}
+    core.close()
+    del als, prob
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +255,8 @@ def main():
     ap.add_argument("--planted", type=float, default=0.3,
                     help="fraction of the interactions planted on the 2048 core items (synth.torch_problem); 0 = the plain SURVEY 8(d) workload "
                          "(power-law item popularity, log-normal user activity, values 1..5, nothing planted)")
+    ap.add_argument("--no-unplanted", action="store_true",
+                    help="N=1: skip the second, untimed-by-the-headline leg on the un-planted workload (roofline_unplanted)")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N>1: solve each slice in this many row chunks and all-gather a finished chunk while the next is solved")
     args = ap.parse_args()
@@ -241,9 +282,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # MALS_BENCH_ONE_DEVICE=1 (tests only, tests/test_gpu_group_transport.py): every rank on device 0 and torch's own
-    # rendezvous on gloo -- with MALS_RCCL_LIBRARY pointing at the tests' stand-in transport this runs the whole N > 1
-    # flow of this script on a box with one GPU.  The numbers of such a run mean nothing.
+    # rendezvous on gloo -- with MALS_BENCH_TRANSPORT pointing at the tests' stand-in transport (this SCRIPT then calls
+    # mals_group_use_transport; the library itself reads no such variable) this runs the whole N > 1 flow of this script
+    # on a box with one GPU.  The numbers of such a run mean nothing.
     one_device = os.environ.get("MALS_BENCH_ONE_DEVICE", "0") == "1"
+    transport = os.environ.get("MALS_BENCH_TRANSPORT")
+    if transport:
+        pkg.GroupALS.use_transport(transport)
     if one_device:
         local_rank = 0
     if world != args.gpus:
@@ -378,6 +423,7 @@ def main():
         exchange["bytes_received_per_rank"] = {"x": (world - 1) * als.per[pkg.SIDE_X] * k * 4, "y": (world - 1) * als.per[pkg.SIDE_Y] * k * 4}
     # untimed quality figure: ReconstructionEvaluator's mean over the observed entries (8(f) row 3)
     rec_sum, rec_cnt = core.reconstruction_error()
+    own_elapsed = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -386,6 +432,25 @@ def main():
         dist.all_reduce(q)
         rec_sum, rec_cnt = float(q[0].item()), int(q[1].item())
 
+    # N > 1: what every rank saw, so that the line proves itself -- size and rank READ BACK from the RCCL communicator,
+    # the HIP device and its PCI bus id, the rows / entries of the rank's two slices, the rank's own clock
+    ranks_info = None
+    if world > 1 or force:
+        mine = {"rank": rank, "local_rank": local_rank, "hip_device": torch.cuda.current_device(), "ms_per_step": 1e3 * own_elapsed / args.steps,
+                "device_name": torch.cuda.get_device_name(local_rank)}
+        if use_group:
+            mine.update(grp.comm_info(0))
+            for side, name in ((pkg.SIDE_X, "x"), (pkg.SIDE_Y, "y")):
+                b = grp.bounds(side)
+                rp = prob["r_csr" if side == pkg.SIDE_X else "c_csr"][0]
+                mine[name + "_rows"] = int(b[rank + 1] - b[rank])
+                mine[name + "_nnz"] = int(rp[int(b[rank + 1])] - rp[int(b[rank])])
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+        else:
+            gathered = [mine]
+        ranks_info = gathered
     planted_err = None
     if world == 1:
         planted_err = synth.planted_reconstruction_error(prob, als.factors(pkg.SIDE_X), als.factors(pkg.SIDE_Y))
@@ -450,6 +515,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # the same fraction on the COUNTER basis: HBM bytes the memory system really moved per launch
+                         "frac_counter": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms > 0 else None,
+                         "iteration_frac": (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "launches": n_launch,
                          "iteration": {"algorithmic_bytes": (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps,
@@ -469,15 +537,23 @@ def main():
             "eigen_host_ms_per_step": st["eigen_host_ms"] / args.steps,
             "half_iteration_kernel_ms": halves,
             "all_gather_alone_ms": exchange,
+            "ranks": ({"per_rank": ranks_info,
+                       "comm_sizes_read_back": sorted({r.get("comm_size") for r in ranks_info}),
+                       "distinct_devices": len({(r.get("pci_bus_id") or r["hip_device"]) for r in ranks_info}),
+                       "ms_per_step_min": min(r["ms_per_step"] for r in ranks_info), "ms_per_step_max": max(r["ms_per_step"] for r in ranks_info)}
+                      if ranks_info else None),
             "reconstruction_error": {"mean": rec_sum / max(rec_cnt, 1), "entries": rec_cnt,
                                      "what": "mean over stored entries of max(0, 1 - x_u.y_i) after warmup+steps iterations "
                                              "(ReconstructionEvaluator.java:91-102), untimed; planted_part = the same over the entries of the "
                                              "planted low-rank part (synth.torch_problem), the only part a factor model can predict",
                                      "planted_part": planted_err},
         }
-        if one_device or os.environ.get("MALS_RCCL_LIBRARY"):
-            out["INVALID_AS_A_MEASUREMENT"] = ("test run: MALS_BENCH_ONE_DEVICE=%s (all ranks on device 0), MALS_RCCL_LIBRARY=%s"
-                                               % (os.environ.get("MALS_BENCH_ONE_DEVICE", "0"), os.environ.get("MALS_RCCL_LIBRARY", "")))
+        if one_device or transport:
+            out["INVALID_AS_A_MEASUREMENT"] = ("test run: MALS_BENCH_ONE_DEVICE=%s (all ranks on device 0), MALS_BENCH_TRANSPORT=%s"
+                                               % (os.environ.get("MALS_BENCH_ONE_DEVICE", "0"), transport or ""))
+        if world == 1 and not rank_shape and not force and args.planted > 0 and prob.get("planted") and not args.no_unplanted:
+            out["roofline_unplanted"] = unplanted_leg(torch, pkg, sharded, synth, n_users, n_items, nnz_req, k, args, gmode, smode, local_rank, device)
+            out["roofline_unplanted"]["slower_than_planted_by"] = out["roofline_unplanted"]["ms_per_step"] / ms_per_step - 1.0
         if world == 1 and not args.no_cpu_baseline and not rank_shape:
             X = als.factors(pkg.SIDE_X)
             Y = als.factors(pkg.SIDE_Y)

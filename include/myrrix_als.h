@@ -441,7 +441,20 @@ int mals_group_world(mals_group g);
 /* the handle of local member i (0 .. n_local-1; n_local = world for mals_group_create, 1 for create_rank)
  * and its rank -- for per-GPU calls such as mals_get_stats, mals_recommend, mals_reconstruction_error */
 int mals_group_local(mals_group g, int32_t i, mals_handle* handle_out, int32_t* rank_out);
-int mals_group_set_exchange_chunks(mals_group g, int32_t n_chunks); /* default 4 */
+/* Row chunks per slice (default 4).  Takes effect with the NEXT matrix upload of each side: a side that already
+ * holds a matrix keeps the count its work lists were built for. */
+int mals_group_set_exchange_chunks(mals_group g, int32_t n_chunks);
+/* Which shared library is loaded as RCCL: by default librccl.so.1 (a copy the process already mapped first).  A
+ * process that wants a particular build -- or the tests' stand-in transport, tests/cpp/libmock_rccl.so -- says so
+ * HERE, once, before its first group or unique id (MALS_INVALID_ARG afterwards); NULL = the default.  Deliberately
+ * not an environment variable: what runs as "RCCL" inside a server process is the process's own decision. */
+int mals_group_use_transport(const char* library_path);
+/* What the communicator itself reports for local member i (ncclCommCount / ncclCommUserRank / ncclCommCuDevice;
+ * 0 / -1 when the group has no communicator: world 1 or the peer-copy backend), the HIP device ordinal of the member
+ * and its PCI bus id ("0000:c1:00.0"; pci_bus_id may be NULL) -- so that a benchmark line can prove how many ranks
+ * RCCL saw and on which devices. */
+int mals_group_comm_info(mals_group g, int32_t local_member, int32_t* comm_size, int32_t* comm_rank, int32_t* hip_device,
+                         char* pci_bus_id, int32_t pci_len);
 int mals_group_set_refine_limit(mals_group g, double limit);        /* mals_set_refine_limit on every local member */
 
 /* Replicas: n_rows_total rows per side on every rank (>= the matrix rows: stale Y rows, ALS:304-308). */
@@ -493,6 +506,13 @@ int mals_group_synchronize(mals_group g);
  * breaks down (pivot <= singularity_threshold) is re-done in fp64 with the reference's own roundings
  * (als_exact_kernel) before it is called singular.  mals_stats.rows_refined counts both. */
 int mals_set_refine_limit(mals_handle h, double limit);
+
+/* Host-side timeline of the current / last half-iteration on this handle (diagnostic), microseconds of one
+ * process-wide steady clock: out4[0] = its first kernel was enqueued, out4[1] / out4[2] = begin / end of the host half
+ * of the dual preparation (the k x k eigendecomposition, computed here or received from the group member that
+ * computed it; 0 = none in this half-iteration), out4[3] reserved.  tests/test_gpu_group.py uses it to check that a
+ * single-process group enqueues every member's kernels before any member's host work. */
+int mals_get_timeline(mals_handle h, double* out4);
 
 int mals_enable_timing(mals_handle h, int32_t on);
 int mals_reset_stats(mals_handle h);

@@ -374,6 +374,12 @@ class ALSCore:
                                            len(ti), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def timeline(self):
+        """mals_get_timeline: host microseconds [first kernel of the half-iteration enqueued, eigendecomposition begin, end, -]."""
+        out = (ctypes.c_double * 4)()
+        self._chk(self._L.mals_get_timeline(self._h, out))
+        return list(out)
+
     def set_refine_limit(self, limit):
         """mals_set_refine_limit: conditioning estimate above which a row is re-solved with fp64 residuals (0 = never)."""
         self._chk(self._L.mals_set_refine_limit(self._h, float(limit)))

@@ -9,6 +9,7 @@
 #include "host_eigen.h"
 #include "host_solver.h"
 #include "topn_kernels.h"
+#include "mals_internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -130,6 +131,16 @@ struct mals_handle_s {
   unsigned* d_zbound = nullptr;
   double* h_G = nullptr;      // pinned k x k
   hipEvent_t ev_G = nullptr;
+  // host half of the dual preparation: the eigendecomposition of G turned into what the device half uploads, in ONE
+  // pinned block (asynchronous copies straight out of it, no stream synchronisation): Q | Q^T (doubles), the same in
+  // fp32, eigenvalues | 1/sqrt(L + lambda alpha), and Q / Q^T as split-f16 B operands
+  char* eig_stage = nullptr;
+  size_t eig_stage_bytes = 0;
+  bool eig_ok = false;        // the staged decomposition qualifies for the dual path
+  double eig_gmax = 0.0;      // max_f G_ff of the decomposed Gramian
+  bool dual_pending = false;  // a chunk's direct kernels are enqueued, its dual part waits for the eigendecomposition
+  int dual_pending_side = -1, dual_pending_chunk = -1;
+  double tl[4] = {0.0, 0.0, 0.0, 0.0};  // mals_get_timeline
   int dual_side = -1;         // what the rotated copy currently holds: solved side, version of the opposite G
   uint64_t dual_version = 0;
   bool dual_ok = false;       // the half-iteration's systems qualify for the dual path
@@ -813,21 +824,72 @@ int launch_dual(mals_handle h, const DualParams& dp, int tn) {
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
 }
 
-// Once per half-iteration: G (opposite side) -> host, eigendecomposition, Q / Q^T / eigenvalues ->
-// device, rotated copy of the opposite factors.  Called AFTER the direct kernels of the first chunk
-// have been enqueued, so the host work runs under them.  Sets h->dual_ok.
-int prepare_dual(mals_handle h, int side) {
-  SideState& s = h->side[side];
+// Once per half-iteration, in two halves.  HOST: G (opposite side, already on its way to h_G) -> eigendecomposition
+// -> everything the device needs, staged in one pinned block.  A group computes it on ONE member and hands the block
+// to the others (`from`): after the all-reduce every member holds the same G, and a k x k eigenproblem solved once
+// per member by the one thread that drives them all would only delay the later members' kernels.  DEVICE:
+// asynchronous uploads out of the block + the rotated copy of the opposite factors.  Both run AFTER the direct
+// kernels of the first chunk have been enqueued, so the host work hides under them.  Sets h->dual_ok.
+double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct EigStage {  // views into mals_handle_s::eig_stage
+  double* Q;
+  float* Qf;
+  float* lam;
+  int32_t* Bs;
+  size_t nQ, nLam, nBs;  // elements: 2 KP^2, 2 KP, KC T 2 64 4 per operand
+};
+EigStage eig_views(mals_handle h) {
+  const size_t KP = (size_t)16 * h->T, KC = (size_t)(h->T + 1) / 2;
+  EigStage e;
+  e.nQ = 2 * KP * KP;
+  e.nLam = 2 * KP;
+  e.nBs = KC * h->T * 2 * 64 * 4;
+  char* b = h->eig_stage;
+  e.Q = reinterpret_cast<double*>(b);
+  e.Qf = reinterpret_cast<float*>(b + sizeof(double) * e.nQ);
+  e.lam = e.Qf + e.nQ;
+  e.Bs = reinterpret_cast<int32_t*>(e.lam + e.nLam);
+  return e;
+}
+int ensure_eig_stage(mals_handle h) {
+  if (h->eig_stage) return MALS_OK;
+  const size_t KP = (size_t)16 * h->T, KC = (size_t)(h->T + 1) / 2;
+  const size_t bytes = sizeof(double) * 2 * KP * KP + sizeof(float) * (2 * KP * KP + 2 * KP) + sizeof(int32_t) * 2 * KC * h->T * 2 * 64 * 4;
+  HIPCHK(h, hipHostMalloc(&h->eig_stage, bytes));
+  h->eig_stage_bytes = bytes;
+  return MALS_OK;
+}
+
+int prepare_dual_host(mals_handle h, int side, mals_handle from) {
   SideState& o = h->side[1 - side];
   const int k = h->cfg.features, KP = 16 * h->T;
   h->dual_side = side;
   h->dual_version = o.G_version;
   h->dual_ok = false;
-  HIPCHK(h, hipEventSynchronize(h->ev_G));  // h_G <- o.G was enqueued before the direct kernels
+  h->eig_ok = false;
+  if (int rc = ensure_eig_stage(h)) return rc;
+  // h_G <- o.G was enqueued before the direct kernels, behind everything of the previous half-iteration: once it is
+  // in, the uploads that read the block last time are done as well and the block may be rewritten
+  HIPCHK(h, hipEventSynchronize(h->ev_G));
+  h->tl[1] = now_us();
+  if (from && from != h) {  // the same G, decomposed by another member of the group
+    if (from->eig_stage_bytes != h->eig_stage_bytes) return fail(h, MALS_INVALID_ARG, "members of a group must share features");
+    std::memcpy(h->eig_stage, from->eig_stage, h->eig_stage_bytes);
+    h->eig_ok = from->eig_ok;
+    h->eig_gmax = from->eig_gmax;
+    h->rotate_f64 = from->rotate_f64;
+    h->rotate_split = from->rotate_split;
+    h->tl[2] = now_us();
+    return MALS_OK;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<double> evals((size_t)k), V((size_t)k * k);
   const bool ok = mals::symmetric_eigen(h->h_G, k, evals.data(), V.data());
   h->stats.eigen_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  h->tl[2] = now_us();
   if (!ok) return MALS_OK;
   double lmin = evals[0], lmax = evals[0];
   for (int f = 0; f < k; ++f) {
@@ -839,33 +901,48 @@ int prepare_dual(mals_handle h, int side) {
   // and the direct path could not have flagged the row either); tiny negative eigenvalues of a
   // rank-deficient G are rounding
   if (!(lmin + la >= 1.0e-4)) return MALS_OK;
-  std::vector<double> Q((size_t)2 * KP * KP, 0.0);
-  std::vector<float> lam((size_t)2 * KP, 0.f);
+  EigStage e = eig_views(h);
+  std::fill(e.Q, e.Q + e.nQ, 0.0);
   for (int f = 0; f < k; ++f)
     for (int j = 0; j < k; ++j) {
-      Q[(size_t)f * KP + j] = V[(size_t)f * k + j];                        // forward: y' = y Q
-      Q[(size_t)KP * KP + (size_t)f * KP + j] = V[(size_t)j * k + f];      // back: x = x' Q^T
+      e.Q[(size_t)f * KP + j] = V[(size_t)f * k + j];                        // forward: y' = y Q
+      e.Q[(size_t)KP * KP + (size_t)f * KP + j] = V[(size_t)j * k + f];      // back: x = x' Q^T
     }
   for (int f = 0; f < KP; ++f) {
     const double l = f < k ? std::max(evals[(size_t)f], 0.0) : 0.0;
-    lam[(size_t)f] = (float)l;
-    lam[(size_t)KP + f] = (float)(1.0 / std::sqrt(l + la));
+    e.lam[(size_t)f] = (float)l;
+    e.lam[(size_t)KP + f] = (float)(1.0 / std::sqrt(l + la));
   }
-  std::vector<float> Qf(Q.begin(), Q.end());
+  for (size_t i = 0; i < e.nQ; ++i) e.Qf[i] = (float)e.Q[i];
   // fp32 rotation unless the spectrum is wide enough for a rotated coordinate to be a small difference of
   // large products (dual_kernels.h, rotate_rows_kernel)
   h->rotate_f64 = (lmax + la) > 1.0e5 * (std::max(lmin, 0.0) + la);
-  if (const char* e = std::getenv("MALS_ROTATE_F64")) h->rotate_f64 = std::atoi(e) != 0;  // tests / A-B
+  if (const char* ev = std::getenv("MALS_ROTATE_F64")) h->rotate_f64 = std::atoi(ev) != 0;  // tests / A-B
   h->rotate_split = k % 8 == 0 && !std::getenv("MALS_ROTATE_NO_SPLIT");
-  std::vector<int32_t> Bs[2];
   if (h->rotate_split) {
-    split_rotation_operand(Q.data(), k, KP, h->T, Bs[0]);
-    split_rotation_operand(Q.data() + (size_t)KP * KP, k, KP, h->T, Bs[1]);
-    if (!h->d_Bs) HIPCHK(h, hipMalloc(&h->d_Bs, sizeof(int32_t) * 2 * Bs[0].size()));
+    std::vector<int32_t> Bs;
+    for (int op = 0; op < 2; ++op) {
+      split_rotation_operand(e.Q + (size_t)op * KP * KP, k, KP, h->T, Bs);
+      std::memcpy(e.Bs + (size_t)op * e.nBs, Bs.data(), sizeof(int32_t) * e.nBs);
+    }
   }
-  if (!h->d_Q) HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * Q.size()));
-  if (!h->d_Qf) HIPCHK(h, hipMalloc(&h->d_Qf, sizeof(float) * Qf.size()));
-  if (!h->d_lam) HIPCHK(h, hipMalloc(&h->d_lam, sizeof(float) * lam.size()));
+  double gmax = 0.0;   // max |y_f| <= sqrt(max_f G_ff)
+  for (int f = 0; f < k; ++f) gmax = std::max(gmax, h->h_G[(size_t)f * k + f]);
+  h->eig_gmax = gmax;
+  h->eig_ok = true;
+  return MALS_OK;
+}
+
+int prepare_dual_device(mals_handle h, int side) {
+  SideState& o = h->side[1 - side];
+  const int k = h->cfg.features, KP = 16 * h->T;
+  h->dual_ok = false;
+  if (!h->eig_ok) return MALS_OK;
+  const EigStage e = eig_views(h);
+  if (h->rotate_split && !h->d_Bs) HIPCHK(h, hipMalloc(&h->d_Bs, sizeof(int32_t) * 2 * e.nBs));
+  if (!h->d_Q) HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * e.nQ));
+  if (!h->d_Qf) HIPCHK(h, hipMalloc(&h->d_Qf, sizeof(float) * e.nQ));
+  if (!h->d_lam) HIPCHK(h, hipMalloc(&h->d_lam, sizeof(float) * e.nLam));
   if (!h->d_zbound) HIPCHK(h, hipMalloc(&h->d_zbound, 2 * sizeof(unsigned)));  // {z bound of the dual kernels, x' bound of the un-rotation}
   const size_t need = (size_t)o.n_total * KP;
   if (h->Mr_cap < need) {
@@ -875,17 +952,15 @@ int prepare_dual(mals_handle h, int side) {
     HIPCHK(h, hipMalloc(&h->d_Mr, sizeof(float) * need));
     h->Mr_cap = need;
   }
-  // pageable sources: these copies return once the data is staged, the vectors may go out of scope
-  HIPCHK(h, hipMemcpyAsync(h->d_Q, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_Qf, Qf.data(), sizeof(float) * Qf.size(), hipMemcpyHostToDevice, h->stream));
+  // pinned source, rewritten no earlier than the next half-iteration's prepare_dual_host (which waits for this stream)
+  HIPCHK(h, hipMemcpyAsync(h->d_Q, e.Q, sizeof(double) * e.nQ, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_Qf, e.Qf, sizeof(float) * e.nQ, hipMemcpyHostToDevice, h->stream));
   if (h->rotate_split) {
-    HIPCHK(h, hipMemcpyAsync(h->d_Bs, Bs[0].data(), sizeof(int32_t) * Bs[0].size(), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_Bs + Bs[0].size(), Bs[1].data(), sizeof(int32_t) * Bs[1].size(), hipMemcpyHostToDevice, h->stream));
-    h->Bs_stride = Bs[0].size();
+    HIPCHK(h, hipMemcpyAsync(h->d_Bs, e.Bs, sizeof(int32_t) * 2 * e.nBs, hipMemcpyHostToDevice, h->stream));
+    h->Bs_stride = e.nBs;
   }
-  HIPCHK(h, hipMemcpyAsync(h->d_lam, lam.data(), sizeof(float) * lam.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_lam, e.lam, sizeof(float) * e.nLam, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_zbound, 0, 2 * sizeof(unsigned), h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
   RotateParams rp;
   rp.src = o.F;
   rp.dst = h->d_Mr;
@@ -907,15 +982,12 @@ int prepare_dual(mals_handle h, int side) {
     sp.src_stride = rp.src_stride; sp.dst_stride = rp.dst_stride; sp.dst_cols = rp.dst_cols;
     sp.Bs = reinterpret_cast<const i32x4*>(h->d_Bs);
     sp.bound_bits = nullptr;
-    double gmax = 0.0;   // max |y_f| <= sqrt(max_f G_ff)
-    for (int f = 0; f < k; ++f) gmax = std::max(gmax, h->h_G[(size_t)f * k + f]);
-    sp.bound_host = (float)std::sqrt(gmax);
+    sp.bound_host = (float)std::sqrt(h->eig_gmax);
     if (int rc = launch_rotate_split<false>(h, sp)) return rc;
   } else if (int rc = h->rotate_f64 ? launch_rotate<false, true>(h, rp) : launch_rotate<false, false>(h, rp)) {
     return rc;
   }
   if (int rc = end_timed(h, pe)) return rc;
-  (void)s;
   h->dual_ok = true;
   return MALS_OK;
 }
@@ -1370,6 +1442,7 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_lam);
   free_dev(h->d_zbound);
   if (h->h_G) (void)hipHostFree(h->h_G);
+  if (h->eig_stage) (void)hipHostFree(h->eig_stage);
   if (h->ev_G) (void)hipEventDestroy(h->ev_G);
   if (h->h_bad) (void)hipHostFree(h->h_bad);
   free_dev(h->d_idx);
@@ -1693,7 +1766,13 @@ int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) {
   return MALS_OK;
 }
 
-static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end) {
+// phase: the whole of every chunk (ALL); or, for callers that drive several handles from one thread (mals_group.cpp),
+// one chunk in two calls -- BEGIN enqueues everything that does not need the eigendecomposition of the dual path and
+// returns (h->dual_pending says whether anything is left), the caller provides the decomposition (prepare_dual_host,
+// once per group), END enqueues the rest.  BEGIN + host + END = ALL.
+enum { SOLVE_ALL = 0, SOLVE_BEGIN = 1, SOLVE_END = 2 };
+
+static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end, int phase = SOLVE_ALL) {
   SideState& s = h->side[side];
   SideState& o = h->side[1 - side];
   if (!s.has_matrix) return fail(h, MALS_INVALID_ARG, "matrix of this side not set");
@@ -1705,6 +1784,14 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   if (use_g && !o.G_valid) return fail(h, MALS_INVALID_ARG, "Gramian of the opposite side not computed");
   if (chunk_begin < 0 || chunk_end > (int)s.chunks.size() || chunk_begin >= chunk_end)
     return fail(h, MALS_INVALID_ARG, "chunk index out of range");
+  const bool resume = phase == SOLVE_END;
+  if (resume) {
+    if (!h->dual_pending) return MALS_OK;  // BEGIN did the whole chunk
+    if (h->dual_pending_side != side || h->dual_pending_chunk != chunk_begin || chunk_end != chunk_begin + 1)
+      return fail(h, MALS_INVALID_ARG, "solve END does not match the pending BEGIN");
+  } else {
+    h->dual_pending = false;  // a BEGIN whose END never came belongs to a half-iteration that was abandoned on an error
+  }
   if (int rc = use_device(h)) return rc;
   if (s.n_local == 0) return MALS_OK;
   const int k = h->cfg.features;
@@ -1714,42 +1801,48 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.val = s.val;
   p.M = o.F;
   p.ldm = k;
-  // A new half-iteration?  The opposite factors do not change while a half-iteration's chunks are solved (in any
-  // order): "new" = the side, the opposite Gramian or the opposite uploads changed, or a chunk comes round again.
-  bool new_half = h->pad_side != side || h->pad_version != o.G_version || h->pad_epoch != o.F_epoch ||
-                  h->pad_done.size() != s.chunks.size();
-  for (int c = chunk_begin; c < chunk_end && !new_half; ++c) new_half = h->pad_done[(size_t)c] != 0;
-  if (new_half) {
-    h->pad_side = side;
-    h->pad_version = o.G_version;
-    h->pad_epoch = o.F_epoch;
-    h->pad_done.assign(s.chunks.size(), 0);
-    // nothing marked yet, no reference-rounded Gramian yet (gramian_ref_kernel)
-    HIPCHK(h, hipMemsetAsync(h->d_gref_state, 0, 2 * sizeof(int), h->stream));
-  }
-  for (int c = chunk_begin; c < chunk_end; ++c) h->pad_done[(size_t)c] = 1;
-  if (k % 16 != 0) {
-    const int ld = 16 * h->T;
-    const size_t need = (size_t)o.n_total * (size_t)ld;
-    if (need > h->Mp_cap) {
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      free_dev(h->d_Mp);
-      h->Mp_cap = 0;
-      new_half = true;   // the copy is gone
-      HIPCHK(h, hipMalloc(&h->d_Mp, sizeof(float) * need));
-      h->Mp_cap = need;
-    }
+  if (!resume) {
+    // A new half-iteration?  The opposite factors do not change while a half-iteration's chunks are solved (in any
+    // order): "new" = the side, the opposite Gramian or the opposite uploads changed, or a chunk comes round again.
+    bool new_half = h->pad_side != side || h->pad_version != o.G_version || h->pad_epoch != o.F_epoch ||
+                    h->pad_done.size() != s.chunks.size();
+    for (int c = chunk_begin; c < chunk_end && !new_half; ++c) new_half = h->pad_done[(size_t)c] != 0;
     if (new_half) {
-      PendingEvent pe;
-      if (int rc = begin_timed(h, 5, (double)o.n_total * 4.0 * (k + ld), pe)) return rc;
-      const int64_t n4 = o.n_total * (ld / 4);
-      const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)h->n_cu * 32);
-      hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, h->stream, o.F, o.n_total, k, ld, h->d_Mp);
-      HIPCHK(h, hipGetLastError());
-      if (int rc = end_timed(h, pe)) return rc;
+      h->pad_side = side;
+      h->pad_version = o.G_version;
+      h->pad_epoch = o.F_epoch;
+      h->pad_done.assign(s.chunks.size(), 0);
+      h->tl[0] = now_us();
+      h->tl[1] = h->tl[2] = 0.0;
+      // nothing marked yet, no reference-rounded Gramian yet (gramian_ref_kernel)
+      HIPCHK(h, hipMemsetAsync(h->d_gref_state, 0, 2 * sizeof(int), h->stream));
     }
+    for (int c = chunk_begin; c < chunk_end; ++c) h->pad_done[(size_t)c] = 1;
+    if (k % 16 != 0) {
+      const int ld = 16 * h->T;
+      const size_t need = (size_t)o.n_total * (size_t)ld;
+      if (need > h->Mp_cap) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        free_dev(h->d_Mp);
+        h->Mp_cap = 0;
+        new_half = true;   // the copy is gone
+        HIPCHK(h, hipMalloc(&h->d_Mp, sizeof(float) * need));
+        h->Mp_cap = need;
+      }
+      if (new_half) {
+        PendingEvent pe;
+        if (int rc = begin_timed(h, 5, (double)o.n_total * 4.0 * (k + ld), pe)) return rc;
+        const int64_t n4 = o.n_total * (ld / 4);
+        const unsigned blocks = (unsigned)std::min<int64_t>((n4 + 255) / 256, (int64_t)h->n_cu * 32);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, h->stream, o.F, o.n_total, k, ld, h->d_Mp);
+        HIPCHK(h, hipGetLastError());
+        if (int rc = end_timed(h, pe)) return rc;
+      }
+    }
+  }
+  if (k % 16 != 0) {
     p.M = h->d_Mp;
-    p.ldm = ld;
+    p.ldm = 16 * h->T;
   }
   p.Gf = o.Gf;
   p.out = s.F + s.row_offset * k;
@@ -1790,7 +1883,7 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   p.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);  // ALS:435
   p.sing_threshold = (float)h->cfg.singularity_threshold;
   p.zscale = h->d_zscale;
-  if (h->split_f16 && (h->zs_side != side || h->zs_version != o.G_version || h->zs_bound != s.max_abs_val || h->zs_mean != s.mean_abs_val)) {
+  if (!resume && h->split_f16 && (h->zs_side != side || h->zs_version != o.G_version || h->zs_bound != s.max_abs_val || h->zs_mean != s.mean_abs_val)) {
     // once per half-iteration, not per chunk: the scale only depends on G and on the value bound
     const double base_w = (h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) ? 1.0 : 0.0;
     const double w_max = base_w + ((h->cfg.flags & MALS_FLAG_RECONSTRUCT_R) ? 0.0 : std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
@@ -1812,24 +1905,37 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end)
   // C5: 1.25M long rows per rank gathering from 100M users) stays on the direct kernels
   const bool dual_pays = h->cfg.solve_mode == MALS_SOLVE_DUAL || s.n_dual_rows * 32 >= o.n_total;
   const bool want_dual = s.n_dual_rows > 0 && dual_pays && h->cfg.flags == 0 && h->cfg.alpha > 0.0 && o.G_valid;
-  const bool dual_stale = want_dual && (h->dual_side != side || h->dual_version != o.G_version);
-  if (dual_stale) {
+  const bool dual_stale = resume || (want_dual && (h->dual_side != side || h->dual_version != o.G_version));
+  if (dual_stale && !resume) {
     if (!h->h_G) HIPCHK(h, hipHostMalloc(&h->h_G, sizeof(double) * (size_t)k * k));
     if (!h->ev_G) HIPCHK(h, hipEventCreateWithFlags(&h->ev_G, hipEventDisableTiming));
     HIPCHK(h, hipMemcpyAsync(h->h_G, o.G, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipEventRecord(h->ev_G, h->stream));
   }
+  if (phase == SOLVE_BEGIN && chunk_end != chunk_begin + 1) return fail(h, MALS_INVALID_ARG, "solve BEGIN takes one chunk");
   const int64_t want_chunk_rows = s.chunk_rows_override >= 0 ? s.chunk_rows_override : h->cfg.chunk_rows;
   const int64_t rows_per_chunk = want_chunk_rows > 0 ? want_chunk_rows : std::max<int64_t>(s.n_local, 1);  // as build_work_lists
   for (int c = chunk_begin; c < chunk_end; ++c) {
     const SideState::ChunkRange& cr = s.chunks[(size_t)c];
     const int64_t row0 = std::min<int64_t>(s.n_local, (int64_t)c * rows_per_chunk);
     const int64_t row1 = std::min<int64_t>(s.n_local, (int64_t)(c + 1) * rows_per_chunk);
-    if (p.refine_flag && row1 > row0) HIPCHK(h, hipMemsetAsync(s.refine + row0, 0, (size_t)(row1 - row0), h->stream));
+    if (!resume && p.refine_flag && row1 > row0) HIPCHK(h, hipMemsetAsync(s.refine + row0, 0, (size_t)(row1 - row0), h->stream));
     bool dual_now = want_dual && !dual_stale && h->dual_ok;
     if (want_dual && dual_stale && c == chunk_begin) {
-      if (int rc = launch_solve(h, s, p, c, LISTS_OWN)) return rc;  // direct lists first ...
-      if (int rc = prepare_dual(h, side)) return rc;            // ... host eigendecomposition under them
+      if (!resume) {
+        if (int rc = launch_solve(h, s, p, c, LISTS_OWN)) return rc;  // direct lists first ...
+        if (phase == SOLVE_BEGIN) {                                   // ... the caller decomposes G under them
+          h->dual_pending = true;
+          h->dual_pending_side = side;
+          h->dual_pending_chunk = c;
+          return MALS_OK;
+        }
+        if (int rc = prepare_dual_host(h, side, nullptr)) return rc;  // ... host eigendecomposition under them
+      } else if (h->dual_side != side || h->dual_version != o.G_version) {
+        return fail(h, MALS_INVALID_ARG, "solve END without the eigendecomposition of this half-iteration");
+      }
+      h->dual_pending = false;
+      if (int rc = prepare_dual_device(h, side)) return rc;
       dual_now = h->dual_ok;
       if (dual_now) {
         if (int rc = launch_dual_chunk(h, side, c)) return rc;
@@ -1883,6 +1989,29 @@ int mals_solve_side(mals_handle h, int side) {
 int mals_solve_chunk(mals_handle h, int side, int32_t chunk) {
   CHECK_SIDE(h, side);
   return solve_chunks(h, side, chunk, chunk + 1);
+}
+
+// ---- csrc/mals_internal.h: the two-call form of mals_solve_chunk for mals_group.cpp (not part of the C-ABI)
+int malsi_solve_chunk_begin(mals_handle h, int side, int32_t chunk) {
+  CHECK_SIDE(h, side);
+  return solve_chunks(h, side, chunk, chunk + 1, SOLVE_BEGIN);
+}
+int malsi_solve_chunk_end(mals_handle h, int side, int32_t chunk) {
+  CHECK_SIDE(h, side);
+  return solve_chunks(h, side, chunk, chunk + 1, SOLVE_END);
+}
+int malsi_dual_pending(mals_handle h) { return h && h->dual_pending ? 1 : 0; }
+int malsi_dual_host(mals_handle h, int side, mals_handle from) {
+  CHECK_SIDE(h, side);
+  if (!h->dual_pending || h->dual_pending_side != side) return fail(h, MALS_INVALID_ARG, "no chunk is waiting for the eigendecomposition");
+  if (int rc = use_device(h)) return rc;
+  return prepare_dual_host(h, side, from);
+}
+
+int mals_get_timeline(mals_handle h, double* out4) {
+  if (!h || !out4) return MALS_INVALID_ARG;
+  for (int i = 0; i < 4; ++i) out4[i] = h->tl[i];
+  return MALS_OK;
 }
 
 int mals_set_chunk_rows(mals_handle h, int side, int64_t chunk_rows) {

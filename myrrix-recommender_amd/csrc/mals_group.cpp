@@ -12,6 +12,7 @@
 // local members are always enclosed in ncclGroupStart/End (one thread drives all devices), and every RCCL call
 // of a rank is issued on that rank's comm stream -- a communicator is never used from two streams at once.
 #include "../../include/myrrix_als.h"
+#include "mals_internal.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -42,16 +43,21 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  std::string forced;  // mals_group_use_transport: this library and no other
 
   bool load(std::string& err) {
     if (lib) return true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    // MALS_RCCL_LIBRARY=<path>: this library and no other (a particular RCCL build; tests/cpp/libmock_rccl.so, the
-    // stand-in transport that lets the tests run N ranks on one device)
-    if (const char* forced = std::getenv("MALS_RCCL_LIBRARY")) {
-      lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    // No environment variable selects the library: what gets loaded as "RCCL" into a server process is decided by the
+    // process itself (mals_group_use_transport: a particular RCCL build, or the tests' stand-in transport).
+    if (!forced.empty()) {
+      lib = dlopen(forced.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (!lib) {
-        err = std::string("MALS_RCCL_LIBRARY=") + forced + " could not be loaded: " + (dlerror() ? dlerror() : "");
+        const char* e = dlerror();  // once: dlerror() clears its state
+        err = "transport library " + forced + " could not be loaded: " + (e ? e : "");
         return false;
       }
     }
@@ -59,18 +65,25 @@ struct Rccl {
       if (lib) break;
       lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // a copy the process already mapped (e.g. PyTorch's) first
     }
+    std::string first_error;
     for (const char* n : names) {
       if (lib) break;
       lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (!lib && first_error.empty()) {  // right behind the failing dlopen: later attempts overwrite the message
+        const char* e = dlerror();
+        first_error = e ? e : "";
+      }
     }
     if (!lib) {
-      err = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "");
+      err = "librccl.so.1 could not be loaded: " + first_error;
       return false;
     }
 #define MALS_SYM(field, name)                                                  \
   field = reinterpret_cast<decltype(field)>(dlsym(lib, name));                 \
   if (!field) {                                                                \
     err = std::string("RCCL symbol missing: ") + name;                         \
+    dlclose(lib);                                                              \
+    lib = nullptr;                                                             \
     return false;                                                              \
   }
     MALS_SYM(GetUniqueId, "ncclGetUniqueId")
@@ -83,6 +96,9 @@ struct Rccl {
     MALS_SYM(GroupStart, "ncclGroupStart")
     MALS_SYM(GroupEnd, "ncclGroupEnd")
     MALS_SYM(GetErrorString, "ncclGetErrorString")
+    MALS_SYM(CommCount, "ncclCommCount")
+    MALS_SYM(CommUserRank, "ncclCommUserRank")
+    MALS_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef MALS_SYM
     return true;
   }
@@ -118,7 +134,9 @@ struct mals_group_s {
   std::vector<int64_t> bounds[2];
   std::vector<int64_t> up_row_ptr[2];  // chunked upload: the full row_ptr
   int64_t up_next_row[2] = {0, 0};
-  int exchange_chunks = 4;
+  int exchange_chunks = 4;        // what the NEXT matrix upload of a side is cut into
+  int side_chunks[2] = {4, 4};    // what each side's CURRENT matrix was cut into (plan_side): the members' work lists are
+                                  // built for this count, so the solve loop, the exchange ranges and the members agree
   std::atomic<int> cancelled{0};
   std::string err;
 };
@@ -156,7 +174,7 @@ int mfail(mals_group g, const Member& mb, int rc) {
 
 int64_t chunk_rows_of(const mals_group g, int side, int rank) {
   const int64_t n = g->bounds[side][(size_t)rank + 1] - g->bounds[side][(size_t)rank];
-  return std::max<int64_t>(1, (n + g->exchange_chunks - 1) / g->exchange_chunks);
+  return std::max<int64_t>(1, (n + g->side_chunks[side] - 1) / g->side_chunks[side]);
 }
 
 // rows [lo, hi) (global) of chunk c of rank's slice
@@ -300,6 +318,7 @@ int refresh_replica_ptrs(mals_group g, int side) {
 // slices planned, every member told its chunking; called with the full row_ptr on the host
 int plan_side(mals_group g, int side, const int64_t* row_ptr, int64_t n_rows) {
   g->n_rows[side] = n_rows;
+  g->side_chunks[side] = g->exchange_chunks;
   g->bounds[side].assign((size_t)g->world + 1, 0);
   if (int rc = mals_plan_shards(row_ptr, n_rows, g->world, -1.0, g->cfg.features, g->bounds[side].data()))
     return gfail(g, rc, "mals_plan_shards failed");
@@ -555,7 +574,39 @@ int mals_group_local(mals_group g, int32_t i, mals_handle* handle_out, int32_t* 
 
 int mals_group_set_exchange_chunks(mals_group g, int32_t n_chunks) {
   if (!g || n_chunks <= 0) return MALS_INVALID_ARG;
+  // takes effect with the next matrix upload of each side: a side that already holds a matrix keeps the count its
+  // members' work lists were built for (side_chunks), so a later call can never leave part of a slice unsolved
   g->exchange_chunks = n_chunks;
+  return MALS_OK;
+}
+
+int mals_group_use_transport(const char* library_path) {
+  if (g_rccl.lib) return MALS_INVALID_ARG;  // already loaded: the choice is made once per process, before the first group
+  g_rccl.forced = library_path ? library_path : "";
+  return MALS_OK;
+}
+
+int mals_group_comm_info(mals_group g, int32_t local_member, int32_t* comm_size, int32_t* comm_rank, int32_t* hip_device,
+                         char* pci_bus_id, int32_t pci_len) {
+  if (!g) return MALS_INVALID_ARG;
+  if (local_member < 0 || (size_t)local_member >= g->m.size()) return gfail(g, MALS_INVALID_ARG, "no such local member");
+  const Member& mb = g->m[(size_t)local_member];
+  int n = 0, r = -1, dev = mb.device;
+  if (mb.nccl) {  // read back from the communicator itself, not from what this library was told
+    GNCCL(g, g_rccl.CommCount(mb.nccl, &n));
+    GNCCL(g, g_rccl.CommUserRank(mb.nccl, &r));
+    GNCCL(g, g_rccl.CommCuDevice(mb.nccl, &dev));
+  }
+  if (comm_size) *comm_size = n;
+  if (comm_rank) *comm_rank = r;
+  if (hip_device) *hip_device = dev;
+  if (pci_bus_id && pci_len > 0) {
+    pci_bus_id[0] = 0;
+    if (hipDeviceGetPCIBusId(pci_bus_id, pci_len, mb.device) != hipSuccess) {
+      (void)hipGetLastError();
+      pci_bus_id[0] = 0;
+    }
+  }
   return MALS_OK;
 }
 
@@ -690,8 +741,17 @@ int mals_group_half_iteration(mals_group g, int side) {
   GSIDE(g, side);
   if (g->bounds[side].empty()) return gfail(g, MALS_INVALID_ARG, "matrix of this side not set");
   if (!g->m[0].F[side] || !g->m[0].F[1 - side]) return gfail(g, MALS_INVALID_ARG, "factor replicas not allocated");
-  int local_rc = MALS_OK;
-  std::string local_msg;
+  // A failure of the local solve (MALS_OOM, MALS_INVALID_ARG ...) must not leave the peers alone in a collective:
+  // the remaining exchanges of the half-iteration are still issued (only the solves are skipped), so that every rank
+  // arrives at the agreed status with matching calls behind it.  Only a communication / device failure ends it here.
+  int solve_rc = MALS_OK;
+  std::string solve_msg;
+  auto member_failed = [&](const Member& mb, int rc) {
+    if (solve_rc == MALS_OK) {
+      solve_rc = rc;
+      solve_msg = std::string("rank ") + std::to_string(mb.rank) + ": " + mals_last_error(mb.h);
+    }
+  };
   auto run = [&]() -> int {
     // the gather of this half reads every row of the opposite replica: all of the previous exchange must be in
     for (Member& mb : g->m) {
@@ -705,13 +765,41 @@ int mals_group_half_iteration(mals_group g, int side) {
           GHIP(g, hipStreamWaitEvent(mb.compute, other.ev_exchanged, 0));
         }
     if (int rc = group_gramian(g, 1 - side)) return rc;  // ALS:342 / ALS:369
-    for (int c = 0; c < g->exchange_chunks; ++c) {
-      for (Member& mb : g->m) {
+    for (int c = 0; c < g->side_chunks[side]; ++c) {
+      // Like the reference's pool, where every worker is started before any result is awaited (ALS:186-191,391-410):
+      // the direct kernels of EVERY member are enqueued before any host work; the k x k eigendecomposition of the
+      // dual path (the same G on every member after the all-reduce) is then computed once, under those kernels, and
+      // handed to the others; only then the members' dual kernels follow.
+      std::vector<char> has(g->m.size(), 0);
+      for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
         GHIP(g, hipSetDevice(mb.device));
         int32_t mine = 0;
         if (int rc = mals_num_chunks(mb.h, side, &mine)) return mfail(g, mb, rc);
-        if (c < mine)
-          if (int rc = mals_solve_chunk(mb.h, side, c)) return mfail(g, mb, rc);  // ALS:344 / ALS:371
+        has[i] = c < mine && solve_rc == MALS_OK;
+        if (has[i])
+          if (int rc = malsi_solve_chunk_begin(mb.h, side, c)) {  // ALS:344 / ALS:371
+            member_failed(mb, rc);
+            has[i] = 0;
+          }
+      }
+      Member* decomposed = nullptr;
+      for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
+        if (!has[i] || !malsi_dual_pending(mb.h)) continue;
+        GHIP(g, hipSetDevice(mb.device));
+        if (int rc = malsi_dual_host(mb.h, side, decomposed ? decomposed->h : nullptr)) {
+          member_failed(mb, rc);
+          has[i] = 0;
+          continue;
+        }
+        if (!decomposed) decomposed = &mb;
+      }
+      for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
+        GHIP(g, hipSetDevice(mb.device));
+        if (has[i])
+          if (int rc = malsi_solve_chunk_end(mb.h, side, c)) member_failed(mb, rc);
         GHIP(g, hipEventRecord(mb.ev_solved, mb.compute));
         GHIP(g, hipStreamWaitEvent(mb.comm, mb.ev_solved, 0));
       }
@@ -721,14 +809,15 @@ int mals_group_half_iteration(mals_group g, int side) {
       GHIP(g, hipSetDevice(mb.device));
       GHIP(g, hipEventRecord(mb.ev_exchanged, mb.comm));
     }
+    if (solve_rc != MALS_OK) return gfail(g, solve_rc, solve_msg);
     for (Member& mb : g->m) {  // ALS:346-361: f.get() of every worker
       GHIP(g, hipSetDevice(mb.device));
       if (int rc = mals_check(mb.h)) return mfail(g, mb, rc);
     }
     return MALS_OK;
   };
-  local_rc = run();
-  local_msg = g->err;
+  const int local_rc = run();
+  const std::string local_msg = g->err;
   // a communication failure cannot be agreed upon over the same communicator
   if (local_rc == MALS_COMM_ERROR || local_rc == MALS_HIP_ERROR) return local_rc;
   return agree_status(g, local_rc, local_msg);
@@ -760,7 +849,7 @@ int mals_group_exchange_only(mals_group g, int side) {
     GHIP(g, hipEventRecord(mb.ev_solved, mb.compute));
     GHIP(g, hipStreamWaitEvent(mb.comm, mb.ev_solved, 0));
   }
-  for (int c = 0; c < g->exchange_chunks; ++c)
+  for (int c = 0; c < g->side_chunks[side]; ++c)
     if (int rc = exchange_chunk(g, side, c)) return rc;
   for (Member& mb : g->m) {
     GHIP(g, hipSetDevice(mb.device));

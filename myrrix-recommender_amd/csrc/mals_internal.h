@@ -1,0 +1,16 @@
+// mals_internal.h -- entry points shared by the translation units of libmyrrix_als.so, NOT part of the C-ABI
+// (include/myrrix_als.h).  mals_group.cpp drives several handles from one thread: it must be able to enqueue the
+// direct kernels of EVERY member before any host work (the eigendecomposition of the dual path) starts, and to
+// decompose the group's Gramian once instead of once per member.
+#pragma once
+#include "../../include/myrrix_als.h"
+
+extern "C" {
+// mals_solve_chunk in two calls: BEGIN enqueues everything of the chunk that does not need the eigendecomposition
+// of the opposite Gramian; when malsi_dual_pending(h) is then 1, the caller runs malsi_dual_host (on one member:
+// from = NULL computes it; on the others: from = that member copies it) and END enqueues the rest.
+__attribute__((visibility("hidden"))) int malsi_solve_chunk_begin(mals_handle h, int side, int32_t chunk);
+__attribute__((visibility("hidden"))) int malsi_solve_chunk_end(mals_handle h, int side, int32_t chunk);
+__attribute__((visibility("hidden"))) int malsi_dual_pending(mals_handle h);
+__attribute__((visibility("hidden"))) int malsi_dual_host(mals_handle h, int side, mals_handle from);
+}

@@ -80,6 +80,22 @@ class GroupALS:
         return self
 
     @staticmethod
+    def use_transport(library_path):
+        """mals_group_use_transport: the shared library to load as RCCL (None = librccl.so.1), once per process and
+        before the first group / unique id.  The tests point it at their stand-in transport."""
+        L = _lib.load()
+        rc = L.mals_group_use_transport(library_path.encode() if library_path else None)
+        if rc != _lib.OK:
+            raise MalsError(rc, "mals_group_use_transport: a transport is already loaded in this process")
+
+    def comm_info(self, i=0):
+        """What the communicator reports for local member i: {"comm_size", "comm_rank", "hip_device", "pci_bus_id"}."""
+        n, r, d = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        buf = ctypes.create_string_buffer(32)
+        self._chk(self._L.mals_group_comm_info(self._g, int(i), ctypes.byref(n), ctypes.byref(r), ctypes.byref(d), buf, 32))
+        return {"comm_size": n.value, "comm_rank": r.value, "hip_device": d.value, "pci_bus_id": buf.value.decode("ascii", "replace")}
+
+    @staticmethod
     def unique_id():
         """mals_group_unique_id: the 128-byte RCCL unique id rank 0 creates and hands to the other ranks."""
         L = _lib.load()

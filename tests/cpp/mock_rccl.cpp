@@ -2,7 +2,7 @@
 // path of csrc/mals_group.cpp (ncclCommInitAll / ncclCommInitRank, grouped ncclSend + ncclRecv exchange,
 // ncclAllReduce, all on each rank's comm stream) can be EXECUTED with N > 1 ranks on a box that has one GPU.
 // RCCL itself refuses two ranks on one device; this library does not care where a rank lives.  Selected with
-// MALS_RCCL_LIBRARY=<path to libmock_rccl.so> (csrc/mals_group.cpp Rccl::load); never used by the product path.
+// mals_group_use_transport(<path to libmock_rccl.so>) (csrc/mals_group.cpp Rccl::load); never used by the product path.
 //
 // What it checks that a real communicator would punish with a hang or silent corruption:
 //   * every ncclSend meets an ncclRecv of the SAME element count on the peer, in the same order per pair
@@ -343,6 +343,24 @@ ncclResult_t ncclGroupStart() {
 ncclResult_t ncclGroupEnd() {
   if (g_depth <= 0) return ncclInvalidUsage;
   return --g_depth == 0 ? flush() : ncclSuccess;
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+  if (!comm || !count) return ncclInvalidArgument;
+  *count = comm->ctx->world;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
+  if (!comm || !rank) return ncclInvalidArgument;
+  *rank = comm->rank;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int* device) {
+  if (!comm || !device) return ncclInvalidArgument;
+  *device = comm->device;
+  return ncclSuccess;
 }
 
 const char* ncclGetErrorString(ncclResult_t result) {

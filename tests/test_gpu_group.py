@@ -149,3 +149,64 @@ def test_device_matrix_and_member_views():
     assert solved == n_users + n_items
     Xo, _ = oracle_iterations(r_csr, c_csr, Y0, 1)
     assert rel(X, Xo) < REL_TOL
+
+
+@pytest.mark.parametrize("k", [64, 128])
+def test_members_are_not_serialised_behind_host_work(k):
+    """One process driving N GPUs (the JVM's deployment, jni/myrrix_als_jni.c -> mals_group_create) is the reference's
+    one pool whose workers all start before any result is awaited (ALS:186-191,391-410): every member's direct kernels
+    are enqueued before ANY member's host work -- the k x k eigendecomposition of the dual path, 4 ms at k = 128 --
+    starts, and that decomposition is computed ONCE per half-iteration (the all-reduced G is the same everywhere),
+    not once per member."""
+    world, n_users, n_items = 4, 4000, 1200
+    r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 60000, k, seed=1234, negatives=0.05)
+    with pkg.GroupALS.single_process(k, [0] * world, backend=_lib.GROUP_PEER_COPY, exchange_chunks=2) as g:
+        g.set_factor_rows(pkg.SIDE_X, n_users)
+        g.set_factor_rows(pkg.SIDE_Y, n_items)
+        g.set_matrix(pkg.SIDE_X, *r_csr)
+        g.set_matrix(pkg.SIDE_Y, *c_csr)
+        g.set_factors(pkg.SIDE_Y, Y0)
+        cores = [g.local(i)[0] for i in range(world)]
+        for side in (pkg.SIDE_X, pkg.SIDE_Y):
+            for c in cores:
+                c.reset_stats()
+            g.half_iteration(side)
+            tl = [c.timeline() for c in cores]
+            st = [c.stats() for c in cores]
+            assert all(s["rows_dual"] > 0 for s in st), "the short rows of every member go through the dual kernels"
+            computed = [i for i in range(world) if st[i]["eigen_host_ms"] > 0.0]
+            assert computed == [0], "one eigendecomposition per group half-iteration, on member 0: %r" % (computed,)
+            first_host_work = min(t[1] for t in tl)
+            assert first_host_work > 0.0
+            for i, t in enumerate(tl):
+                assert 0.0 < t[0] <= first_host_work, "member %d's first kernel was enqueued %.0f us AFTER host work began" % (i, t[0] - first_host_work)
+                assert t[1] <= t[2]
+        X = g.get_factors(pkg.SIDE_X, 0, n_users)
+        Y = g.get_factors(pkg.SIDE_Y, 0, n_items)
+    Xo = oracle.half_iteration(*r_csr, Y0, threads=4)
+    Yo = oracle.half_iteration(*c_csr, Xo, threads=4)
+    assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL
+
+
+def test_exchange_chunks_changed_after_the_upload_cannot_leave_rows_unsolved():
+    """mals_group_set_exchange_chunks after a matrix is set used to shorten the solve loop under the members' work
+    lists: the count now belongs to the upload."""
+    k, n_users, n_items = 64, 3000, 800
+    r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 40000, k, seed=4321)
+    with pkg.GroupALS.single_process(k, [0, 0], backend=_lib.GROUP_PEER_COPY, exchange_chunks=4) as g:
+        g.set_factor_rows(pkg.SIDE_X, n_users)
+        g.set_factor_rows(pkg.SIDE_Y, n_items)
+        g.set_matrix(pkg.SIDE_X, *r_csr)
+        g.set_matrix(pkg.SIDE_Y, *c_csr)
+        g.set_factors(pkg.SIDE_Y, Y0)
+        g._chk(g._L.mals_group_set_exchange_chunks(g._g, 2))      # lower it under the uploaded X side ...
+        g.half_iteration(pkg.SIDE_X)
+        X = g.get_factors(pkg.SIDE_X, 0, n_users)
+        g.set_matrix(pkg.SIDE_Y, *c_csr)                          # ... and let the Y side be uploaded with the new count
+        g.half_iteration(pkg.SIDE_Y)
+        Y = g.get_factors(pkg.SIDE_Y, 0, n_items)
+        assert sum(g.local(i)[0].stats()["rows_solved"] for i in range(2)) == n_users + n_items
+        assert g.local(0)[0].num_chunks(pkg.SIDE_X) == 4 and g.local(0)[0].num_chunks(pkg.SIDE_Y) == 2
+    Xo = oracle.half_iteration(*r_csr, Y0, threads=4)
+    Yo = oracle.half_iteration(*c_csr, Xo, threads=4)
+    assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL

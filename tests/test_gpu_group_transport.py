@@ -1,7 +1,7 @@
 """The RCCL code path of csrc/mals_group.cpp EXECUTED with N > 1 ranks on the one GPU of the test box.
 
 RCCL refuses two ranks on one device, so these tests point the library at tests/cpp/libmock_rccl.so
-(MALS_RCCL_LIBRARY): a stand-in with RCCL's entry points that moves the bytes with plain copies and turns every
+(mals_group_use_transport): a stand-in with RCCL's entry points that moves the bytes with plain copies and turns every
 mismatched call (a send without its receive, different counts, a rank missing from an all-reduce) into an error
 instead of a hang.  What runs is the product's own call sequence -- ncclCommInitAll / ncclCommInitRank, the
 grouped ncclSend + ncclRecv exchange per chunk on the comm streams, the k x k and status all-reduces -- and the
@@ -34,9 +34,9 @@ def _problem(k, seed):
 
 def _in_process(world, k, chunks, q):
     try:
-        os.environ["MALS_RCCL_LIBRARY"] = MOCK
         import myrrix_recommender_amd as pkg
         from myrrix_recommender_amd import _lib
+        pkg.GroupALS.use_transport(MOCK)
         r_csr, c_csr, Y0 = _problem(k, 500 + world)
         n_users, n_items = len(r_csr[0]) - 1, len(c_csr[0]) - 1
         with pkg.GroupALS.single_process(k, [0] * world, backend=_lib.GROUP_RCCL, exchange_chunks=chunks) as g:
@@ -50,6 +50,8 @@ def _in_process(world, k, chunks, q):
             Y = g.get_factors(pkg.SIDE_Y, 0, n_items)
             same = all(np.array_equal(g.local(i)[0].get_factors(pkg.SIDE_X), X) and np.array_equal(g.local(i)[0].get_factors(pkg.SIDE_Y), Y)
                        for i in range(world))
+            info = [g.comm_info(i) for i in range(world)]       # read back from the communicator
+            same = same and [c["comm_size"] for c in info] == [world] * world and [c["comm_rank"] for c in info] == list(range(world))
         q.put(("ok", X, Y, same))
     except Exception as e:  # noqa: BLE001 -- reported to the parent
         q.put(("error", repr(e)))
@@ -57,8 +59,8 @@ def _in_process(world, k, chunks, q):
 
 def _one_rank(rank, world, k, chunks, uid_q, out_q):
     try:
-        os.environ["MALS_RCCL_LIBRARY"] = MOCK
         import myrrix_recommender_amd as pkg
+        pkg.GroupALS.use_transport(MOCK)
         r_csr, c_csr, Y0 = _problem(k, 600 + world)
         n_users, n_items = len(r_csr[0]) - 1, len(c_csr[0]) - 1
         if rank == 0:
@@ -131,7 +133,7 @@ def test_rccl_backend_one_rank_per_process(world, k, chunks):
 def test_bench_script_as_the_driver_launches_it(world):
     """`python bench.py --gpus N` end to end (self-launch through torch.distributed.run, one rank per process, the
     group API, the timing bracket, ONE JSON line from rank 0 as the last line of stdout) on the stand-in transport."""
-    env = dict(os.environ, MALS_RCCL_LIBRARY=MOCK, MALS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MALS_BENCH_TRANSPORT=MOCK, MALS_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
@@ -147,4 +149,11 @@ def test_bench_script_as_the_driver_launches_it(world):
     xb = d["config"]["slices"]["x_bounds"]
     assert len(xb) == world + 1 and xb[0] == 0 and xb[-1] == d["config"]["users"]
     assert d["all_gather_alone_ms"]["x_ms"] > 0
+    # the line proves how many ranks the communicator saw and what every rank held
+    rk = d["ranks"]
+    assert rk["comm_sizes_read_back"] == [world] and len(rk["per_rank"]) == world
+    assert sorted(r["comm_rank"] for r in rk["per_rank"]) == list(range(world))
+    assert sum(r["x_rows"] for r in rk["per_rank"]) == d["config"]["users"] and sum(r["y_rows"] for r in rk["per_rank"]) == d["config"]["items"]
+    assert sum(r["x_nnz"] for r in rk["per_rank"]) == d["config"]["nnz"] == sum(r["y_nnz"] for r in rk["per_rank"])
+    assert all(r["pci_bus_id"] for r in rk["per_rank"]) and 0 < rk["ms_per_step_min"] <= rk["ms_per_step_max"]
     assert 0.0 <= d["reconstruction_error"]["mean"] <= 1.0

@@ -13,6 +13,7 @@ def main():
     filt = sys.argv[2] if len(sys.argv) > 2 else "mals::"
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(set))
+    each = defaultdict(lambda: defaultdict(dict))   # per dispatch, in dispatch order (the X-half and Y-half launches of one kernel differ)
     for f in sorted(glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True)):
         with open(f) as fh:
             for row in csv.DictReader(fh):
@@ -23,11 +24,15 @@ def main():
                 c = row["Counter_Name"]
                 agg[name][c] += float(row["Counter_Value"])
                 calls[name][c].add(row.get("Dispatch_Id"))
+                d = int(row.get("Dispatch_Id") or 0)
+                each[name][c][d] = each[name][c].get(d, 0.0) + float(row["Counter_Value"])
     for name in sorted(agg):
         print(name)
         for c in sorted(agg[name]):
             n = max(len(calls[name][c]), 1)
             print("    %-28s per-dispatch %18.1f   (dispatches %d)" % (c, agg[name][c] / n, n))
+            if 1 < n <= 16:
+                print("        in dispatch order: " + " ".join("%.4g" % each[name][c][d] for d in sorted(each[name][c])))
 
 
 if __name__ == "__main__":
