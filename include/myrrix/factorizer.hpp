@@ -169,8 +169,12 @@ class AlternatingLeastSquares final : public MatrixFactorizer {
     Csr r = toCsr(RbyRow_, userIDs, itemIndex), c = toCsr(RbyColumn_, itemIDs, userIndex);
     std::vector<float> y0((size_t)yIDs.size() * k);
     for (size_t i = 0; i < yIDs.size(); ++i) std::copy(Y0[yIDs[i]].begin(), Y0[yIDs[i]].end(), y0.begin() + i * k);
-    std::vector<int64_t> tu = chooseAboutN(NUM_USER_ITEMS_TO_TEST_CONVERGENCE, userIDs.size(), rng);  // ALS:206-209
-    std::vector<int64_t> ti = chooseAboutN(NUM_USER_ITEMS_TO_TEST_CONVERGENCE, itemIDs.size(), rng);  // ALS:210-213
+    // ALS:206 asks RandomManager for ANOTHER generator (constructInitialY had its own, ALS:266): under the test seed every
+    // getRandom() is a fresh MersenneTwister(TEST_SEED) (RandomManager.java:61-64) -- the sample's skips start at the
+    // beginning of the stream whatever constructInitialY consumed
+    MersenneTwister rngSample(std::stoll(System::getProperty("model.test.seed", "1234567890")));
+    std::vector<int64_t> tu = chooseAboutN(NUM_USER_ITEMS_TO_TEST_CONVERGENCE, userIDs.size(), rngSample);  // ALS:206-209
+    std::vector<int64_t> ti = chooseAboutN(NUM_USER_ITEMS_TO_TEST_CONVERGENCE, itemIDs.size(), rngSample);  // ALS:210-213
 
     mals_config cfg;
     mals_default_config(&cfg);

@@ -438,6 +438,7 @@ int mals_group_create_rank(const mals_config* cfg, int32_t world, int32_t rank, 
 int mals_group_destroy(mals_group g);
 const char* mals_group_last_error(mals_group g);
 int mals_group_world(mals_group g);
+int mals_group_features(mals_group g);   /* cfg.features (0 for a null group): lets a binding size-check factor arrays */
 /* the handle of local member i (0 .. n_local-1; n_local = world for mals_group_create, 1 for create_rank)
  * and its rank -- for per-GPU calls such as mals_get_stats, mals_recommend, mals_reconstruction_error */
 int mals_group_local(mals_group g, int32_t i, mals_handle* handle_out, int32_t* rank_out);
@@ -475,6 +476,9 @@ int mals_group_set_matrix(mals_group g, int side, int64_t n_rows, int64_t nnz, c
 int mals_group_begin_matrix(mals_group g, int side, int64_t n_rows, const int64_t* row_ptr);
 int mals_group_append_rows(mals_group g, int side, int64_t n_rows, const int32_t* col_idx, const float* val);
 int mals_group_end_matrix(mals_group g, int side);
+/* How many entries the next n_rows rows of the chunked upload in progress hold (from the row_ptr given to begin): what a
+ * binding checks its arrays against BEFORE mals_group_append_rows reads them. */
+int mals_group_pending_entries(mals_group g, int side, int64_t n_rows, int64_t* n_entries_out);
 /* slice bounds of a side after its matrix was set: bounds_out[world+1] */
 int mals_group_bounds(mals_group g, int side, int64_t* bounds_out);
 

@@ -97,6 +97,11 @@ JNIEXPORT jint JNICALL JNI_FN(nativeAppendRows)(JNIEnv* env, jclass cls, jlong g
                                                 jfloatArray val, jint n_entries) {
   (void)cls;
   if ((*env)->GetArrayLength(env, col_idx) < n_entries || (*env)->GetArrayLength(env, val) < n_entries) return MALS_INVALID_ARG;
+  /* the library reads row_ptr[b] - row_ptr[a] entries whatever the caller believes: the two must agree BEFORE it does */
+  int64_t expected = -1;
+  const int prc = mals_group_pending_entries(as_group(group), side, n_rows, &expected);
+  if (prc != MALS_OK) return prc;
+  if (expected != (int64_t)n_entries) return MALS_INVALID_ARG;
   jint* c = (*env)->GetIntArrayElements(env, col_idx, NULL);
   if (!c) return MALS_OOM;
   jfloat* v = (*env)->GetFloatArrayElements(env, val, NULL);
@@ -120,6 +125,7 @@ JNIEXPORT jint JNICALL JNI_FN(nativeEndMatrix)(JNIEnv* env, jclass cls, jlong gr
 JNIEXPORT jint JNICALL JNI_FN(nativeSetFactors)(JNIEnv* env, jclass cls, jlong group, jint side, jlong row_begin, jint n_rows,
                                                 jfloatArray rows) {
   (void)cls;
+  if (n_rows < 0 || (int64_t)(*env)->GetArrayLength(env, rows) < (int64_t)n_rows * mals_group_features(as_group(group))) return MALS_INVALID_ARG;
   jfloat* r = (*env)->GetFloatArrayElements(env, rows, NULL);
   if (!r) return MALS_OOM;
   const int rc = mals_group_set_factors(as_group(group), side, row_begin, n_rows, (const float*)r);
@@ -131,6 +137,7 @@ JNIEXPORT jint JNICALL JNI_FN(nativeSetFactors)(JNIEnv* env, jclass cls, jlong g
 JNIEXPORT jint JNICALL JNI_FN(nativeGetFactors)(JNIEnv* env, jclass cls, jlong group, jint side, jlong row_begin, jint n_rows,
                                                 jfloatArray out) {
   (void)cls;
+  if (n_rows < 0 || (int64_t)(*env)->GetArrayLength(env, out) < (int64_t)n_rows * mals_group_features(as_group(group))) return MALS_INVALID_ARG;
   jfloat* r = (*env)->GetFloatArrayElements(env, out, NULL);
   if (!r) return MALS_OOM;
   const int rc = mals_group_get_factors(as_group(group), side, row_begin, n_rows, (float*)r);

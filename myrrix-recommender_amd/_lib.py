@@ -134,6 +134,8 @@ SYMBOLS = {
     "mals_group_destroy": (ctypes.c_int, [_H]),
     "mals_group_last_error": (ctypes.c_char_p, [_H]),
     "mals_group_world": (ctypes.c_int, [_H]),
+    "mals_group_features": (ctypes.c_int, [_H]),
+    "mals_group_pending_entries": (ctypes.c_int, [_H, ctypes.c_int, _I64, ctypes.POINTER(_I64)]),
     "mals_group_local": (ctypes.c_int, [_H, _I32, ctypes.POINTER(_H), ctypes.POINTER(_I32)]),
     "mals_group_set_exchange_chunks": (ctypes.c_int, [_H, _I32]),
     "mals_group_use_transport": (ctypes.c_int, [ctypes.c_char_p]),

@@ -564,6 +564,18 @@ const char* mals_group_last_error(mals_group g) { return g ? g->err.c_str() : "n
 
 int mals_group_world(mals_group g) { return g ? g->world : 0; }
 
+int mals_group_features(mals_group g) { return g ? g->cfg.features : 0; }
+
+int mals_group_pending_entries(mals_group g, int side, int64_t n_rows, int64_t* n_entries_out) {
+  GSIDE(g, side);
+  const std::vector<int64_t>& rp = g->up_row_ptr[side];
+  if (rp.empty() || !n_entries_out) return gfail(g, MALS_INVALID_ARG, "no chunked upload in progress");
+  const int64_t a = g->up_next_row[side], b = a + n_rows;
+  if (n_rows < 0 || b > g->n_rows[side]) return gfail(g, MALS_INVALID_ARG, "piece exceeds the declared matrix");
+  *n_entries_out = rp[(size_t)b] - rp[(size_t)a];
+  return MALS_OK;
+}
+
 int mals_group_local(mals_group g, int32_t i, mals_handle* handle_out, int32_t* rank_out) {
   if (!g) return MALS_INVALID_ARG;
   if (i < 0 || (size_t)i >= g->m.size()) return gfail(g, MALS_INVALID_ARG, "no such local member");

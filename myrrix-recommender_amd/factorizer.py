@@ -254,6 +254,14 @@ class AlternatingLeastSquares(MatrixFactorizer):
                     recent.append(v)
         return Y
 
+    @classmethod
+    def _convergence_sample(cls, seed, user_ids, item_ids):
+        """ALS:205-215: dense indices of the ~100 x ~100 test pairs, users first, from ONE fresh generator."""
+        rng_sample = MersenneTwister(seed)
+        tu = _choose_about_n(cls.NUM_USER_ITEMS_TO_TEST_CONVERGENCE, user_ids, rng_sample)  # ALS:206-209
+        ti = _choose_about_n(cls.NUM_USER_ITEMS_TO_TEST_CONVERGENCE, item_ids, rng_sample)  # ALS:210-213
+        return tu, ti
+
     @staticmethod
     def _csr(rows_by_id, row_ids, col_index, what):
         row_ptr = np.zeros(len(row_ids) + 1, dtype=np.int64)
@@ -300,8 +308,10 @@ class AlternatingLeastSquares(MatrixFactorizer):
         c_csr = self._csr(self.RbyColumn, item_ids, user_index, "RbyColumn")
         Y0m = np.stack([Y0[i] for i in y_ids]).astype(np.float32)
 
-        tu = _choose_about_n(self.NUM_USER_ITEMS_TO_TEST_CONVERGENCE, user_ids, rng)  # ALS:206-209
-        ti = _choose_about_n(self.NUM_USER_ITEMS_TO_TEST_CONVERGENCE, item_ids, rng)  # ALS:210-213
+        # ALS:206 asks RandomManager for ANOTHER generator (constructInitialY had its own, ALS:266): under the test seed
+        # every getRandom() is a fresh MersenneTwister(TEST_SEED) (RandomManager.java:61-64), so the sample's skips
+        # start at the beginning of the stream whatever constructInitialY consumed
+        tu, ti = self._convergence_sample(seed, user_ids, item_ids)
 
         try:
             core = ALSCore(k, alpha=alpha, lam=lam, flags=flags, device=self.device,

@@ -159,14 +159,36 @@ class ShardedALS:
         for stage, lo, hi in stages:
             full.view(self.world, per, k)[:, lo:hi].copy_(stage)
 
+    def check(self):
+        """core.check() agreed over the ranks: a singular row is found by the rank that owns it only; the others
+        would walk on into the next half-iteration's collectives and block there until the timeout.  Every rank
+        therefore contributes its status to one MAX all-reduce and all of them raise (mals_group's agree_status
+        does the same below the C-ABI)."""
+        if self.single:
+            self.core.check()
+            return
+        import torch.distributed as dist
+        err = None
+        try:
+            self.core.check()
+        except Exception as e:   # noqa: BLE001 -- re-raised below, after the collective
+            err = e
+        code = 0 if err is None else int(getattr(err, "status", 3) or 3)
+        t = self.torch.tensor([code], dtype=self.torch.int32, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if err is not None:
+            raise err
+        if int(t.item()) != 0:
+            raise RuntimeError("another rank reported status %d in this half-iteration" % int(t.item()))
+
     def iterate(self, n=1, check=True):
         """check: report a singular row after EVERY half-iteration, before its zeroed factors are
-        exchanged into later Gramians (the reference fails at the f.get() of that half, ALS:346-361);
-        check=False defers to the caller (timing loops)."""
+        exchanged into later Gramians (the reference fails at the f.get() of that half, ALS:346-361) -- on every
+        rank (self.check); check=False defers to the caller (timing loops)."""
         for _ in range(n):
             self.half_iteration(SIDE_X)
             if check:
-                self.core.check()
+                self.check()
             self.half_iteration(SIDE_Y)
             if check:
-                self.core.check()
+                self.check()

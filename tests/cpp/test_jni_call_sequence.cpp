@@ -3,7 +3,8 @@
 // (java/net/myrrix/online/factorizer/als/HipAlternatingLeastSquares.java):
 //   mals_default_config, mals_group_create(devices, n)
 //   mals_group_set_refine_limit (optional), mals_group_set_factor_rows(X), (Y)
-//   mals_group_begin_matrix / mals_group_append_rows (pieces of whole rows) / mals_group_end_matrix, for R and R^T
+//   mals_group_begin_matrix / [mals_group_pending_entries +] mals_group_append_rows (pieces of whole rows) /
+//   mals_group_end_matrix, for R and R^T; mals_group_features (array size checks of the shim)
 //   mals_group_set_factors(Y, pieces)                      setPreviousY / initial Y
 //   mals_group_factorize                                    call()
 //   mals_group_get_factors(X), (Y)                          getX() / getY()
@@ -81,9 +82,19 @@ int main(int argc, char** argv) {
     REQUIRE_OK(mals_group_begin_matrix(g, side, n_rows, row_ptr.data()));
     for (int r0 = 0; r0 < n_rows; r0 += piece) {
       const int r1 = r0 + piece < n_rows ? r0 + piece : n_rows;
+      int64_t expected_entries = -1;   // nativeAppendRows checks its arrays against this before the library reads them
+      REQUIRE_OK(mals_group_pending_entries(g, side, r1 - r0, &expected_entries));
+      if (expected_entries != row_ptr[(size_t)r1] - row_ptr[(size_t)r0]) {
+        std::printf("FAIL mals_group_pending_entries: %lld\n", (long long)expected_entries);
+        return 1;
+      }
       REQUIRE_OK(mals_group_append_rows(g, side, r1 - r0, col.data() + row_ptr[(size_t)r0], val.data() + row_ptr[(size_t)r0]));
     }
     REQUIRE_OK(mals_group_end_matrix(g, side));
+  }
+  if (mals_group_features(g) != features) {   // nativeSetFactors / nativeGetFactors size-check their float[] with it
+    std::printf("FAIL mals_group_features\n");
+    return 1;
   }
   for (int r0 = 0; r0 < n_items; r0 += piece) {
     const int n = r0 + piece < n_items ? piece : n_items - r0;

@@ -63,3 +63,46 @@ def test_jni_call_sequence_reproduces_the_known_answers(tmp_path, name, members,
     r = subprocess.run([BIN, str(p), str(members), str(backend), str(piece)], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
+
+
+# ---- the Solver SPI behind the reference's own hook (MatrixUtils.java:44-49 -> net.myrrix.common.math.JBlasLinearSystemSolver)
+SPI_BIN = os.path.join(CPP, "test_solver_spi_sequence")
+
+
+def test_solver_spi_sources_are_complete():
+    """JBlasLinearSystemSolver (same FQCN the reference loads reflectively) + NativeSolver + their JNI functions:
+    every native method has its function, the shim only calls declared entry points, and the class implements
+    exactly the reference's package-private interface."""
+    import re
+    lss = open(os.path.join(ROOT, "java/net/myrrix/common/math/JBlasLinearSystemSolver.java")).read()
+    ns = open(os.path.join(ROOT, "java/net/myrrix/common/math/NativeSolver.java")).read()
+    shim = open(os.path.join(ROOT, "jni/myrrix_solver_jni.c")).read()
+    header = open(os.path.join(ROOT, "include/myrrix_als.h")).read()
+    assert "package net.myrrix.common.math;" in lss and "public final class JBlasLinearSystemSolver implements LinearSystemSolver" in lss
+    assert "public Solver getSolver(RealMatrix M)" in lss and "public boolean isNonSingular(RealMatrix M)" in lss   # LinearSystemSolver.java:39,45
+    assert "public float[] solveDToF(double[] b)" in ns and "public double[] solveFToD(float[] b)" in ns            # Solver.java:35,41
+    natives = set(re.findall(r"static native \w+(?:\[\])? (native\w+)\(", ns))
+    assert natives == {"nativeCreate", "nativeRecompute", "nativeSolveDToF", "nativeSolveFToD", "nativeDestroy"}
+    assert natives == set(re.findall(r"JNI_FN\((native\w+)\)", shim))
+    assert "Java_net_myrrix_common_math_NativeSolver_" in shim
+    for fn in set(re.findall(r"\b(mals_\w+)\(", shim)):
+        assert re.search(r"\b%s\(" % fn, header), fn
+    strip = lambda t: re.sub(r"/\*.*?\*/|//[^\n]*", "", t, flags=re.S)      # noqa: E731
+    assert all("..." not in strip(t) for t in (lss, ns, shim))
+
+
+def test_solver_spi_call_sequence_on_the_host():
+    """Generation.recomputeSolver's inputs (Generation.java:142-158) through mals_solver_*: healthy side, inf-norm < 1
+    (IllConditionedSolverException before any solver is built), fewer rows than features (SingularMatrixSolverException
+    with the apparent rank), isNonSingular.  No GPU needed."""
+    subprocess.check_call(["make", "-C", CPP, "test_solver_spi_sequence"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([SPI_BIN], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ALL PASSED (host)" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_solver_spi_call_sequence_with_the_device_gramian():
+    """... plus NativeSolver.recompute: M^T M of the factors resident in the factorizer's group on the device."""
+    subprocess.check_call(["make", "-C", CPP, "test_solver_spi_sequence"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([SPI_BIN, "device"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALL PASSED (host + device)" in r.stdout, r.stdout + r.stderr

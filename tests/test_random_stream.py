@@ -77,3 +77,22 @@ def test_cpp_mirror_draws_the_same_stream():
     gs = [float.fromhex(t) for t in out[len(vals):len(vals) + 101]]
     gp = [mt.nextGaussian() for _ in range(101)]
     assert np.allclose(gs, gp, rtol=4e-16, atol=0)   # libm on both sides; the compilers may contract differently
+
+
+def test_convergence_sample_starts_a_fresh_generator():
+    """ALS:206 calls RandomManager.getRandom() again -- under the test seed a NEW MersenneTwister(1234567890)
+    (RandomManager.java:61-64) -- so the ~100 x ~100 sample does not depend on how much of the stream
+    constructInitialY (ALS:266, its own generator) consumed."""
+    from myrrix_recommender_amd import factorizer
+    from myrrix_recommender_amd.random_mt import MersenneTwister
+    seed = 1234567890
+    users, items = list(range(5000)), list(range(100, 2100))
+    tu, ti = factorizer.AlternatingLeastSquares._convergence_sample(seed, users, items)
+    fresh = MersenneTwister(seed)
+    assert tu == factorizer._choose_about_n(100, users, fresh)
+    assert ti == factorizer._choose_about_n(100, items, fresh)       # the same generator goes on to the items (ALS:210-213)
+    used = MersenneTwister(seed)
+    for _ in range(1000):
+        used.nextGaussian()                                          # what a cold start draws first
+    assert tu != factorizer._choose_about_n(100, users, used)
+    assert 40 < len(tu) < 180 and 40 < len(ti) < 180 and tu == sorted(set(tu))

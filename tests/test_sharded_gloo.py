@@ -120,3 +120,50 @@ def test_world2_gloo_matches_unsharded(mode):
         # fp64 rounding, far below fp32 storage
         assert np.allclose(X, Xo, rtol=1e-5, atol=1e-6), rank
         assert np.allclose(Y, Yo, rtol=1e-5, atol=1e-6), rank
+
+
+def _worker_singular(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_users, n_items, k = 40, 20, 4
+        r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 300, k, seed=3)
+
+        class FailsOnRank1(OracleBackedCore):
+            def check(self):
+                if rank == 1:     # the rank that owns the singular row (CMLSS:46-54 on that rank only)
+                    raise pkg.SingularSystem(1, "near-singular system for row 33 of side X", 0, 33, 2)
+
+        s = sharded.ShardedALS(FailsOnRank1(k), n_users, n_items, k, rank=rank, world=world, device="cpu")
+        s.set_matrix_from_full(pkg.SIDE_X, *r_csr)
+        s.set_matrix_from_full(pkg.SIDE_Y, *c_csr)
+        s.set_factors(pkg.SIDE_Y, Y0)
+        try:
+            s.iterate(1)
+            q.put((rank, "no error"))
+        except pkg.SingularSystem as e:
+            q.put((rank, "singular row %d" % e.row))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+        dist.barrier()           # both ranks left the half-iteration together: nobody is stuck in a collective
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_singular_row_fails_every_rank():
+    """a singular row raises on the rank that owns it only; the other rank must not walk on into the next
+    half-iteration's all-reduce and block there."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_singular, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] == "singular row 33"
+    assert "another rank reported status 1" in results[0]
