@@ -588,9 +588,11 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-// E = entry slots per lane and super-step: 8 -> 32 entries, v_mfma_f32_16x16x32_f16 (T <= 6);
-// 4 -> 16 entries, v_mfma_f32_16x16x16_f16 (T = 7, 8, where 8 slots would not fit the registers).
-// Both MFMAs take 16 cycles, so E = 8 does twice the work per matrix-pipe cycle.
+// E = entry slots per lane and super-step: 8 -> 32 entries, v_mfma_f32_16x16x32_f16 (T <= 7);
+// 4 -> 16 entries, v_mfma_f32_16x16x16_f16 (T = 8: 144 accumulators + 64 raw + 64 operand registers do not fit).
+// Both MFMAs take 16 cycles, so E = 8 does twice the work per matrix-pipe cycle.  Round 3: T = 6 (238 VGPRs, no
+// spill) and T = 7 (256 VGPRs + 84 B of scratch in the rows kernel, 44 B in the segments kernel) moved to E = 8:
+// C3 (k = 100) 16.2 -> 15.35 ms, k = 112 38.2 -> 36.3 ms per iteration on the same box.
 template <int E>
 struct ZOp {  // one f16 MFMA operand: E halves = E/2 dwords
   int r[E / 2];
@@ -606,7 +608,10 @@ __device__ __forceinline__ f32x4 mfma_h(const ZOp<E>& a, const ZOp<E>& b, f32x4 
 __device__ __forceinline__ int pk_rtz(float a, float b) {  // v_cvt_pkrtz_f16_f32
   return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
-__host__ __device__ constexpr int split_slots(int T) { return T <= 5 ? 8 : 4; }
+#ifndef MALS_SPLIT8_MAXT
+#define MALS_SPLIT8_MAXT 7
+#endif
+__host__ __device__ constexpr int split_slots(int T) { return T <= MALS_SPLIT8_MAXT ? 8 : 4; }
 
 // the Gramian weight of the chunk becomes sqrt(w) * S
 __device__ __forceinline__ void chunk_weights_h(const SolveParams& p, Chunk& e, float zscale) {

@@ -154,6 +154,14 @@ struct mals_handle_s {
   int n_cu = 256;
   SideState side[2];
   hipStream_t stream = nullptr;
+  // The three independent parts of a chunk -- rows list, long rows (segments + finish), dual lists (rotation + dual
+  // kernels) -- are enqueued on three streams between a fork and a join event: the small launches (a few hundred
+  // workgroups: the long rows of C2, the dual classes, the rotations) fill the slots the rows kernel's tail leaves
+  // instead of each paying its own ramp-up and tail.  MALS_OVERLAP=0 puts everything back on the one stream.
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  bool overlap = true;
+  bool forked[2] = {false, false};
   std::string err;
   unsigned long long* d_bad = nullptr;   // [4]: first non-PD row per side, then the smallest-pivot suspect per side
   unsigned long long* h_bad = nullptr;   // pinned
@@ -551,7 +559,9 @@ int persistent_grid(mals_handle h, K kernel, int64_t n_work, unsigned* grid) {
   return MALS_OK;
 }
 
-enum { LISTS_OWN = 1, LISTS_DUAL_ROWS = 2 };  // the direct kernels over: segments / rows / finish / zero-fill; the dual lists
+// what one launch_solve call covers: the rows list (+ zero-fill) / the dual lists through the direct kernel / the long
+// rows (segments + finish).  The three are independent of each other (disjoint output rows, read-only inputs).
+enum { LISTS_ROWS = 1, LISTS_DUAL_ROWS = 2, LISTS_LONG = 4, LISTS_OWN = LISTS_ROWS | LISTS_LONG };
 
 // One persistent launch, plus -- for a split-precision kernel -- its fp32-gather twin right behind it with
 // flag bit 3: exactly one of the two does the work (gather_scale_kernel's range flag), the other returns at once.
@@ -580,8 +590,8 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int whic
   const double per = 4.0 * p.k + 8.0;  // gathered row + col idx + value; written row + row_ptr
   const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
   PendingEvent pe;
-  const bool own = which & LISTS_OWN, dual_rows_too = which & LISTS_DUAL_ROWS;
-  if (own && cr.nB) {
+  const bool own = which & LISTS_ROWS, longs = which & LISTS_LONG, dual_rows_too = which & LISTS_DUAL_ROWS;
+  if (longs && cr.nB) {
     p.n_work = cr.nB;
     p.items = s.itemsB + cr.offB;
     if (int rc = launch_persistent(h, segments_kernel, segments_fallback, p, 1, (double)cr.nnzB * per)) return rc;
@@ -596,7 +606,7 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int whic
     p.items = s.itemsA + cr.offA + cr.nA;
     if (int rc = launch_persistent(h, rows_kernel, rows_fallback, p, 0, (double)cr.nnz_dual() * per + (double)cr.n_dual() * per)) return rc;
   }
-  if (own && cr.nC) {
+  if (longs && cr.nC) {
     p.n_work = cr.nC;
     p.rowsC = s.rowsC + cr.offC;
     if (int rc = begin_timed(h, 2, (double)cr.nC * per, pe)) return rc;
@@ -1384,6 +1394,14 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
     return MALS_HIP_ERROR;
   }
   if (const char* e = std::getenv("MALS_REFINE_LIMIT")) h->refine_limit = std::max(0.f, (float)std::atof(e));
+  if (const char* e = std::getenv("MALS_OVERLAP")) h->overlap = std::atoi(e) != 0;
+  if (h->overlap) {
+    bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+      ok = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) h->overlap = false;
+  }
 #ifdef MALS_PROFILING
   if (std::getenv("MALS_DEBUG_TRACE")) {
     (void)hipMalloc(&h->d_trace, 64 * 64 * 6 * sizeof(unsigned long long));
@@ -1443,6 +1461,12 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_zbound);
   if (h->h_G) (void)hipHostFree(h->h_G);
   if (h->eig_stage) (void)hipHostFree(h->eig_stage);
+  for (int i = 0; i < 2; ++i) {
+    if (h->aux[i]) (void)hipStreamSynchronize(h->aux[i]);
+    if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+    if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_G) (void)hipEventDestroy(h->ev_G);
   if (h->h_bad) (void)hipHostFree(h->h_bad);
   free_dev(h->d_idx);
@@ -1766,6 +1790,37 @@ int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) {
   return MALS_OK;
 }
 
+// fork: the side streams start behind everything enqueued on the main stream so far; join: the main stream continues
+// behind whatever was put on them.  A scope swaps h->stream so that every launch helper (and its timing events) lands
+// on the side stream.
+struct SideStream {
+  mals_handle h;
+  hipStream_t saved;
+  SideStream(mals_handle hh, int i) : h(hh), saved(hh->stream) {
+    if (h->overlap && h->forked[i]) h->stream = h->aux[i];
+  }
+  ~SideStream() { h->stream = saved; }
+};
+static int fork_streams(mals_handle h) {
+  if (!h->overlap) return MALS_OK;
+  HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(h, hipStreamWaitEvent(h->aux[i], h->ev_fork, 0));
+    h->forked[i] = true;
+  }
+  return MALS_OK;
+}
+static int join_streams(mals_handle h) {
+  if (!h->overlap) return MALS_OK;
+  for (int i = 0; i < 2; ++i) {
+    if (!h->forked[i]) continue;
+    HIPCHK(h, hipEventRecord(h->ev_join[i], h->aux[i]));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+    h->forked[i] = false;
+  }
+  return MALS_OK;
+}
+
 // phase: the whole of every chunk (ALL); or, for callers that drive several handles from one thread (mals_group.cpp),
 // one chunk in two calls -- BEGIN enqueues everything that does not need the eigendecomposition of the dual path and
 // returns (h->dual_pending says whether anything is left), the caller provides the decomposition (prepare_dual_host,
@@ -1921,32 +1976,48 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
     const int64_t row1 = std::min<int64_t>(s.n_local, (int64_t)(c + 1) * rows_per_chunk);
     if (!resume && p.refine_flag && row1 > row0) HIPCHK(h, hipMemsetAsync(s.refine + row0, 0, (size_t)(row1 - row0), h->stream));
     bool dual_now = want_dual && !dual_stale && h->dual_ok;
+    if (!resume)
+      if (int rc = fork_streams(h)) return rc;
     if (want_dual && dual_stale && c == chunk_begin) {
       if (!resume) {
-        if (int rc = launch_solve(h, s, p, c, LISTS_OWN)) return rc;  // direct lists first ...
-        if (phase == SOLVE_BEGIN) {                                   // ... the caller decomposes G under them
+        {
+          SideStream long_rows(h, 0);
+          if (int rc = launch_solve(h, s, p, c, LISTS_LONG)) return rc;
+        }
+        if (int rc = launch_solve(h, s, p, c, LISTS_ROWS)) return rc;   // direct lists first ...
+        if (phase == SOLVE_BEGIN) {                                     // ... the caller decomposes G under them
           h->dual_pending = true;
           h->dual_pending_side = side;
           h->dual_pending_chunk = c;
           return MALS_OK;
         }
-        if (int rc = prepare_dual_host(h, side, nullptr)) return rc;  // ... host eigendecomposition under them
+        if (int rc = prepare_dual_host(h, side, nullptr)) return rc;    // ... host eigendecomposition under them
       } else if (h->dual_side != side || h->dual_version != o.G_version) {
         return fail(h, MALS_INVALID_ARG, "solve END without the eigendecomposition of this half-iteration");
       }
       h->dual_pending = false;
-      if (int rc = prepare_dual_device(h, side)) return rc;
-      dual_now = h->dual_ok;
-      if (dual_now) {
-        if (int rc = launch_dual_chunk(h, side, c)) return rc;
-      } else if (cr.n_dual()) {  // does not qualify: the dual lists through the direct kernel after all
-        if (int rc = launch_solve(h, s, p, c, LISTS_DUAL_ROWS)) return rc;
+      {
+        SideStream dual_rows(h, 1);
+        if (int rc = prepare_dual_device(h, side)) return rc;
+        dual_now = h->dual_ok;
+        if (dual_now) {
+          if (int rc = launch_dual_chunk(h, side, c)) return rc;
+        } else if (cr.n_dual()) {  // does not qualify: the dual lists through the direct kernel after all
+          if (int rc = launch_solve(h, s, p, c, LISTS_DUAL_ROWS)) return rc;
+        }
       }
     } else {
-      if (int rc = launch_solve(h, s, p, c, dual_now ? LISTS_OWN : (LISTS_OWN | LISTS_DUAL_ROWS))) return rc;
-      if (dual_now && cr.n_dual())
+      {
+        SideStream long_rows(h, 0);
+        if (int rc = launch_solve(h, s, p, c, LISTS_LONG)) return rc;
+      }
+      if (dual_now && cr.n_dual()) {
+        SideStream dual_rows(h, 1);
         if (int rc = launch_dual_chunk(h, side, c)) return rc;
+      }
+      if (int rc = launch_solve(h, s, p, c, dual_now ? LISTS_ROWS : (LISTS_ROWS | LISTS_DUAL_ROWS))) return rc;
     }
+    if (int rc = join_streams(h)) return rc;
     if (p.refine_flag && row1 > row0) {  // behind every kernel of the chunk (the un-rotation of the dual rows included)
       if (!h->d_Gref) {   // before the parameter block below takes the pointers
         const size_t kp2 = (size_t)(16 * h->T) * (size_t)(16 * h->T);
