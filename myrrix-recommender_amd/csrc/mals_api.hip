@@ -157,10 +157,13 @@ struct mals_handle_s {
   // The three independent parts of a chunk -- rows list, long rows (segments + finish), dual lists (rotation + dual
   // kernels) -- are enqueued on three streams between a fork and a join event: the small launches (a few hundred
   // workgroups: the long rows of C2, the dual classes, the rotations) fill the slots the rows kernel's tail leaves
-  // instead of each paying its own ramp-up and tail.  MALS_OVERLAP=0 puts everything back on the one stream.
+  // instead of each paying its own ramp-up and tail.  Measured (round 3, same box, one stream vs three): C2 2.22 ->
+  // 2.18 ms, C4 81.8 -> 80.6, C5 rank 168.8 -> 165.3, C3 14.8 -> 15.3 (worse: its long rows then fight the rows
+  // kernel for the cache-resident table) -- 1-2 %, and every per-kernel HIP-event time (the roofline figures of
+  // mals_stats) then includes the other streams' contention.  So: OFF unless MALS_OVERLAP=1.
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-  bool overlap = true;
+  bool overlap = false;
   bool forked[2] = {false, false};
   std::string err;
   unsigned long long* d_bad = nullptr;   // [4]: first non-PD row per side, then the smallest-pivot suspect per side

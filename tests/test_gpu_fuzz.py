@@ -132,6 +132,41 @@ def test_seeded_configuration_sweep(seed):
         assert np.array_equal(Y[n_items:], Y0[n_items:])   # stale rows are never re-solved (ALS:304-308)
 
 
+def _well_conditioned(k, n_users, n_items, r_csr, cfg):
+    """The cases of the sweep whose systems are tame enough for TWO CHAINED half-iterations to be compared end to end:
+    moderate weights against a real ridge and more rows than features on both sides.  (On the others a 4e-7
+    difference in X legitimately moves Y by 1e-2 -- in the reference as well, see the comment in the sweep.)"""
+    return (cfg["lam"] >= 0.1 and cfg["alpha"] <= 1.0 and float(np.abs(r_csr[2]).max(initial=0.0)) <= 5.0 and
+            not (cfg["flags"] & pkg.FLAG_LOSS_IGNORES_UNSPECIFIED) and n_users >= 2 * k + 20 and n_items >= 2 * k + 20)
+
+
+@pytest.mark.parametrize("seed", [s for s in range(_FIRST, _FIRST + int(os.environ.get("MALS_FUZZ_SEEDS", "240")))])
+def test_seeded_sweep_two_chained_halves(seed):
+    """The sweep above resets X to the oracle's before the Y-half (parity is a statement about one half-iteration).
+    On the well-conditioned subset the two halves are ALSO run back to back on the device -- Y from the GPU's own X,
+    Gramian of that X included -- and compared with the oracle's chain end to end."""
+    k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg = draw_case(seed)
+    if not _well_conditioned(k, n_users, n_items, r_csr, cfg):
+        pytest.skip("not in the well-conditioned subset")
+    kw = dict(alpha=cfg["alpha"], lam=cfg["lam"], flags=cfg["flags"], threads=4)
+    try:
+        Xo = oracle.half_iteration(*r_csr, Y0, **kw)
+        Yo = oracle.half_iteration(*c_csr, Xo, **kw)
+    except oracle.SingularMatrix:
+        pytest.skip("singular in the reference (covered by the sweep above)")
+    with pkg.ALSCore(k, **cfg) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items + n_stale)
+        core.set_matrix(pkg.SIDE_X, *r_csr)
+        core.set_matrix(pkg.SIDE_Y, *c_csr)
+        core.set_factors(pkg.SIDE_Y, Y0)
+        core.half_iteration(pkg.SIDE_X)
+        core.half_iteration(pkg.SIDE_Y)          # from the device's own X: nothing is reset in between
+        X, Y = core.get_factors(pkg.SIDE_X), core.get_factors(pkg.SIDE_Y)
+    assert rel(X, Xo) < REL_TOL, (seed, k, cfg, rel(X, Xo))
+    assert rel(Y[:n_items], Yo) < REL_TOL, (seed, k, cfg, rel(Y[:n_items], Yo))
+
+
 # ---- call() (ALS:176-262): iteration count, convergence value and factors over several iterations ---------------------
 def well_posed_case(seed):
     """A case of the sweep above restricted to what several chained iterations can be compared on: the reference's
