@@ -121,6 +121,7 @@ struct mals_handle_s {
   uint64_t pad_version = 0;   // factor-upload count at the time of the copy
   uint64_t pad_epoch = 0;
   std::vector<uint8_t> pad_done;  // chunks solved from the current copy: solving one again starts a new half-iteration
+  char* d_eig = nullptr;      // device image of eig_stage; the four pointers below are views into it
   double* d_Q = nullptr;      // [2][16T][16T]: Q (k x 16T, zero padded) and Q^T
   float* d_Qf = nullptr;      // the same in fp32
   bool rotate_f64 = false;    // this half-iteration's forward rotation runs on the fp64 matrix cores
@@ -952,10 +953,13 @@ int prepare_dual_device(mals_handle h, int side) {
   h->dual_ok = false;
   if (!h->eig_ok) return MALS_OK;
   const EigStage e = eig_views(h);
-  if (h->rotate_split && !h->d_Bs) HIPCHK(h, hipMalloc(&h->d_Bs, sizeof(int32_t) * 2 * e.nBs));
-  if (!h->d_Q) HIPCHK(h, hipMalloc(&h->d_Q, sizeof(double) * e.nQ));
-  if (!h->d_Qf) HIPCHK(h, hipMalloc(&h->d_Qf, sizeof(float) * e.nQ));
-  if (!h->d_lam) HIPCHK(h, hipMalloc(&h->d_lam, sizeof(float) * e.nLam));
+  if (!h->d_eig) {  // one device block with the layout of the pinned one: ONE upload per half-iteration instead of four
+    HIPCHK(h, hipMalloc(&h->d_eig, h->eig_stage_bytes));
+    h->d_Q = reinterpret_cast<double*>(h->d_eig);
+    h->d_Qf = reinterpret_cast<float*>(h->d_eig + (reinterpret_cast<char*>(e.Qf) - h->eig_stage));
+    h->d_lam = reinterpret_cast<float*>(h->d_eig + (reinterpret_cast<char*>(e.lam) - h->eig_stage));
+    h->d_Bs = reinterpret_cast<int32_t*>(h->d_eig + (reinterpret_cast<char*>(e.Bs) - h->eig_stage));
+  }
   if (!h->d_zbound) HIPCHK(h, hipMalloc(&h->d_zbound, 2 * sizeof(unsigned)));  // {z bound of the dual kernels, x' bound of the un-rotation}
   const size_t need = (size_t)o.n_total * KP;
   if (h->Mr_cap < need) {
@@ -966,13 +970,8 @@ int prepare_dual_device(mals_handle h, int side) {
     h->Mr_cap = need;
   }
   // pinned source, rewritten no earlier than the next half-iteration's prepare_dual_host (which waits for this stream)
-  HIPCHK(h, hipMemcpyAsync(h->d_Q, e.Q, sizeof(double) * e.nQ, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_Qf, e.Qf, sizeof(float) * e.nQ, hipMemcpyHostToDevice, h->stream));
-  if (h->rotate_split) {
-    HIPCHK(h, hipMemcpyAsync(h->d_Bs, e.Bs, sizeof(int32_t) * 2 * e.nBs, hipMemcpyHostToDevice, h->stream));
-    h->Bs_stride = e.nBs;
-  }
-  HIPCHK(h, hipMemcpyAsync(h->d_lam, e.lam, sizeof(float) * e.nLam, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_eig, h->eig_stage, h->eig_stage_bytes, hipMemcpyHostToDevice, h->stream));
+  h->Bs_stride = e.nBs;
   HIPCHK(h, hipMemsetAsync(h->d_zbound, 0, 2 * sizeof(unsigned), h->stream));
   RotateParams rp;
   rp.src = o.F;
@@ -1457,10 +1456,7 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_colrange);
   free_dev(h->d_Mr);
   free_dev(h->d_Mp);
-  free_dev(h->d_Q);
-  free_dev(h->d_Qf);
-  free_dev(h->d_Bs);
-  free_dev(h->d_lam);
+  free_dev(h->d_eig);  // d_Q, d_Qf, d_lam, d_Bs are views into it
   free_dev(h->d_zbound);
   if (h->h_G) (void)hipHostFree(h->h_G);
   if (h->eig_stage) (void)hipHostFree(h->eig_stage);
