@@ -93,3 +93,32 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.mals_plan_shards(None, 0, 2, -1.0, 64, None) == _lib.INVALID_ARG
     assert L.mals_set_chunk_rows(None, 0, 10) == _lib.INVALID_ARG
     assert L.mals_set_refine_limit(None, 1024.0) == _lib.INVALID_ARG
+
+
+def test_round3_entry_points_reject_bad_arguments_without_a_gpu():
+    """Host-only argument checks of the entry points added in round 3 (no device work)."""
+    L = _lib.load()
+    out4 = (ctypes.c_double * 4)()
+    assert L.mals_get_timeline(None, out4) == _lib.INVALID_ARG
+    assert L.mals_group_features(None) == 0
+    n = ctypes.c_int64(-1)
+    assert L.mals_group_pending_entries(None, 0, 1, ctypes.byref(n)) == _lib.INVALID_ARG
+    a, b, c = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert L.mals_group_comm_info(None, 0, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), None, 0) == _lib.INVALID_ARG
+    # the transport is chosen by an API call of the host process (never by the environment) and only before it is loaded
+    assert L.mals_group_use_transport(None) == _lib.OK
+    src = open(os.path.join(ROOT, "myrrix-recommender_amd", "csrc", "mals_group.cpp")).read()
+    assert "getenv" not in src, "the group layer must not pick its transport (or anything else) from the environment"
+
+
+def test_unloadable_transport_is_a_status_not_a_crash():
+    """the error text of a failed dlopen used to be built from two dlerror() calls (the second returns NULL:
+    std::string + nullptr) -- mals_group_unique_id must come back with MALS_COMM_ERROR.  Child process: the choice of
+    transport is made once per process."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from myrrix_recommender_amd import _lib; L = _lib.load(); "
+            "assert L.mals_group_use_transport(b'/nonexistent/librccl_missing.so') == 0; "
+            "buf = (ctypes.c_uint8 * 128)(); rc = L.mals_group_unique_id(buf); print('rc', rc); sys.exit(0 if rc == _lib.COMM_ERROR else 1)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
