@@ -511,6 +511,13 @@ int mals_group_synchronize(mals_group g);
  * (als_exact_kernel) before it is called singular.  mals_stats.rows_refined counts both. */
 int mals_set_refine_limit(mals_handle h, double limit);
 
+/* The operand scale of the split-precision gather as the last half-iteration computed it on the device (diagnostic):
+ * out4 = {S, 1/S^2, range flag (1 = split-precision kernels ran, 0 = their fp32 twins), the bound on |y| that was
+ * used}.  The bound is the exact max |element| of the gathered factor matrix whenever this library formed its Gramian
+ * (mals_gramian, mals_half_iteration, mals_factorize, the group calls: the Gramian kernels record it, a group all-reduces
+ * it), and sqrt(max_f G_ff) -- loose by up to sqrt(rows) -- after mals_set_gramian. */
+int mals_get_gather_scale(mals_handle h, float* out4);
+
 /* Host-side timeline of the current / last half-iteration on this handle (diagnostic), microseconds of one
  * process-wide steady clock: out4[0] = its first kernel was enqueued, out4[1] / out4[2] = begin / end of the host half
  * of the dual preparation (the k x k eigendecomposition, computed here or received from the group member that

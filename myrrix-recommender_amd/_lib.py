@@ -141,6 +141,7 @@ SYMBOLS = {
     "mals_group_use_transport": (ctypes.c_int, [ctypes.c_char_p]),
     "mals_group_comm_info": (ctypes.c_int, [_H, _I32, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.c_char_p, _I32]),
     "mals_get_timeline": (ctypes.c_int, [_H, _P]),
+    "mals_get_gather_scale": (ctypes.c_int, [_H, _P]),
     "mals_group_set_refine_limit": (ctypes.c_int, [_H, ctypes.c_double]),
     "mals_group_set_factor_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64]),
     "mals_group_set_factors": (ctypes.c_int, [_H, ctypes.c_int, _I64, _I64, _P]),

@@ -380,6 +380,12 @@ class ALSCore:
         self._chk(self._L.mals_get_timeline(self._h, out))
         return list(out)
 
+    def gather_scale(self):
+        """mals_get_gather_scale: [S, 1/S^2, range flag, bound on |y| used] of the last half-iteration's split-precision gather."""
+        out = (ctypes.c_float * 4)()
+        self._chk(self._L.mals_get_gather_scale(self._h, out))
+        return list(out)
+
     def set_refine_limit(self, limit):
         """mals_set_refine_limit: conditioning estimate above which a row is re-solved with fp64 residuals (0 = never)."""
         self._chk(self._L.mals_set_refine_limit(self._h, float(limit)))

@@ -1568,7 +1568,8 @@ __global__ __launch_bounds__(256) void als_exact_kernel(RefineParams q, int leve
 // MU:232; the exact fp64 product used here differs from that by < 2^-24 relative per term.)
 template <int T>
 __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __restrict__ M, int64_t n_rows, int k,
-                                                              int64_t rows_per_wave, double* __restrict__ partial) {
+                                                              int64_t rows_per_wave, double* __restrict__ partial,
+                                                              unsigned* __restrict__ ymax) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t r0 = wave * rows_per_wave;
@@ -1577,6 +1578,7 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
   f64x4 acc[tri(T)];
 #pragma unroll
   for (int t = 0; t < tri(T); ++t) acc[t] = f64x4{0., 0., 0., 0.};
+  float am = 0.f;  // largest |element| this lane has seen: the exact bound of the split-precision gather's operand scale
   for (int64_t r = r0; r < r1; r += 4) {
     const int64_t row = r + g;
     const bool ok = row < r1;
@@ -1587,6 +1589,7 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
       const int f = 16 * v + c;
       const float x = p[f < k ? f : k - 1];
       y[v] = (ok && f < k) ? (double)x : 0.0;
+      am = fmaxf(am, (ok && f < k) ? fabsf(x) : 0.f);
     }
 #pragma unroll
     for (int i = 0; i < T; ++i)
@@ -1599,6 +1602,12 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
   for (int t = 0; t < tri(T); ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[(t * 4 + r) * 64] = acc[t][r];
+  if (ymax) {
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
+    // same-address atomics serialise: only a wave that raises the maximum issues one; NaN / inf order above every finite
+    // bit pattern and are kept (the consumer then falls back to the Gramian's diagonal)
+    if (lane == 0 && __float_as_uint(am) > __builtin_nontemporal_load(ymax)) atomicMax(ymax, __float_as_uint(am));
+  }
 }
 
 // 64 (tile, reg, lane) elements per workgroup: each of the 4 waves sums a contiguous quarter of the
@@ -1734,7 +1743,8 @@ __global__ __launch_bounds__(256) void gramian_ref_kernel(const float* __restric
 // operand of the instruction at once (contraction over the 16 rows of the step).
 template <int T>
 __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __restrict__ M, int64_t n_rows, int k,
-                                                               int64_t rows_per_slab, float* __restrict__ partial) {
+                                                               int64_t rows_per_slab, float* __restrict__ partial,
+                                                               unsigned* __restrict__ ymax) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int64_t slab = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t r0 = slab * rows_per_slab;
@@ -1744,6 +1754,7 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
 #pragma unroll
   for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   int pw = 100;  // current scale 2^pw: max |z| <= 2^14
+  int slab_max = 0;  // bit pattern of the largest |element| of the slab (-> ymax: operand bound of the split-precision gather)
   for (int64_t r = r0; r < r1; r += 16) {
     // all 4T loads of the step first, no arithmetic on them in between (a use right behind each load makes the
     // compiler wait for every one in turn: 13 us per step instead of one memory latency)
@@ -1772,6 +1783,7 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
     int m = __float_as_int(amax);  // non-negative floats order like their bit patterns
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     m = uniform(m);
+    slab_max = max(slab_max, m);
     if (m != 0) {
       const int eb = ((m >> 23) & 255) - 126;  // step max < 2^eb
       const int want = 14 - eb;
@@ -1822,6 +1834,7 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
   for (int t = 0; t < tri(T); ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[(t * 4 + r) * 64] = acc[t][r] * back;
+  if (ymax && lane == 0 && (unsigned)slab_max > __builtin_nontemporal_load(ymax)) atomicMax(ymax, (unsigned)slab_max);
 }
 
 // G (k x k fp64 row-major) -> fp32 acc-layout image used by K2 (see gramian_finalize_kernel)
@@ -1840,22 +1853,31 @@ __global__ void gramian_pack_kernel(const double* __restrict__ G, int k, int T, 
 }
 
 // Split-precision gather: S = 2^p with  max|z| = sqrt(w_max) * S * max|y| <= 2^14.  max|y| is
-// bounded by sqrt(max_f G_ff) (G = M^T M of the gathered factor matrix, always at hand), w_max by
-// the largest |value| of the matrix side (max_abs_kernel at upload).  out = {S, 1/S^2, range flag}.
+// bounded by sqrt(max_f G_ff) (G = M^T M of the gathered factor matrix, always at hand) -- loose by up to
+// sqrt(n_rows): 13 binades of the 16 the range flag allows at the 1e8 rows of C5's X -- or, when the Gramian
+// kernels of this library made G (they read every element anyway), by the exact max |y| they recorded (ymax;
+// round 3).  w_max = the largest |value| of the matrix side (max_abs_kernel at upload).
+// out = {S, 1/S^2, range flag, bound on |y| used}.
 // Range flag: a typical operand, sqrt(w_mean) * rms|y_f| (rms over the n_rows rows that make up G), sits
 // log2(bound / typical) binades below the bound; both f16 halves of z keep all their bits while
 // z S >= 2^-2, i.e. up to 16 binades.  Beyond that (an outlier value or factor row stretching the
 // bound) the launch is NOT run in split precision: flag = 0 makes the split kernels return at once and
 // the fp32-gather kernels enqueued behind them do the work (no host round trip).
 __global__ void gather_scale_kernel(const double* __restrict__ G, int k, float sqrt_w_max, float sqrt_w_mean, double n_rows,
-                                    int force_flag, float* __restrict__ out) {
+                                    int force_flag, const unsigned* __restrict__ ymax, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double d = 0.0, tr = 0.0;
   for (int f = 0; f < k; ++f) {
     d = fmax(d, G[(int64_t)f * k + f]);
     tr += G[(int64_t)f * k + f];
   }
-  const double bound = sqrt(d) * (double)sqrt_w_max;
+  double ybound = sqrt(d);
+  if (ymax) {
+    const float ym = __uint_as_float(*ymax);
+    if (ym > 0.f && ym < 3.0e38f && (double)ym < ybound) ybound = (double)ym;   // non-finite: keep the diagonal's verdict
+  }
+  out[3] = (float)ybound;
+  const double bound = ybound * (double)sqrt_w_max;
   int e = 0;
   if (bound > 0.0 && bound < 1.0e300) {
     int eb;

@@ -86,6 +86,9 @@ struct SideState {
   size_t partial_bytes = 0;
   bool G_valid = false;
   uint64_t G_version = 0;  // bumped whenever G changes (cached operand scale of the split-precision gather)
+  unsigned* d_ymax = nullptr;  // bit pattern of max |element| over the rows G was formed from, recorded by the Gramian kernels
+  uint64_t ymax_version = 0;   // the G_version d_ymax belongs to (0 = none: G came from outside, gather_scale_kernel then
+                               // bounds |y| by sqrt(max_f G_ff))
   uint64_t F_epoch = 0;    // bumped whenever the library itself writes the replica (uploads, solves, rebinding)
 };
 
@@ -483,7 +486,7 @@ constexpr int64_t GRAMIAN_SPLIT_MIN_ROWS = 262144;
 constexpr int64_t GRAMIAN_SLAB_ROWS = 512;
 
 template <int T>
-int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows, double* G_out, float* Gf_out) {
+int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows, double* G_out, float* Gf_out, unsigned* ymax) {
   const int k = h->cfg.features;
   const int elems = tri(T) * 256;
   static const bool force_f64 = std::getenv("MALS_GRAMIAN_F64") != nullptr;  // A/B
@@ -504,7 +507,7 @@ int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows
     float* pf = reinterpret_cast<float*>(s.partials);
     double* pd = reinterpret_cast<double*>(reinterpret_cast<char*>(s.partials) + slab_bytes);  // slab_bytes is a multiple of 1024
     hipLaunchKernelGGL((gramian_split_kernel<T>), dim3((unsigned)(n_slabs / 4)), dim3(256), 0, h->stream, M, n_rows, k,
-                       GRAMIAN_SLAB_ROWS, pf);
+                       GRAMIAN_SLAB_ROWS, pf, ymax);
     hipLaunchKernelGGL(gramian_reduce_slabs_kernel, dim3((unsigned)((elems + 255) / 256), GROUPS), dim3(256), 0, h->stream, pf, n_slabs,
                        elems, GROUPS, pd);
     hipLaunchKernelGGL((gramian_finalize_kernel<T, false>), dim3(elems / 64), dim3(256), 0, h->stream, pd, (int64_t)GROUPS, k, G_out, Gf_out);
@@ -524,23 +527,23 @@ int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows
     s.partial_bytes = bytes;
   }
   hipLaunchKernelGGL((gramian_partial_kernel<T>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, h->stream, M, n_rows, k,
-                     rows_per_wave, s.partials);
+                     rows_per_wave, s.partials, ymax);
   hipLaunchKernelGGL((gramian_finalize_kernel<T, true>), dim3(elems / 64), dim3(256), 0, h->stream, s.partials, n_waves,
                      k, G_out, Gf_out);
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
 }
 
-int launch_gramian(mals_handle h, SideState& s, const float* M, int64_t n_rows, double* G_out, float* Gf_out) {
+int launch_gramian(mals_handle h, SideState& s, const float* M, int64_t n_rows, double* G_out, float* Gf_out, unsigned* ymax = nullptr) {
   switch (h->T) {
-    case 1: return launch_gramian_T<1>(h, s, M, n_rows, G_out, Gf_out);
-    case 2: return launch_gramian_T<2>(h, s, M, n_rows, G_out, Gf_out);
-    case 3: return launch_gramian_T<3>(h, s, M, n_rows, G_out, Gf_out);
-    case 4: return launch_gramian_T<4>(h, s, M, n_rows, G_out, Gf_out);
-    case 5: return launch_gramian_T<5>(h, s, M, n_rows, G_out, Gf_out);
-    case 6: return launch_gramian_T<6>(h, s, M, n_rows, G_out, Gf_out);
-    case 7: return launch_gramian_T<7>(h, s, M, n_rows, G_out, Gf_out);
-    case 8: return launch_gramian_T<8>(h, s, M, n_rows, G_out, Gf_out);
+    case 1: return launch_gramian_T<1>(h, s, M, n_rows, G_out, Gf_out, ymax);
+    case 2: return launch_gramian_T<2>(h, s, M, n_rows, G_out, Gf_out, ymax);
+    case 3: return launch_gramian_T<3>(h, s, M, n_rows, G_out, Gf_out, ymax);
+    case 4: return launch_gramian_T<4>(h, s, M, n_rows, G_out, Gf_out, ymax);
+    case 5: return launch_gramian_T<5>(h, s, M, n_rows, G_out, Gf_out, ymax);
+    case 6: return launch_gramian_T<6>(h, s, M, n_rows, G_out, Gf_out, ymax);
+    case 7: return launch_gramian_T<7>(h, s, M, n_rows, G_out, Gf_out, ymax);
+    case 8: return launch_gramian_T<8>(h, s, M, n_rows, G_out, Gf_out, ymax);
   }
   return fail(h, MALS_INVALID_ARG, "unsupported feature count");
 }
@@ -1070,6 +1073,7 @@ int ensure_gramian_buffers(mals_handle h, SideState& s) {
   const int k = h->cfg.features;
   if (!s.G) HIPCHK(h, hipMalloc(&s.G, sizeof(double) * (size_t)k * k));
   if (!s.Gf) HIPCHK(h, hipMalloc(&s.Gf, sizeof(float) * (size_t)tri(h->T) * 256));
+  if (!s.d_ymax) HIPCHK(h, hipMalloc(&s.d_ymax, sizeof(unsigned)));
   return MALS_OK;
 }
 
@@ -1444,6 +1448,7 @@ int mals_destroy(mals_handle h) {
     if (s.F_owned) free_dev(s.F);
     free_dev(s.G);
     free_dev(s.Gf);
+    free_dev(s.d_ymax);
     free_dev(s.partials);
   }
   free_dev(h->d_bad);
@@ -1746,11 +1751,13 @@ int mals_gramian(mals_handle h, int side, double* host_G) {
   if (int rc = use_device(h)) return rc;
   if (int rc = ensure_gramian_buffers(h, s)) return rc;
   PendingEvent pe;
+  HIPCHK(h, hipMemsetAsync(s.d_ymax, 0, sizeof(unsigned), h->stream));
   if (int rc = begin_timed(h, 3, (double)s.n_total * 4.0 * h->cfg.features, pe)) return rc;
-  if (int rc = launch_gramian(h, s, s.F, s.n_total, s.G, s.Gf)) return rc;
+  if (int rc = launch_gramian(h, s, s.F, s.n_total, s.G, s.Gf, s.d_ymax)) return rc;
   if (int rc = end_timed(h, pe)) return rc;
   s.G_valid = true;
   ++s.G_version;
+  s.ymax_version = s.G_version;   // every element of the replica went through the kernel: its maximum is exact
   if (host_G) {
     const int k = h->cfg.features;
     HIPCHK(h, hipMemcpyAsync(host_G, s.G, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, h->stream));
@@ -1759,7 +1766,7 @@ int mals_gramian(mals_handle h, int side, double* host_G) {
   return MALS_OK;
 }
 
-int mals_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_rows, double* device_out) {
+int malsi_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_rows, double* device_out, unsigned* device_max) {
   CHECK_SIDE(h, side);
   SideState& s = h->side[side];
   if (!s.F) return fail(h, MALS_INVALID_ARG, "factor replica not allocated");
@@ -1768,11 +1775,17 @@ int mals_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_r
   if (int rc = use_device(h)) return rc;
   PendingEvent pe;
   if (int rc = begin_timed(h, 3, (double)n_rows * 4.0 * h->cfg.features, pe)) return rc;
-  if (int rc = launch_gramian(h, s, s.F + row_begin * h->cfg.features, n_rows, device_out, nullptr)) return rc;
+  if (int rc = launch_gramian(h, s, s.F + row_begin * h->cfg.features, n_rows, device_out, nullptr, device_max)) return rc;
   return end_timed(h, pe);
 }
 
-int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) {
+int mals_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_rows, double* device_out) {
+  return malsi_gramian_partial(h, side, row_begin, n_rows, device_out, nullptr);
+}
+
+// device_max: device scalar holding the bit pattern of max |element| over ALL rows the installed G was formed from (the
+// group's all-reduced maximum of the members' malsi_gramian_partial maxima), or NULL when the caller has none
+int malsi_set_gramian(mals_handle h, int side, const double* G, int mem_kind, const unsigned* device_max) {
   CHECK_SIDE(h, side);
   if (!G) return fail(h, MALS_INVALID_ARG, "null Gramian");
   SideState& s = h->side[side];
@@ -1783,11 +1796,15 @@ int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) {
                            mem_kind == MALS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(gramian_pack_kernel, dim3((unsigned)tri(h->T)), dim3(256), 0, h->stream, s.G, k, h->T, s.Gf);
   HIPCHK(h, hipGetLastError());
+  if (device_max) HIPCHK(h, hipMemcpyAsync(s.d_ymax, device_max, sizeof(unsigned), hipMemcpyDeviceToDevice, h->stream));
   if (mem_kind != MALS_MEM_DEVICE) HIPCHK(h, hipStreamSynchronize(h->stream));
   s.G_valid = true;
   ++s.G_version;
+  s.ymax_version = device_max ? s.G_version : 0;
   return MALS_OK;
 }
+
+int mals_set_gramian(mals_handle h, int side, const double* G, int mem_kind) { return malsi_set_gramian(h, side, G, mem_kind, nullptr); }
 
 // fork: the side streams start behind everything enqueued on the main stream so far; join: the main stream continues
 // behind whatever was put on them.  A scope swaps h->stream so that every launch helper (and its timing events) lands
@@ -1945,7 +1962,7 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
     int force = -1;  // MALS_FORCE_RANGE_FLAG=0/1 (tests): override the range decision
     if (const char* e = std::getenv("MALS_FORCE_RANGE_FLAG")) force = std::atoi(e) != 0;
     hipLaunchKernelGGL(gather_scale_kernel, dim3(1), dim3(64), 0, h->stream, o.G, k, (float)std::sqrt(w_max), (float)std::sqrt(w_mean),
-                       (double)o.n_total, force, h->d_zscale);
+                       (double)o.n_total, force, (o.ymax_version != 0 && o.ymax_version == o.G_version) ? o.d_ymax : nullptr, h->d_zscale);
     HIPCHK(h, hipGetLastError());
     h->zs_side = side;
     h->zs_version = o.G_version;
@@ -2076,6 +2093,14 @@ int malsi_dual_host(mals_handle h, int side, mals_handle from) {
   if (!h->dual_pending || h->dual_pending_side != side) return fail(h, MALS_INVALID_ARG, "no chunk is waiting for the eigendecomposition");
   if (int rc = use_device(h)) return rc;
   return prepare_dual_host(h, side, from);
+}
+
+int mals_get_gather_scale(mals_handle h, float* out4) {
+  if (!h || !out4) return MALS_INVALID_ARG;
+  if (int rc = use_device(h)) return rc;
+  HIPCHK(h, hipMemcpyAsync(out4, h->d_zscale, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MALS_OK;
 }
 
 int mals_get_timeline(mals_handle h, double* out4) {

@@ -115,6 +115,7 @@ struct Member {
   ncclComm_t nccl = nullptr;
   double* d_gp = nullptr;    // k*k: partial Gramian / all-reduce buffer
   double* d_stat = nullptr;  // 4 doubles: value statistics, status
+  float* d_ymax = nullptr;   // max |element| of the rows of this member's partial Gramian (bit pattern = non-negative float)
   float* F[2] = {nullptr, nullptr};
   int64_t* d_row_ptr[2] = {nullptr, nullptr};  // rebased row pointers of borrowed device matrices
   // chunked upload
@@ -200,6 +201,7 @@ int init_member(mals_group g, Member& mb, const mals_config& cfg, int device, in
   const size_t kk = (size_t)cfg.features * cfg.features;
   GHIP(g, hipMalloc(&mb.d_gp, sizeof(double) * kk));
   GHIP(g, hipMalloc(&mb.d_stat, sizeof(double) * 4));
+  GHIP(g, hipMalloc(&mb.d_ymax, sizeof(float)));
   if (int rc = mals_set_stream(mb.h, mb.compute)) return mfail(g, mb, rc);
   return MALS_OK;
 }
@@ -214,6 +216,7 @@ void destroy_member(Member& mb) {
     if (mb.d_row_ptr[sd]) (void)hipFree(mb.d_row_ptr[sd]);
   if (mb.d_gp) (void)hipFree(mb.d_gp);
   if (mb.d_stat) (void)hipFree(mb.d_stat);
+  if (mb.d_ymax) (void)hipFree(mb.d_ymax);
   if (mb.ev_solved) (void)hipEventDestroy(mb.ev_solved);
   if (mb.ev_exchanged) (void)hipEventDestroy(mb.ev_exchanged);
   if (mb.comm) (void)hipStreamDestroy(mb.comm);
@@ -378,8 +381,12 @@ int group_gramian(mals_group g, int side) {
     GHIP(g, hipSetDevice(mb.device));
     const int64_t r0 = std::min(g->n_total[side], per * mb.rank);
     const int64_t r1 = std::min(g->n_total[side], per * (mb.rank + 1));
+    // the kernels that form the partial Gramian also record the largest |element| of their rows: summed Gramian + the
+    // maximum over all ranks give every member the exact operand bound of the split-precision gather (instead of
+    // sqrt(max_f G_ff), which at 1e8 rows is 13 binades loose)
+    GHIP(g, hipMemsetAsync(mb.d_ymax, 0, sizeof(float), mb.compute));
     if (r1 > r0) {
-      if (int rc = mals_gramian_partial(mb.h, side, r0, r1 - r0, mb.d_gp)) return mfail(g, mb, rc);
+      if (int rc = malsi_gramian_partial(mb.h, side, r0, r1 - r0, mb.d_gp, reinterpret_cast<unsigned*>(mb.d_ymax))) return mfail(g, mb, rc);
     } else {
       GHIP(g, hipMemsetAsync(mb.d_gp, 0, sizeof(double) * kk, mb.compute));
     }
@@ -387,15 +394,19 @@ int group_gramian(mals_group g, int side) {
   if (g->world > 1 || g->m[0].nccl) {
     if (g->backend == MALS_GROUP_PEER_COPY) {  // fixed summation order (rank 0, 1, ...): deterministic
       std::vector<double> acc(kk, 0.0), tmp(kk);
+      float ymax = 0.f, ytmp = 0.f;
       for (Member& mb : g->m) {
         GHIP(g, hipSetDevice(mb.device));
         GHIP(g, hipMemcpyAsync(tmp.data(), mb.d_gp, sizeof(double) * kk, hipMemcpyDeviceToHost, mb.compute));
+        GHIP(g, hipMemcpyAsync(&ytmp, mb.d_ymax, sizeof(float), hipMemcpyDeviceToHost, mb.compute));
         GHIP(g, hipStreamSynchronize(mb.compute));
         for (size_t i = 0; i < kk; ++i) acc[i] += tmp[i];
+        if (!(ytmp <= ymax)) ymax = ytmp;   // a NaN / inf pattern wins and makes the consumer fall back
       }
       for (Member& mb : g->m) {
         GHIP(g, hipSetDevice(mb.device));
         GHIP(g, hipMemcpyAsync(mb.d_gp, acc.data(), sizeof(double) * kk, hipMemcpyHostToDevice, mb.compute));
+        GHIP(g, hipMemcpyAsync(mb.d_ymax, &ymax, sizeof(float), hipMemcpyHostToDevice, mb.compute));
         GHIP(g, hipStreamSynchronize(mb.compute));
       }
     } else {
@@ -407,7 +418,8 @@ int group_gramian(mals_group g, int side) {
       }
       GNCCL(g, g_rccl.GroupStart());
       for (Member& mb : g->m) {
-        const ncclResult_t r = g_rccl.AllReduce(mb.d_gp, mb.d_gp, kk, ncclDouble, ncclSum, mb.nccl, mb.comm);
+        ncclResult_t r = g_rccl.AllReduce(mb.d_gp, mb.d_gp, kk, ncclDouble, ncclSum, mb.nccl, mb.comm);
+        if (r == ncclSuccess) r = g_rccl.AllReduce(mb.d_ymax, mb.d_ymax, 1, ncclFloat, ncclMax, mb.nccl, mb.comm);
         if (r != ncclSuccess) {
           (void)g_rccl.GroupEnd();
           return gfail(g, MALS_COMM_ERROR, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
@@ -423,7 +435,7 @@ int group_gramian(mals_group g, int side) {
   }
   for (Member& mb : g->m) {
     GHIP(g, hipSetDevice(mb.device));
-    if (int rc = mals_set_gramian(mb.h, side, mb.d_gp, MALS_MEM_DEVICE)) return mfail(g, mb, rc);
+    if (int rc = malsi_set_gramian(mb.h, side, mb.d_gp, MALS_MEM_DEVICE, reinterpret_cast<const unsigned*>(mb.d_ymax))) return mfail(g, mb, rc);
   }
   return MALS_OK;
 }

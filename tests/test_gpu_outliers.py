@@ -199,16 +199,19 @@ def test_refinement_leaves_well_conditioned_problems_alone():
 
 
 def test_operand_range_check_switches_to_the_fp32_gather():
-    """One value 3e6 times the others over a 200K-row factor matrix stretches bound / typical operand
-    (sqrt(w_max / w_mean) * sqrt(max G_ff / mean y_f^2) ~ 2^17) past the 16 binades both f16 halves can
+    """One value 3e3 times the others AND one factor element 2e4 times the others over a 200K-row factor matrix stretch
+    bound / typical operand (sqrt(w_max / w_mean) * max |y| / rms |y| ~ 2^18) past the 16 binades both f16 halves can
     hold: the launch must run the fp32-gather kernels (bitwise the GRAMIAN_FP32 result), with no host
-    round trip (the split kernels return at once on the device-side flag)."""
+    round trip (the split kernels return at once on the device-side flag).  (Until round 3 the bound on |y| was
+    sqrt(max_f G_ff) and one value of 1e7 alone tripped the flag; with the exact maximum a single outlier VALUE cannot --
+    it drags the mean weight along --, see test_operand_bound_is_the_exact_maximum_not_the_gramian_diagonal.)"""
     k = 64
     lengths = np.random.default_rng(4).integers(40, 300, size=500)
     csr, M = rows_problem(lengths, 200000, k, seed=24)
     v = csr[2].copy()
-    v[7] = 1.0e7
+    v[7] = 1.0e4
     csr = (csr[0], csr[1], v)
+    M[123, 5] *= 2.0e4
     X_auto, _ = solve_x(k, csr, M, solve_mode=_lib.SOLVE_DIRECT)
     X_fp32, _ = solve_x(k, csr, M, solve_mode=_lib.SOLVE_DIRECT, gramian_mode=_lib.GRAMIAN_FP32)
     assert np.array_equal(X_auto, X_fp32)
@@ -233,3 +236,38 @@ def test_negative_alpha_runs_the_fp32_gather():
     X, _ = solve_x(k, csr, M, alpha=-0.001)
     Xo = oracle.half_iteration(*csr, M, alpha=-0.001, threads=2)
     assert rel(X, Xo) < REL_TOL
+
+
+def test_operand_bound_is_the_exact_maximum_not_the_gramian_diagonal():
+    """The split-precision gather scales its operands with a bound on |y|.  sqrt(max_f G_ff) is loose by sqrt(rows) --
+    10 binades at 1e6 rows, 13 at the 1e8 rows of C5's X -- and with heavy-tailed values (one play count of 20 000 among
+    1..5) that alone pushed the range flag over its 16 binades: the whole half-iteration fell back to the fp32 gather.
+    The Gramian kernels now record the exact max |element| (round 3): same data, split-precision kernels, same answer."""
+    k, n_items = 64, 1_200_000
+    lengths = np.random.default_rng(5).integers(49, 200, size=1500)        # direct rows (k = 64: dual up to 48 entries)
+    csr, M = rows_problem(lengths, n_items, k, seed=26, negatives=0.0)
+    v = csr[2].copy()
+    v[csr[0][3] + 1] = 2.0e4
+    csr = (csr[0], csr[1], v)
+    n_rows = len(lengths)
+    G = oracle.gramian(M)
+    Xo = oracle.solve_rows(*csr, M, G, threads=8)
+    with pkg.ALSCore(k, solve_mode=_lib.SOLVE_DIRECT) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_rows)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_matrix(pkg.SIDE_X, *csr)
+        core.set_factors(pkg.SIDE_Y, M)
+        core.half_iteration(pkg.SIDE_X)              # G by this library's kernels: exact bound
+        S, _, flag, bound = core.gather_scale()
+        X = core.get_factors(pkg.SIDE_X)
+        assert flag == 1.0, "the split-precision kernels must run"
+        assert abs(bound - float(np.abs(M).max())) <= 1e-6 * bound
+        assert rel(X, Xo) < REL_TOL, rel(X, Xo)
+        # the same Gramian handed in from outside: no maximum came with it -> the diagonal's bound, which trips the flag
+        core.set_gramian(pkg.SIDE_Y, G)
+        core.solve_side(pkg.SIDE_X)
+        core.check()
+        S2, _, flag2, bound2 = core.gather_scale()
+        X2 = core.get_factors(pkg.SIDE_X)
+        assert bound2 > 100.0 * bound and S2 < S and flag2 == 0.0
+        assert rel(X2, Xo) < REL_TOL, rel(X2, Xo)     # the fp32 twins: correct as well, just slower
