@@ -43,6 +43,8 @@ __host__ __device__ constexpr int tri(int T) { return T * (T + 1) / 2; }
 // index of upper tile (i <= j), row-major over the upper triangle
 __host__ __device__ constexpr int tidx(int T, int i, int j) { return i * T - (i * (i - 1)) / 2 + (j - i); }
 
+constexpr int YMAX_SLOTS = 64;  // addresses the Gramian kernels spread their max |element| atomics over (power of two)
+
 struct WorkItem {   // one row (list A) or one segment of a long row (list B); 16 bytes, s_load_dwordx4
   int64_t begin;    // absolute offset into col/val
   int32_t len;      // entries
@@ -1568,8 +1570,7 @@ __global__ __launch_bounds__(256) void als_exact_kernel(RefineParams q, int leve
 // MU:232; the exact fp64 product used here differs from that by < 2^-24 relative per term.)
 template <int T>
 __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __restrict__ M, int64_t n_rows, int k,
-                                                              int64_t rows_per_wave, double* __restrict__ partial,
-                                                              unsigned* __restrict__ ymax) {
+                                                              int64_t rows_per_wave, double* __restrict__ partial) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t r0 = wave * rows_per_wave;
@@ -1578,7 +1579,6 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
   f64x4 acc[tri(T)];
 #pragma unroll
   for (int t = 0; t < tri(T); ++t) acc[t] = f64x4{0., 0., 0., 0.};
-  float am = 0.f;  // largest |element| this lane has seen: the exact bound of the split-precision gather's operand scale
   for (int64_t r = r0; r < r1; r += 4) {
     const int64_t row = r + g;
     const bool ok = row < r1;
@@ -1589,7 +1589,6 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
       const int f = 16 * v + c;
       const float x = p[f < k ? f : k - 1];
       y[v] = (ok && f < k) ? (double)x : 0.0;
-      am = fmaxf(am, (ok && f < k) ? fabsf(x) : 0.f);
     }
 #pragma unroll
     for (int i = 0; i < T; ++i)
@@ -1602,12 +1601,6 @@ __global__ __launch_bounds__(256) void gramian_partial_kernel(const float* __res
   for (int t = 0; t < tri(T); ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[(t * 4 + r) * 64] = acc[t][r];
-  if (ymax) {
-    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off));
-    // same-address atomics serialise: only a wave that raises the maximum issues one; NaN / inf order above every finite
-    // bit pattern and are kept (the consumer then falls back to the Gramian's diagonal)
-    if (lane == 0 && __float_as_uint(am) > __builtin_nontemporal_load(ymax)) atomicMax(ymax, __float_as_uint(am));
-  }
 }
 
 // 64 (tile, reg, lane) elements per workgroup: each of the 4 waves sums a contiguous quarter of the
@@ -1834,7 +1827,12 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
   for (int t = 0; t < tri(T); ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[(t * 4 + r) * 64] = acc[t][r] * back;
-  if (ymax && lane == 0 && (unsigned)slab_max > __builtin_nontemporal_load(ymax)) atomicMax(ymax, (unsigned)slab_max);
+  if (ymax && lane == 0) {
+    unsigned* slot = ymax + (slab & (YMAX_SLOTS - 1));
+    // same-address atomics serialise (~0.1 us each, and the waves of a launch finish together): YMAX_SLOTS addresses,
+    // the consumer takes their maximum
+    if ((unsigned)slab_max > __builtin_nontemporal_load(slot)) atomicMax(slot, (unsigned)slab_max);
+  }
 }
 
 // G (k x k fp64 row-major) -> fp32 acc-layout image used by K2 (see gramian_finalize_kernel)
@@ -1854,9 +1852,10 @@ __global__ void gramian_pack_kernel(const double* __restrict__ G, int k, int T, 
 
 // Split-precision gather: S = 2^p with  max|z| = sqrt(w_max) * S * max|y| <= 2^14.  max|y| is
 // bounded by sqrt(max_f G_ff) (G = M^T M of the gathered factor matrix, always at hand) -- loose by up to
-// sqrt(n_rows): 13 binades of the 16 the range flag allows at the 1e8 rows of C5's X -- or, when the Gramian
-// kernels of this library made G (they read every element anyway), by the exact max |y| they recorded (ymax;
-// round 3).  w_max = the largest |value| of the matrix side (max_abs_kernel at upload).
+// sqrt(n_rows): 13 binades of the 16 the range flag allows at the 1e8 rows of C5's X -- or, when the split-f16
+// Gramian kernel of this library made G (>= 262144 rows, where the looseness matters; it computes every step's
+// max |element| for its own scaling anyway), by the exact max |y| it recorded (ymax; round 3; a word above 3e38 =
+// "some part of G was formed without one": diagonal bound).  w_max = the largest |value| of the matrix side (max_abs_kernel at upload).
 // out = {S, 1/S^2, range flag, bound on |y| used}.
 // Range flag: a typical operand, sqrt(w_mean) * rms|y_f| (rms over the n_rows rows that make up G), sits
 // log2(bound / typical) binades below the bound; both f16 halves of z keep all their bits while
@@ -1873,7 +1872,9 @@ __global__ void gather_scale_kernel(const double* __restrict__ G, int k, float s
   }
   double ybound = sqrt(d);
   if (ymax) {
-    const float ym = __uint_as_float(*ymax);
+    unsigned bits = 0;
+    for (int i = 0; i < YMAX_SLOTS; ++i) bits = max(bits, ymax[i]);
+    const float ym = __uint_as_float(bits);
     if (ym > 0.f && ym < 3.0e38f && (double)ym < ybound) ybound = (double)ym;   // non-finite: keep the diagonal's verdict
   }
   out[3] = (float)ybound;

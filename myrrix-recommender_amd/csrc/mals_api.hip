@@ -526,8 +526,11 @@ int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows
     HIPCHK(h, hipMalloc(&s.partials, bytes));
     s.partial_bytes = bytes;
   }
+  // the fp64 kernel (small matrices: the diagonal's bound is at most 9 binades loose there) records no maximum; tracking
+  // it cost the latency-bound kernel 20-40 % (measured on C2).  "Unknown" = a word above 3e38 that survives every max.
+  if (ymax) HIPCHK(h, hipMemsetAsync(ymax, 0x7f, sizeof(unsigned), h->stream));
   hipLaunchKernelGGL((gramian_partial_kernel<T>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, h->stream, M, n_rows, k,
-                     rows_per_wave, s.partials, ymax);
+                     rows_per_wave, s.partials);
   hipLaunchKernelGGL((gramian_finalize_kernel<T, true>), dim3(elems / 64), dim3(256), 0, h->stream, s.partials, n_waves,
                      k, G_out, Gf_out);
   HIPCHK(h, hipGetLastError());
@@ -1073,7 +1076,7 @@ int ensure_gramian_buffers(mals_handle h, SideState& s) {
   const int k = h->cfg.features;
   if (!s.G) HIPCHK(h, hipMalloc(&s.G, sizeof(double) * (size_t)k * k));
   if (!s.Gf) HIPCHK(h, hipMalloc(&s.Gf, sizeof(float) * (size_t)tri(h->T) * 256));
-  if (!s.d_ymax) HIPCHK(h, hipMalloc(&s.d_ymax, sizeof(unsigned)));
+  if (!s.d_ymax) HIPCHK(h, hipMalloc(&s.d_ymax, sizeof(unsigned) * YMAX_SLOTS));
   return MALS_OK;
 }
 
@@ -1751,7 +1754,7 @@ int mals_gramian(mals_handle h, int side, double* host_G) {
   if (int rc = use_device(h)) return rc;
   if (int rc = ensure_gramian_buffers(h, s)) return rc;
   PendingEvent pe;
-  HIPCHK(h, hipMemsetAsync(s.d_ymax, 0, sizeof(unsigned), h->stream));
+  HIPCHK(h, hipMemsetAsync(s.d_ymax, 0, sizeof(unsigned) * YMAX_SLOTS, h->stream));
   if (int rc = begin_timed(h, 3, (double)s.n_total * 4.0 * h->cfg.features, pe)) return rc;
   if (int rc = launch_gramian(h, s, s.F, s.n_total, s.G, s.Gf, s.d_ymax)) return rc;
   if (int rc = end_timed(h, pe)) return rc;
@@ -1783,7 +1786,7 @@ int mals_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_r
   return malsi_gramian_partial(h, side, row_begin, n_rows, device_out, nullptr);
 }
 
-// device_max: device scalar holding the bit pattern of max |element| over ALL rows the installed G was formed from (the
+// device_max: YMAX_SLOTS device words (malsi_ymax_slots()) whose maximum is the bit pattern of max |element| over ALL rows the installed G was formed from (the
 // group's all-reduced maximum of the members' malsi_gramian_partial maxima), or NULL when the caller has none
 int malsi_set_gramian(mals_handle h, int side, const double* G, int mem_kind, const unsigned* device_max) {
   CHECK_SIDE(h, side);
@@ -1796,7 +1799,7 @@ int malsi_set_gramian(mals_handle h, int side, const double* G, int mem_kind, co
                            mem_kind == MALS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(gramian_pack_kernel, dim3((unsigned)tri(h->T)), dim3(256), 0, h->stream, s.G, k, h->T, s.Gf);
   HIPCHK(h, hipGetLastError());
-  if (device_max) HIPCHK(h, hipMemcpyAsync(s.d_ymax, device_max, sizeof(unsigned), hipMemcpyDeviceToDevice, h->stream));
+  if (device_max) HIPCHK(h, hipMemcpyAsync(s.d_ymax, device_max, sizeof(unsigned) * YMAX_SLOTS, hipMemcpyDeviceToDevice, h->stream));
   if (mem_kind != MALS_MEM_DEVICE) HIPCHK(h, hipStreamSynchronize(h->stream));
   s.G_valid = true;
   ++s.G_version;
@@ -2088,6 +2091,7 @@ int malsi_solve_chunk_end(mals_handle h, int side, int32_t chunk) {
   return solve_chunks(h, side, chunk, chunk + 1, SOLVE_END);
 }
 int malsi_dual_pending(mals_handle h) { return h && h->dual_pending ? 1 : 0; }
+int malsi_ymax_slots(void) { return YMAX_SLOTS; }
 int malsi_dual_host(mals_handle h, int side, mals_handle from) {
   CHECK_SIDE(h, side);
   if (!h->dual_pending || h->dual_pending_side != side) return fail(h, MALS_INVALID_ARG, "no chunk is waiting for the eigendecomposition");

@@ -201,7 +201,7 @@ int init_member(mals_group g, Member& mb, const mals_config& cfg, int device, in
   const size_t kk = (size_t)cfg.features * cfg.features;
   GHIP(g, hipMalloc(&mb.d_gp, sizeof(double) * kk));
   GHIP(g, hipMalloc(&mb.d_stat, sizeof(double) * 4));
-  GHIP(g, hipMalloc(&mb.d_ymax, sizeof(float)));
+  GHIP(g, hipMalloc(&mb.d_ymax, sizeof(float) * (size_t)malsi_ymax_slots()));
   if (int rc = mals_set_stream(mb.h, mb.compute)) return mfail(g, mb, rc);
   return MALS_OK;
 }
@@ -384,7 +384,7 @@ int group_gramian(mals_group g, int side) {
     // the kernels that form the partial Gramian also record the largest |element| of their rows: summed Gramian + the
     // maximum over all ranks give every member the exact operand bound of the split-precision gather (instead of
     // sqrt(max_f G_ff), which at 1e8 rows is 13 binades loose)
-    GHIP(g, hipMemsetAsync(mb.d_ymax, 0, sizeof(float), mb.compute));
+    GHIP(g, hipMemsetAsync(mb.d_ymax, 0, sizeof(float) * (size_t)malsi_ymax_slots(), mb.compute));
     if (r1 > r0) {
       if (int rc = malsi_gramian_partial(mb.h, side, r0, r1 - r0, mb.d_gp, reinterpret_cast<unsigned*>(mb.d_ymax))) return mfail(g, mb, rc);
     } else {
@@ -394,19 +394,21 @@ int group_gramian(mals_group g, int side) {
   if (g->world > 1 || g->m[0].nccl) {
     if (g->backend == MALS_GROUP_PEER_COPY) {  // fixed summation order (rank 0, 1, ...): deterministic
       std::vector<double> acc(kk, 0.0), tmp(kk);
-      float ymax = 0.f, ytmp = 0.f;
+      const size_t ns = (size_t)malsi_ymax_slots();
+      std::vector<float> ymax(ns, 0.f), ytmp(ns, 0.f);
       for (Member& mb : g->m) {
         GHIP(g, hipSetDevice(mb.device));
         GHIP(g, hipMemcpyAsync(tmp.data(), mb.d_gp, sizeof(double) * kk, hipMemcpyDeviceToHost, mb.compute));
-        GHIP(g, hipMemcpyAsync(&ytmp, mb.d_ymax, sizeof(float), hipMemcpyDeviceToHost, mb.compute));
+        GHIP(g, hipMemcpyAsync(ytmp.data(), mb.d_ymax, sizeof(float) * ns, hipMemcpyDeviceToHost, mb.compute));
         GHIP(g, hipStreamSynchronize(mb.compute));
         for (size_t i = 0; i < kk; ++i) acc[i] += tmp[i];
-        if (!(ytmp <= ymax)) ymax = ytmp;   // a NaN / inf pattern wins and makes the consumer fall back
+        for (size_t i = 0; i < ns; ++i)
+          if (!(ytmp[i] <= ymax[i])) ymax[i] = ytmp[i];   // an inf pattern wins and makes the consumer fall back
       }
       for (Member& mb : g->m) {
         GHIP(g, hipSetDevice(mb.device));
         GHIP(g, hipMemcpyAsync(mb.d_gp, acc.data(), sizeof(double) * kk, hipMemcpyHostToDevice, mb.compute));
-        GHIP(g, hipMemcpyAsync(mb.d_ymax, &ymax, sizeof(float), hipMemcpyHostToDevice, mb.compute));
+        GHIP(g, hipMemcpyAsync(mb.d_ymax, ymax.data(), sizeof(float) * ns, hipMemcpyHostToDevice, mb.compute));
         GHIP(g, hipStreamSynchronize(mb.compute));
       }
     } else {
@@ -419,7 +421,7 @@ int group_gramian(mals_group g, int side) {
       GNCCL(g, g_rccl.GroupStart());
       for (Member& mb : g->m) {
         ncclResult_t r = g_rccl.AllReduce(mb.d_gp, mb.d_gp, kk, ncclDouble, ncclSum, mb.nccl, mb.comm);
-        if (r == ncclSuccess) r = g_rccl.AllReduce(mb.d_ymax, mb.d_ymax, 1, ncclFloat, ncclMax, mb.nccl, mb.comm);
+        if (r == ncclSuccess) r = g_rccl.AllReduce(mb.d_ymax, mb.d_ymax, (size_t)malsi_ymax_slots(), ncclFloat, ncclMax, mb.nccl, mb.comm);
         if (r != ncclSuccess) {
           (void)g_rccl.GroupEnd();
           return gfail(g, MALS_COMM_ERROR, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));

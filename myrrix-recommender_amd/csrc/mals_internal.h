@@ -14,9 +14,11 @@ __attribute__((visibility("hidden"))) int malsi_solve_chunk_end(mals_handle h, i
 __attribute__((visibility("hidden"))) int malsi_dual_pending(mals_handle h);
 __attribute__((visibility("hidden"))) int malsi_dual_host(mals_handle h, int side, mals_handle from);
 // mals_gramian_partial / mals_set_gramian with the exact bound on |y| of the split-precision gather: the partial Gramian
-// kernels also record max |element| of their rows (device_max: caller-zeroed device scalar, bit pattern of a float >= 0);
+// kernels also record max |element| of their rows (device_max: malsi_ymax_slots() caller-zeroed device words, bit patterns
+// of floats >= 0, spread over several addresses because same-address atomics serialise; the maximum is what counts);
 // the group all-reduces the members' maxima and installs the result with the summed Gramian.
 __attribute__((visibility("hidden"))) int malsi_gramian_partial(mals_handle h, int side, int64_t row_begin, int64_t n_rows, double* device_out,
                                                               unsigned* device_max);
+__attribute__((visibility("hidden"))) int malsi_ymax_slots(void);
 __attribute__((visibility("hidden"))) int malsi_set_gramian(mals_handle h, int side, const double* G, int mem_kind, const unsigned* device_max);
 }

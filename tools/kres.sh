@@ -17,6 +17,6 @@ for ln in sys.stdin:
         k,v=t.split(":",1); cur[k.strip()]=v.strip()
 for r in rows:
     n=subprocess.run(["c++filt",r["name"]],capture_output=True,text=True).stdout.strip()
-    if "persistent" in n or "dual" in n or "finish" in n or "wide" in n or "gramian_s" in n or "refine" in n:
+    if "persistent" in n or "dual" in n or "finish" in n or "wide" in n or "gramian_" in n or "refine" in n:
         print("%-70s vgpr %4s agpr %3s vspill %4s scratch %5s occ %s lds %s" % (n[:70], r.get("VGPRs"), r.get("AGPRs"), r.get("VGPRs Spill"), r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
 '
