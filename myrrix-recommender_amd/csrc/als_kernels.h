@@ -1827,11 +1827,17 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
   for (int t = 0; t < tri(T); ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[(t * 4 + r) * 64] = acc[t][r] * back;
-  if (ymax && lane == 0) {
-    unsigned* slot = ymax + (slab & (YMAX_SLOTS - 1));
-    // same-address atomics serialise (~0.1 us each, and the waves of a launch finish together): YMAX_SLOTS addresses,
-    // the consumer takes their maximum
-    if ((unsigned)slab_max > __builtin_nontemporal_load(slot)) atomicMax(slot, (unsigned)slab_max);
+  if (ymax) {  // wave-uniform
+    // one atomic per workgroup, spread over YMAX_SLOTS addresses: same-address atomics serialise (~0.1 us each) and the
+    // waves of a launch finish together; the consumer takes the maximum of the slots
+    __shared__ int s_max[4];
+    if (lane == 0) s_max[threadIdx.x >> 6] = slab_max;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned m4 = (unsigned)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+      unsigned* slot = ymax + (blockIdx.x & (YMAX_SLOTS - 1));
+      if (m4 > __builtin_nontemporal_load(slot)) atomicMax(slot, m4);
+    }
   }
 }
 
