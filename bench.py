@@ -33,6 +33,10 @@ WORKLOADS = {
     # against the 100M x 128 X (51.2 GB).  (users, items) below = the rows this rank solves per iteration.
     "c5rank": (12_500_000, 1_250_000, 1_250_000_000, 128, "one rank of C5 at 8 GPUs, both slices at true shape: 12.5M user rows x 10M items (625M entries) "
                "+ 1.25M item rows x 100M users (625M entries) gathering from the full 100M x 128 X replica (51.2 GB), k=128"),
+    # the same for C4 (the headline configuration at 8 GPUs): 1.25M user rows against the 1M x 64 Y, 125K item rows (~1000 entries
+    # each) against the full 10M x 64 X -- what one rank computes per iteration when the exchange is free
+    "c4rank": (1_250_000, 125_000, 250_000_000, 64, "one rank of C4 at 8 GPUs, both slices at true shape: 1.25M user rows x 1M items (125M entries) "
+               "+ 125K item rows x 10M users (125M entries) gathering from the full 10M x 64 X replica (2.56 GB), k=64"),
     "k128long": (1_000_000, 100_000, 400_000_000, 128, "k=128 with long rows (1M x 100K, 400M interactions requested)"),
     "k112": (2_000_000, 200_000, 200_000_000, 112, "k=112 (2M x 200K, 200M interactions requested)"),
     "k30": (10_000_000, 1_000_000, 1_000_000_000, 30, "the reference's default feature count on the C4 shape (10M x 1M, 1e9 interactions requested, k=30)"),
@@ -312,9 +316,9 @@ def main():
     red_device = torch.device("cpu") if one_device else device   # where the few scalars of this script are reduced
 
     n_users, n_items, nnz_req, k, desc = WORKLOADS[args.workload]
-    rank_shape = args.workload == "c5rank"
+    rank_shape = args.workload in ("c5rank", "c4rank")
     if rank_shape:
-        assert world == 1 and not force, "c5rank emulates ONE rank of an 8-GPU group on one GPU"
+        assert world == 1 and not force, "c5rank / c4rank emulate ONE rank of an 8-GPU group on one GPU"
     t_gen = time.perf_counter()
     if rank_shape:
         prob = rank_problem(torch, synth, n_users, n_items, nnz_req // 2, k, device, world_emulated=8, planted=args.planted)
