@@ -229,3 +229,36 @@ def test_auto_mode_skips_the_rotation_when_few_rows_would_use_it():
     assert std["rows_dual"] == 100
     Xo = oracle.half_iteration(*csr, M, threads=4)
     assert rel(Xa, Xo) < REL_TOL and rel(Xd, Xo) < REL_TOL
+
+
+@pytest.mark.parametrize("k", [50, 64, 128])
+def test_three_stream_overlap_gives_the_same_bits(k):
+    """MALS_OVERLAP=1 (off by default) enqueues a chunk's rows list, long rows and dual lists on
+    three streams between a fork and a join event: the kernels and their inputs are the same, so are the factors -- bit
+    for bit -- over two chained half-iterations with chunking, long rows (segments + finish) and dual rows."""
+    import os
+    from myrrix_recommender_amd import synth
+    n_users, n_items = 3000, 900
+    r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 60000, k, seed=77, negatives=0.05)
+    res = []
+    for overlap in ("0", "1"):
+        os.environ["MALS_OVERLAP"] = overlap
+        try:
+            with pkg.ALSCore(k, segment_nnz=64, chunk_rows=700) as core:
+                core.set_factor_rows(pkg.SIDE_X, n_users)
+                core.set_factor_rows(pkg.SIDE_Y, n_items)
+                core.set_matrix(pkg.SIDE_X, *r_csr)
+                core.set_matrix(pkg.SIDE_Y, *c_csr)
+                core.set_factors(pkg.SIDE_Y, Y0)
+                core.reset_stats()
+                core.half_iteration(pkg.SIDE_X)
+                core.half_iteration(pkg.SIDE_Y)
+                st = core.stats()
+                res.append((core.get_factors(pkg.SIDE_X), core.get_factors(pkg.SIDE_Y)))
+        finally:
+            del os.environ["MALS_OVERLAP"]
+        assert st["rows_solved"] == n_users + n_items and st["rows_dual"] > 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    Xo = oracle.half_iteration(*r_csr, Y0, threads=4)
+    Yo = oracle.half_iteration(*c_csr, Xo, threads=4)
+    assert rel(res[1][0], Xo) < 1e-4 and rel(res[1][1], Yo) < 1e-4
