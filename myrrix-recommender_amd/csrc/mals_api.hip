@@ -1754,13 +1754,16 @@ int mals_gramian(mals_handle h, int side, double* host_G) {
   if (int rc = use_device(h)) return rc;
   if (int rc = ensure_gramian_buffers(h, s)) return rc;
   PendingEvent pe;
-  HIPCHK(h, hipMemsetAsync(s.d_ymax, 0, sizeof(unsigned) * YMAX_SLOTS, h->stream));
+  // only the split-f16 kernel (large matrices) records the maximum; below its threshold not even the two memsets are
+  // spent (C2 is 50 launches of a few microseconds each)
+  const bool with_max = s.n_total >= GRAMIAN_SPLIT_MIN_ROWS;
+  if (with_max) HIPCHK(h, hipMemsetAsync(s.d_ymax, 0, sizeof(unsigned) * YMAX_SLOTS, h->stream));
   if (int rc = begin_timed(h, 3, (double)s.n_total * 4.0 * h->cfg.features, pe)) return rc;
-  if (int rc = launch_gramian(h, s, s.F, s.n_total, s.G, s.Gf, s.d_ymax)) return rc;
+  if (int rc = launch_gramian(h, s, s.F, s.n_total, s.G, s.Gf, with_max ? s.d_ymax : nullptr)) return rc;
   if (int rc = end_timed(h, pe)) return rc;
   s.G_valid = true;
   ++s.G_version;
-  s.ymax_version = s.G_version;   // every element of the replica went through the kernel: its maximum is exact
+  s.ymax_version = with_max ? s.G_version : 0;   // every element of the replica went through the kernel: its maximum is exact
   if (host_G) {
     const int k = h->cfg.features;
     HIPCHK(h, hipMemcpyAsync(host_G, s.G, sizeof(double) * (size_t)k * k, hipMemcpyDeviceToHost, h->stream));
