@@ -339,6 +339,20 @@ int build_work_lists(mals_handle h, SideState& s) {
         cr.nnzB += len;
       }
     }
+    // How the long rows (more than segment_nnz entries) are cut: segments of up to segment_nnz entries when that gives
+    // at least one per SIMD, shorter ones otherwise -- a wave takes ~20 ns per entry, and the user half of C2 (a handful
+    // of rows above 4 096 entries) ran FOUR waves for 80 us on the critical path (round 3: 80 -> 22 us).  Each segment
+    // costs a partial slot, written and read back one after the other by the finish kernel's one wave per row: with
+    // six times the segments on C2's item half the finish kernel went from 23 to 70 us and ate the gain -- hence only
+    // for lists that cannot even give every SIMD a segment, and never below 512 entries.
+    int64_t seg_b = seg;
+    {
+      const int64_t want_segments = (int64_t)h->n_cu * 4;
+      const int64_t lo = std::min<int64_t>(512, seg);
+      seg_b = std::max<int64_t>(lo, std::min<int64_t>(seg, (cr.nnzB + want_segments - 1) / want_segments));
+      seg_b = (seg_b + 31) & ~(int64_t)31;                   // whole 32-entry super-steps
+      if (seg_b > seg) seg_b = seg;
+    }
     int64_t acc = cr.offA;
     for (size_t b = 0; b < count.size(); ++b) {
       const int64_t cnt = count[b];
@@ -354,7 +368,7 @@ int build_work_lists(mals_handle h, SideState& s) {
         w.len = (int32_t)len;
         w.id = (int32_t)r;
       } else {
-        const int64_t nseg = (len + seg - 1) / seg;
+        const int64_t nseg = (len + seg_b - 1) / seg_b;
         int64_t per = (len + nseg - 1) / nseg;
         per = (per + 3) & ~(int64_t)3;  // whole 4-entry steps
         RowC rc;
