@@ -1870,16 +1870,26 @@ __global__ void gramian_pack_kernel(const double* __restrict__ G, int k, int T, 
 // the fp32-gather kernels enqueued behind them do the work (no host round trip).
 __global__ void gather_scale_kernel(const double* __restrict__ G, int k, float sqrt_w_max, float sqrt_w_mean, double n_rows,
                                     int force_flag, const unsigned* __restrict__ ymax, float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: the lanes fetch the diagonal (and the maximum's slots) side by side -- a single thread walking k dependent
+  // loads took 13 us on the critical path of every half-iteration
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
   double d = 0.0, tr = 0.0;
-  for (int f = 0; f < k; ++f) {
-    d = fmax(d, G[(int64_t)f * k + f]);
-    tr += G[(int64_t)f * k + f];
+  for (int f = lane; f < k; f += 64) {
+    const double g = G[(int64_t)f * k + f];
+    d = fmax(d, g);
+    tr += g;
   }
+  unsigned bits = (ymax && lane < YMAX_SLOTS) ? ymax[lane] : 0u;
+  static_assert(YMAX_SLOTS <= 64, "one slot per lane");
+  for (int off = 32; off > 0; off >>= 1) {
+    d = fmax(d, __shfl_xor(d, off));
+    tr += __shfl_xor(tr, off);
+    bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
+  }
+  if (lane != 0) return;
   double ybound = sqrt(d);
   if (ymax) {
-    unsigned bits = 0;
-    for (int i = 0; i < YMAX_SLOTS; ++i) bits = max(bits, ymax[i]);
     const float ym = __uint_as_float(bits);
     if (ym > 0.f && ym < 3.0e38f && (double)ym < ybound) ybound = (double)ym;   // non-finite: keep the diagonal's verdict
   }
