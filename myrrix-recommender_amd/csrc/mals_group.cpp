@@ -373,7 +373,17 @@ int exchange_chunk(mals_group g, int side, int c) {
 // replica is complete when this runs (the caller has waited for the exchange), so the rows -- stale Y rows
 // behind the matrix included (ALS:304-308) -- are simply cut into `world` equal ranges: the work of M^T M
 // is proportional to rows, not to entries.
-int group_gramian(mals_group g, int side) {
+// A LOCAL failure of a member's partial Gramian or of installing the sum (MALS_OOM ...) does not leave the collective:
+// the member contributes zeros, every rank's all-reduces stay matched, and the failure is handed back through
+// local_rc / local_msg for the caller to skip the solves and agree on the status at the end of the half-iteration.
+// The return value is for failures that end the half-iteration on the spot (communication, device).
+int group_gramian(mals_group g, int side, int* local_rc, std::string* local_msg) {
+  auto member_failed = [&](const Member& mb, int rc) {
+    if (*local_rc == MALS_OK) {
+      *local_rc = rc;
+      *local_msg = std::string("rank ") + std::to_string(mb.rank) + ": " + mals_last_error(mb.h);
+    }
+  };
   const int k = g->cfg.features;
   const size_t kk = (size_t)k * k;
   const int64_t per = (g->n_total[side] + g->world - 1) / g->world;
@@ -385,11 +395,13 @@ int group_gramian(mals_group g, int side) {
     // maximum over all ranks give every member the exact operand bound of the split-precision gather (instead of
     // sqrt(max_f G_ff), which at 1e8 rows is 13 binades loose)
     GHIP(g, hipMemsetAsync(mb.d_ymax, 0, sizeof(float) * (size_t)malsi_ymax_slots(), mb.compute));
+    int prc = MALS_OK;
     if (r1 > r0) {
-      if (int rc = malsi_gramian_partial(mb.h, side, r0, r1 - r0, mb.d_gp, reinterpret_cast<unsigned*>(mb.d_ymax))) return mfail(g, mb, rc);
-    } else {
-      GHIP(g, hipMemsetAsync(mb.d_gp, 0, sizeof(double) * kk, mb.compute));
+      prc = malsi_gramian_partial(mb.h, side, r0, r1 - r0, mb.d_gp, reinterpret_cast<unsigned*>(mb.d_ymax));
+      if (prc == MALS_HIP_ERROR) return mfail(g, mb, prc);
+      if (prc != MALS_OK) member_failed(mb, prc);
     }
+    if (r1 <= r0 || prc != MALS_OK) GHIP(g, hipMemsetAsync(mb.d_gp, 0, sizeof(double) * kk, mb.compute));
   }
   if (g->world > 1 || g->m[0].nccl) {
     if (g->backend == MALS_GROUP_PEER_COPY) {  // fixed summation order (rank 0, 1, ...): deterministic
@@ -437,7 +449,10 @@ int group_gramian(mals_group g, int side) {
   }
   for (Member& mb : g->m) {
     GHIP(g, hipSetDevice(mb.device));
-    if (int rc = malsi_set_gramian(mb.h, side, mb.d_gp, MALS_MEM_DEVICE, reinterpret_cast<const unsigned*>(mb.d_ymax))) return mfail(g, mb, rc);
+    if (int rc = malsi_set_gramian(mb.h, side, mb.d_gp, MALS_MEM_DEVICE, reinterpret_cast<const unsigned*>(mb.d_ymax))) {
+      if (rc == MALS_HIP_ERROR) return mfail(g, mb, rc);
+      member_failed(mb, rc);
+    }
   }
   return MALS_OK;
 }
@@ -790,7 +805,7 @@ int mals_group_half_iteration(mals_group g, int side) {
           GHIP(g, hipSetDevice(mb.device));
           GHIP(g, hipStreamWaitEvent(mb.compute, other.ev_exchanged, 0));
         }
-    if (int rc = group_gramian(g, 1 - side)) return rc;  // ALS:342 / ALS:369
+    if (int rc = group_gramian(g, 1 - side, &solve_rc, &solve_msg)) return rc;  // ALS:342 / ALS:369
     for (int c = 0; c < g->side_chunks[side]; ++c) {
       // Like the reference's pool, where every worker is started before any result is awaited (ALS:186-191,391-410):
       // the direct kernels of EVERY member are enqueued before any host work; the k x k eigendecomposition of the
