@@ -299,7 +299,26 @@ __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, f
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       acc[tidx(T, kb, j)] = tile_ptq(Uinv, acc[tidx(T, kb, j)], zero);
     }
-    if constexpr (SPLIT) {
+#ifndef MALS_SYRK_RESPLIT_MINT
+#define MALS_SYRK_RESPLIT_MINT 8
+#endif
+    if constexpr (SPLIT && T >= MALS_SYRK_RESPLIT_MINT) {
+      // T = 8: the split tiles of block row kb are made where they are used instead of being kept in q[T] -- 28 registers
+      // next to 144 accumulators and the next row's 32 raw registers in flight.  +56 split_tile per row (~670 VALU),
+      // 42 -> 15 spilled dwords, and the spill traffic was the larger cost: c5rank 168.2 -> 164.6 ms, its user-half
+      // rows kernel 61.7 -> 58.8 ms, c5shard8 183.1 -> 180.0 (round 3, same box)
+#pragma unroll
+      for (int i = kb + 1; i < T; ++i) {
+        const TileH qi = split_tile(acc[tidx(T, kb, i)]);
+        const TileH np = negate_tile(qi);
+        acc[tidx(T, i, i)] = tile_ptq_h(np, qi, acc[tidx(T, i, i)]);
+#pragma unroll
+        for (int j = i + 1; j < T; ++j) {    // A_ij -= U_ki^T U_kj
+          const TileH qj = split_tile(acc[tidx(T, kb, j)]);
+          acc[tidx(T, i, j)] = tile_ptq_h(np, qj, acc[tidx(T, i, j)]);
+        }
+      }
+    } else if constexpr (SPLIT) {
       TileH q[T];
 #pragma unroll
       for (int j = kb + 1; j < T; ++j) q[j] = split_tile(acc[tidx(T, kb, j)]);
