@@ -1081,8 +1081,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
 // The same two lists with the split-precision gather (gather_row_h).  Pipeline per wave: the raw
 // registers always hold the NEXT super-step in flight -- of this row or, from the last convert of
 // a row on, super-step 0 of the next row, which therefore flies during the whole factorization.
-// That needs the next row's first chunk (col, value) on chip a row ahead (nch, requested two rows
-// ahead as nnch) and the work items three ahead.  Rows are sorted by length, so the empty rows
+// That needs the next row's first chunk (col, value) on chip a row ahead (nch) and the work items three ahead.  Rows are sorted by length, so the empty rows
 // (nothing to gather: W = G, b = 0) form the tail of a wave's list and are handled after the loop.
 template <int T, int MODE, bool FULL>
 __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_kernel_h(SolveParams p) {
@@ -1116,7 +1115,6 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
     chunk_weights_h(p, ch, zscale);
     prime_row_h<T, E, FULL>(p, ch.col, lane, raw);
     for (;;) {
-      const Chunk nnch = nx2.len > 0 ? chunk_issue(p, nx2.begin, nx2.len, 0, lane) : nch;
       const WorkItem nx3 = load_item(p, it + 3 * n_waves);
       f32x4 acc[tri(T)];
 #pragma unroll
@@ -1183,7 +1181,10 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
       cur = nxt;
       nxt = nx2;
       nx2 = nx3;
-      nch = nnch;
+      // first chunk of the row after the next (nxt, after the shift): requested a whole row (~10-20 us) before the end
+      // of the next row needs its columns.  (Until round 3 it was requested two rows ahead, in three more registers:
+      // measured neutral on C4 / C5, 1 % slower on C3, where the registers spill.)
+      nch = nxt.len > 0 ? chunk_issue(p, nxt.begin, nxt.len, 0, lane) : nch;
       it += n_waves;
       if (cur.len <= 0) break;
     }
