@@ -871,6 +871,10 @@ __device__ __forceinline__ float row_part_max(const f32x4 (&acc)[tri(T)], const 
   return __int_as_float(wave_max_bits(mf, lane));
 }
 
+// Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32 on whole accumulator tiles) up to this many feature blocks
+#ifndef MALS_PK_MAXT
+#define MALS_PK_MAXT 7
+#endif
 // Scale the row's system W x = b by s^2 = 2^(2p) with s * sqrt(max_i W_ii) <= 2^13 (entries of the
 // Cholesky factor of s^2 W are then <= 2^13): exact, and undone by comparing the pivots against
 // threshold * s^2 (the caller multiplies minpiv by the returned 1/s^2) -- x itself is unchanged.
@@ -884,9 +888,14 @@ __device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T
   p2 = p2 < -100 ? -100 : (p2 > 100 ? 100 : p2);
   const float s2 = __int_as_float((p2 + 127) << 23), inv_s2 = __int_as_float((127 - p2) << 23);
 #pragma unroll
-  for (int t = 0; t < tri(T); ++t)
+  for (int t = 0; t < tri(T); ++t) {
+    if constexpr (T <= MALS_PK_MAXT) {
+      acc[t] = acc[t] * s2;  // whole-tile products: v_pk_mul_f32, two values per issue slot
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[t][r] *= s2;
+      for (int r = 0; r < 4; ++r) acc[t][r] *= s2;
+    }
+  }
 #pragma unroll
   for (int v = 0; v < T; ++v) bcol[v] *= s2;
   return inv_s2;
@@ -927,12 +936,20 @@ __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T]
       *p.any_marked = 1;
     }
   }
-  if (lane < 16) {
+  // xcol[v] is the same in all four lane groups: group g writes blocks g, 4 + g -- (T + 3) / 4 full-wave stores, and only a
+  // store that can reach the last block needs the feature bound (k > 16 (T - 1)); T quarter-wave stores under T
+  // hoisted predicates cost 190-250 instructions per row, most of them reloads of spilled exec masks
+  {
     float* o = p.out + (int64_t)row * p.k;
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));  // (the masks and offsets below recomputed here, not kept live from the top of the row loop)
+    const int g = l2 >> 4, c = l2 & 15;
 #pragma unroll
-    for (int v = 0; v < T; ++v) {
-      const int feat = 16 * v + lane;
-      if (feat < p.k) o[feat] = xcol[v];
+    for (int m = 0; 4 * m < T; ++m) {
+      const float x = select4(g, xcol[4 * m], 4 * m + 1 < T ? xcol[4 * m + 1] : 0.f, 4 * m + 2 < T ? xcol[4 * m + 2] : 0.f,
+                              4 * m + 3 < T ? xcol[4 * m + 3] : 0.f);
+      const int feat = 16 * (4 * m + g) + c;
+      if (4 * m + 3 < T - 1 || feat < p.k) o[feat] = x;
     }
   }
 }
@@ -1143,8 +1160,12 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
 #pragma unroll
         for (int t = 0; t < tri(T); ++t) {
           const f32x4 g4 = sG[t * 64 + lane];
+          if constexpr (T <= MALS_PK_MAXT) {
+            acc[t] = __builtin_elementwise_fma(acc[t], f32x4{inv_s2, inv_s2, inv_s2, inv_s2}, g4);  // v_pk_fma_f32
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(acc[t][r], inv_s2, g4[r]);
+            for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(acc[t][r], inv_s2, g4[r]);
+          }
         }
         add_ridge<T, FULL>(p, acc, cur.len, lane);
         float minpiv = 3.0e38f, wmax;

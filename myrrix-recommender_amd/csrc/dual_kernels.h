@@ -311,6 +311,18 @@ __global__ void zero_rows_kernel(const WorkItem* __restrict__ items, int64_t n, 
   out[(int64_t)items[i].id * k + (e - i * k)] = 0.f;
 }
 
+// z - (float)h.lo / z - (float)h.hi for a packed f16 pair h: one v_fma_mix_f32 each (f16 source 0, fp32 constant and addend)
+__device__ __forceinline__ float residual_lo(int h, float z) {
+  float o;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(h), "v"(z));
+  return o;
+}
+__device__ __forceinline__ float residual_hi(int h, float z) {
+  float o;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(h), "v"(z));
+  return o;
+}
+
 template <int TN>
 struct DualEntries {
   int col[TN];
@@ -387,17 +399,14 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
     const int n = cur.len;
     // (1) all gathers of the row: lane (g,c) reads, for entry c of every 16-entry block, 16 bytes at
     // float offset 16 j + 4 g of the rotated row -- 64 contiguous bytes per entry and instruction
+    // (entries past the end of the row carry a clamped column and a zero weight, dual_load_entries: their
+    // gathers are valid and contribute nothing -- no predicate, no zero fill)
     f32x4 raw[TN][T];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      if (16 * b < n) {
-        const float* ptr = p.Mr + ((uint64_t)(uint32_t)en.col[b] * (uint32_t)KP + (uint32_t)(4 * g));
+      const float* ptr = p.Mr + ((uint64_t)(uint32_t)en.col[b] * (uint32_t)KP + (uint32_t)(4 * g));
 #pragma unroll
-        for (int j = 0; j < T; ++j) raw[b][j] = *reinterpret_cast<const f32x4*>(ptr + 16 * j);
-      } else {
-#pragma unroll
-        for (int j = 0; j < T; ++j) raw[b][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int j = 0; j < T; ++j) raw[b][j] = *reinterpret_cast<const f32x4*>(ptr + 16 * j);
     }
     // weights of this lane's entries (ALS:471-482)
     float ws[TN], qcol[TN];
@@ -406,9 +415,10 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
       const bool ok = 16 * b + c < n;
       const float r = en.r[b];
       const float ar = p.alpha * fabsf(r);
-      const float w = ok ? __builtin_sqrtf(ar) : 0.f;
+      // v_sqrt_f32 / v_rcp_f32 (1 ulp each, as chunk_weights_h): the IEEE expansions were 60 instructions per entry block
+      const float w = ok ? __builtin_amdgcn_sqrtf(ar) : 0.f;
       const float cb = (ok && r > 0.f) ? 1.f + ar : 0.f;
-      qcol[b] = w > 0.f ? cb / w : 0.f;
+      qcol[b] = w > 0.f ? cb * __builtin_amdgcn_rcpf(w) : 0.f;
       ws[b] = w * sc;
     }
     // next row's entries and the item after it land during this row's arithmetic
@@ -424,15 +434,14 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
       for (int j = 0; j < 2 * KC; ++j) {
         if (j < T) {
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(dn + 16 * j);
-          const f32x4 y = raw[b][j];
-          const float z0 = y[0] * d4[0] * ws[b], z1 = y[1] * d4[1] * ws[b];
-          const float z2 = y[2] * d4[2] * ws[b], z3 = y[3] * d4[3] * ws[b];
-          const int h01 = pk_rtz(z0, z1), h23 = pk_rtz(z2, z3);
-          const f16x2 a = __builtin_bit_cast(f16x2, h01), bb = __builtin_bit_cast(f16x2, h23);
+          // whole-vector products (v_pk_mul_f32: two values per issue slot); the residuals z - (float)zh as
+          // v_fma_mix_f32 on the packed halves, written out: hipcc only finds that form on scalar products
+          const f32x4 z4 = raw[b][j] * d4 * ws[b];
+          const int h01 = pk_rtz(z4[0], z4[1]), h23 = pk_rtz(z4[2], z4[3]);
           zh[b][j >> 1].r[2 * (j & 1)] = h01;
           zh[b][j >> 1].r[2 * (j & 1) + 1] = h23;
-          zl[b][j >> 1].r[2 * (j & 1)] = pk_rtz(fmaf((float)a[0], -1.f, z0), fmaf((float)a[1], -1.f, z1));
-          zl[b][j >> 1].r[2 * (j & 1) + 1] = pk_rtz(fmaf((float)bb[0], -1.f, z2), fmaf((float)bb[1], -1.f, z3));
+          zl[b][j >> 1].r[2 * (j & 1)] = pk_rtz(residual_lo(h01, z4[0]), residual_hi(h01, z4[1]));
+          zl[b][j >> 1].r[2 * (j & 1) + 1] = pk_rtz(residual_lo(h23, z4[2]), residual_hi(h23, z4[3]));
         } else {  // odd T: the upper half of the last 32-feature chunk is padding
           zh[b][j >> 1].r[2 * (j & 1)] = 0;
           zh[b][j >> 1].r[2 * (j & 1) + 1] = 0;
@@ -509,8 +518,37 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
       p.refine_flag[cur.id] = 1;
       *p.any_marked = 1;
     }
-    {
-      float* o = p.out + (int64_t)cur.id * p.k;
+    float* o = p.out + (int64_t)cur.id * p.k;
+    if constexpr (T >= 3 && T * TN < 32) {  // (T = 8, TN = 4 is at the register limit: this form spills there, 8.2 -> 8.9 ns per row)
+      // The sum over the four lane groups by halving: after the exchange with lane ^ 32 a lane keeps the blocks of its
+      // half of the wave, after lane ^ 16 those of its group -- group g ends up with blocks NB g .. NB g + NB - 1
+      // complete and the row leaves as NB full-wave stores instead of T quarter-wave ones (T = 8: 6 ds_bpermute
+      // instead of 16, 2 predicated stores instead of 8).
+      constexpr int P = T > 4 ? 8 : 4, NB = P / 4;
+      // (lane-derived addresses and masks of this block are recomputed per row from an opaque copy of the lane id:
+      // hoisted out of the row loop they stay live across the gather and the TN = 4 kernel at T = 8 spills)
+      int l2 = lane;
+      asm volatile("" : "+v"(l2));
+      const bool hi = l2 & 32, odd = l2 & 16;
+      const int g2 = l2 >> 4, c2 = l2 & 15;
+      float u[P / 2], v[NB];
+#pragma unroll
+      for (int i = 0; i < P / 2; ++i) {
+        const float lo_blk = xacc[i], hi_blk = i + P / 2 < T ? xacc[i + P / 2] : 0.f;
+        u[i] = (hi ? hi_blk : lo_blk) + bperm((l2 ^ 32) << 2, hi ? lo_blk : hi_blk);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) v[i] = (odd ? u[i + NB] : u[i]) + bperm((l2 ^ 16) << 2, odd ? u[i] : u[i + NB]);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int feat = 16 * (NB * g2 + i) + c2;
+        if (feat < p.k) {
+          const float x = v[i] * sD[(n - 1) * KP + feat] * inv_sc;
+          o[feat] = bad ? 0.f : x;
+          xmax = fmaxf(xmax, bad ? 0.f : fabsf(x));
+        }
+      }
+    } else {
       const float* dc = sD + (n - 1) * KP + c;
 #pragma unroll
       for (int j = 0; j < T; ++j) {
@@ -527,7 +565,7 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
     it += n_waves;
   }
   if (p.xbound) {
-    for (int off = 8; off > 0; off >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, off));
+    for (int off = 32; off > 0; off >>= 1) xmax = fmaxf(xmax, __shfl_xor(xmax, off));
     // same-address atomics serialise in L2 (~10 ns each, 1e5 waves): only waves that raise the bound issue one
     if (lane == 0 && xmax > __uint_as_float(__builtin_nontemporal_load(p.xbound))) atomicMax(p.xbound, __float_as_uint(xmax));
   }
