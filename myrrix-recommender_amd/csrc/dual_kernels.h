@@ -361,7 +361,9 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   for (int e = threadIdx.x; e < NMAX * KP; e += 256) {
     const int n = e / KP + 1, f = e - (n - 1) * KP;
-    sD[e] = 1.0f / sqrtf(p.lam[f] + p.lambda_alpha * (float)n);
+    // v_rsq_f32 (1 ulp): a workgroup of a short class list has four rows to solve, the IEEE sqrt + division of its
+    // NMAX x KP table entries was a quarter of its instructions
+    sD[e] = __builtin_amdgcn_rsqf(p.lam[f] + p.lambda_alpha * (float)n);
   }
   __syncthreads();
   const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
