@@ -470,8 +470,14 @@ __device__ __forceinline__ void bperm2_i(int addr, int v, int& r0, int& r1) {
 // Entry base+lane of a row with len > 0.  Issued in two halves so that no arithmetic waits on the
 // loads right after they are issued: chunk_issue only loads (col, raw value), chunk_weights turns
 // the raw value into the two weights when the chunk is about to be used.
+// ROWMAJOR (the split-precision kernels): lane 16 g + m holds entry base + 4 m + g instead of base + lane -- the entries
+// lane group g consumes (4 e + g, e = 0..15) then sit in ITS OWN 16 lanes, and handing entry e's weights to the group
+// is a DPP row broadcast of lane e (v_mov_b32_dpp row_newbcast, 4.4 issue cycles, no LDS) instead of a ds_bpermute
+// (8 cycles on the SIMD + 5 on the CU's shared crossbar + a wait on its latency).  The 64 lanes still read 64
+// consecutive entries.
+template <bool ROWMAJOR = false>
 __device__ __forceinline__ Chunk chunk_issue(const SolveParams& p, int64_t begin, int len, int base, int lane) {
-  const int n = base + lane;
+  const int n = base + (ROWMAJOR ? (((lane & 15) << 2) | (lane >> 4)) : lane);
   const int nn = n < len ? n : len - 1;
   Chunk e;
   // the entry stream is read exactly once: non-temporal, so that it does not push factor rows
@@ -641,7 +647,7 @@ __device__ __forceinline__ void chunk_weights_h(const SolveParams& p, Chunk& e, 
 }
 
 // Gather the two entries 4e+g, e = 2*E2 and 2*E2+1, of one super-step: their columns sit in lanes
-// (off/4 + 4e + g) of col_src (off = 4g + 16*E*part of the chunk).  Entries past the end of the row
+// (off/4 + e) of col_src (row-major chunk: off = 4 (16 g + E*part)).  Entries past the end of the row
 // have a clamped column (chunk_issue) and zero weights, so they gather a valid, cached row that
 // contributes nothing: no per-entry predication.  As in load_rows, the features past k of a partial last
 // block are the zero padding of the table.
@@ -649,7 +655,7 @@ template <int T, int E, bool FULL, int E2>
 __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, int off, int lane, float (&raw)[T][E]) {
   const int c = lane & 15;
   int col[2];
-  bperm2_i<32 * E2, 32 * E2 + 16>(off, col_src, col[0], col[1]);
+  bperm2_i<8 * E2, 8 * E2 + 4>(off, col_src, col[0], col[1]);  // entries 4 (2 E2 + i) + g of the part: lanes 16 g + 2 E2 + i (+ E part)
 #ifdef MALS_PROFILING
   if (p.flags & 0x400) {  // ablation (MALS_DEBUG_FLAGS=4): every gather hits the cache
     col[0] &= 0xfff;
@@ -669,10 +675,9 @@ __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, 
 template <int T, int E, bool FULL, int PART, int E2>
 __device__ __forceinline__ void convert_pair_h(const SolveParams& p, const Chunk& ch, int lane, const float (&raw)[T][E], ZOp<E> (&zh)[T],
                                                ZOp<E> (&zl)[T], float (&bpart)[T]) {
-  const int gb = (lane >> 4) << 2;
-  constexpr int o0 = 16 * E * PART + 32 * E2, o1 = o0 + 16;
-  float s0, s1, c0, c1;
-  bperm2x2<o0, o1>(gb, ch.w, ch.cb, s0, s1, c0, c1);
+  constexpr int m0 = E * PART + 2 * E2;  // entry 4 m0 + g of the chunk: lane m0 of this group's row (chunk_issue<true>)
+  const float s0 = row_bcast<m0>(ch.w), s1 = row_bcast<m0 + 1>(ch.w);
+  const float c0 = row_bcast<m0>(ch.cb), c1 = row_bcast<m0 + 1>(ch.cb);
 #pragma unroll
   for (int v = 0; v < T; ++v) {
     const float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
@@ -737,12 +742,12 @@ __device__ __forceinline__ void gram_super_step(const ZOp<E> (&zh)[T], const ZOp
 // The gathers of a whole super-step (start of a wave's first row only).
 template <int T, int E, bool FULL>
 __device__ __forceinline__ void prime_row_h(const SolveParams& p, int col_src, int lane, float (&raw)[T][E]) {
-  const int gb = (lane >> 4) << 2;
-  issue_pair_h<T, E, FULL, 0>(p, col_src, gb, lane, raw);
-  issue_pair_h<T, E, FULL, 1>(p, col_src, gb, lane, raw);
+  const int rb = (lane & 48) << 2;  // byte address of lane 0 of this group's row
+  issue_pair_h<T, E, FULL, 0>(p, col_src, rb, lane, raw);
+  issue_pair_h<T, E, FULL, 1>(p, col_src, rb, lane, raw);
   if constexpr (E == 8) {
-    issue_pair_h<T, E, FULL, 2>(p, col_src, gb, lane, raw);
-    issue_pair_h<T, E, FULL, 3>(p, col_src, gb, lane, raw);
+    issue_pair_h<T, E, FULL, 2>(p, col_src, rb, lane, raw);
+    issue_pair_h<T, E, FULL, 3>(p, col_src, rb, lane, raw);
   }
 }
 
@@ -751,13 +756,13 @@ template <int T, int E, bool FULL, int PART>
 __device__ __forceinline__ void super_step_h(const SolveParams& p, const Chunk& ch, const Chunk& chn, int next_col, bool last, int lane,
                                              float (&raw)[T][E], f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
   constexpr int NP = 16 / E;  // super-steps per 64-entry chunk
-  const int gb = (lane >> 4) << 2;
+  const int rb = (lane & 48) << 2;  // byte address of lane 0 of this group's row
   ZOp<E> zh[T], zl[T];
   // what the raw registers are refilled with: the next part of this chunk, part 0 of the next chunk,
   // or (after the row's last super-step) the first super-step of the next row
   const int same_row_col = PART == NP - 1 ? chn.col : ch.col;
-  const int same_row_off = PART == NP - 1 ? gb : gb + 16 * E * (PART + 1);
-  convert_refill_h<T, E, FULL, PART>(p, ch, last ? next_col : same_row_col, last ? gb : same_row_off, lane, raw, zh, zl, bpart);
+  const int same_row_off = PART == NP - 1 ? rb : rb + 4 * E * (PART + 1);
+  convert_refill_h<T, E, FULL, PART>(p, ch, last ? next_col : same_row_col, last ? rb : same_row_off, lane, raw, zh, zl, bpart);
   __builtin_amdgcn_sched_barrier(0);
   gram_super_step<T, E>(zh, zl, acc);
   __builtin_amdgcn_sched_barrier(0);
@@ -773,7 +778,7 @@ __device__ __forceinline__ void gather_row_h(const SolveParams& p, int64_t begin
   const int n_ss = (len + NS - 1) / NS;
   for (int q = 0; NP * q < n_ss; ++q) {
     // next chunk (clamped inside the row, so always safe to issue); lands during this chunk
-    Chunk chn = chunk_issue(p, begin, len, 64 * (q + 1), lane);
+    Chunk chn = chunk_issue<true>(p, begin, len, 64 * (q + 1), lane);
     const int ss = NP * q;
     super_step_h<T, E, FULL, 0>(p, ch, chn, next_col, ss + 1 >= n_ss, lane, raw, acc, bpart);
     if (ss + 1 < n_ss) {
@@ -1126,9 +1131,9 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
 #pragma unroll
     for (int e = 0; e < E; ++e) raw[v][e] = 0.f;
   if (cur.len > 0) {
-    Chunk ch = chunk_issue(p, cur.begin, cur.len, 0, lane);
+    Chunk ch = chunk_issue<true>(p, cur.begin, cur.len, 0, lane);
     // first chunks of the next two rows; where there is no such row, any valid columns do
-    Chunk nch = nxt.len > 0 ? chunk_issue(p, nxt.begin, nxt.len, 0, lane) : ch;
+    Chunk nch = nxt.len > 0 ? chunk_issue<true>(p, nxt.begin, nxt.len, 0, lane) : ch;
     chunk_weights_h(p, ch, zscale);
     prime_row_h<T, E, FULL>(p, ch.col, lane, raw);
     for (;;) {
@@ -1205,7 +1210,7 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
       // first chunk of the row after the next (nxt, after the shift): requested a whole row (~10-20 us) before the end
       // of the next row needs its columns.  (Until round 3 it was requested two rows ahead, in three more registers:
       // measured neutral on C4 / C5, 1 % slower on C3, where the registers spill.)
-      nch = nxt.len > 0 ? chunk_issue(p, nxt.begin, nxt.len, 0, lane) : nch;
+      nch = nxt.len > 0 ? chunk_issue<true>(p, nxt.begin, nxt.len, 0, lane) : nch;
       it += n_waves;
       if (cur.len <= 0) break;
     }
