@@ -457,6 +457,19 @@ __device__ __forceinline__ void bperm2x2(int addr, float a, float b, float& a0, 
       : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
       : "v"(addr), "v"(a), "v"(b), "n"(O0), "n"(O1));
 }
+// The same in two halves: the two ds_bpermute now, the wait where the values are needed.  The wait statement names the
+// values as operands, so nothing that reads them can be scheduled ahead of it.
+template <int O0, int O1>
+__device__ __forceinline__ void bperm2_i_start(int addr, int v, int& r0, int& r1) {
+  asm volatile(
+      "ds_bpermute_b32 %0, %2, %3 offset:%4\n\t"
+      "ds_bpermute_b32 %1, %2, %3 offset:%5"
+      : "=&v"(r0), "=&v"(r1)
+      : "v"(addr), "v"(v), "n"(O0), "n"(O1));
+}
+__device__ __forceinline__ void bperm2_i_land(int& r0, int& r1) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1));
+}
 template <int O0, int O1>
 __device__ __forceinline__ void bperm2_i(int addr, int v, int& r0, int& r1) {
   asm volatile(
@@ -671,6 +684,32 @@ __device__ __forceinline__ void issue_pair_h(const SolveParams& p, int col_src, 
   }
 }
 
+// issue_pair_h in two halves (convert_refill_h): the columns are requested before the conversion of the pair whose raw
+// registers they will refill, the loads issued after it -- the LDS round trip runs under ~70 VALU instructions instead
+// of stalling the wave four times per super-step
+template <int E2>
+__device__ __forceinline__ void fetch_pair_cols_h(int col_src, int off, int (&col)[2]) {
+  bperm2_i_start<8 * E2, 8 * E2 + 4>(off, col_src, col[0], col[1]);
+}
+template <int T, int E, bool FULL, int E2>
+__device__ __forceinline__ void issue_pair_loads_h(const SolveParams& p, int (&col)[2], int lane, float (&raw)[T][E]) {
+  const int c = lane & 15;
+  bperm2_i_land(col[0], col[1]);
+#ifdef MALS_PROFILING
+  if (p.flags & 0x400) {  // ablation (MALS_DEBUG_FLAGS=4): every gather hits the cache
+    col[0] &= 0xfff;
+    col[1] &= 0xfff;
+  }
+#endif
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = 2 * E2 + i;
+    const float* ptr = p.M + ((uint64_t)(uint32_t)col[i] * (uint32_t)p.ldm + (uint32_t)c);
+#pragma unroll
+    for (int v = 0; v < T; ++v) raw[v][e] = ptr[16 * v];
+  }
+}
+
 // raw rows of one entry pair -> scaled, split f16 operands; RHS partial sums (fp32, raw rows)
 template <int T, int E, bool FULL, int PART, int E2>
 __device__ __forceinline__ void convert_pair_h(const SolveParams& p, const Chunk& ch, int lane, const float (&raw)[T][E], ZOp<E> (&zh)[T],
@@ -702,22 +741,28 @@ template <int T, int E, bool FULL, int PART>
 __device__ __forceinline__ void convert_refill_h(const SolveParams& p, const Chunk& ch, int next_col, int next_off, int lane,
                                                  float (&raw)[T][E], ZOp<E> (&zh)[T], ZOp<E> (&zl)[T], float (&bpart)[T]) {
 #define MALS_SB __builtin_amdgcn_sched_barrier(0)
+  int col[2];
+  fetch_pair_cols_h<0>(next_col, next_off, col);
+  MALS_SB;
   convert_pair_h<T, E, FULL, PART, 0>(p, ch, lane, raw, zh, zl, bpart);
   MALS_SB;
-  issue_pair_h<T, E, FULL, 0>(p, next_col, next_off, lane, raw);
+  issue_pair_loads_h<T, E, FULL, 0>(p, col, lane, raw);
+  fetch_pair_cols_h<1>(next_col, next_off, col);
   MALS_SB;
   convert_pair_h<T, E, FULL, PART, 1>(p, ch, lane, raw, zh, zl, bpart);
   MALS_SB;
-  issue_pair_h<T, E, FULL, 1>(p, next_col, next_off, lane, raw);
+  issue_pair_loads_h<T, E, FULL, 1>(p, col, lane, raw);
   if constexpr (E == 8) {
+    fetch_pair_cols_h<2>(next_col, next_off, col);
     MALS_SB;
     convert_pair_h<T, E, FULL, PART, 2>(p, ch, lane, raw, zh, zl, bpart);
     MALS_SB;
-    issue_pair_h<T, E, FULL, 2>(p, next_col, next_off, lane, raw);
+    issue_pair_loads_h<T, E, FULL, 2>(p, col, lane, raw);
+    fetch_pair_cols_h<3>(next_col, next_off, col);
     MALS_SB;
     convert_pair_h<T, E, FULL, PART, 3>(p, ch, lane, raw, zh, zl, bpart);
     MALS_SB;
-    issue_pair_h<T, E, FULL, 3>(p, next_col, next_off, lane, raw);
+    issue_pair_loads_h<T, E, FULL, 3>(p, col, lane, raw);
   }
 #undef MALS_SB
 }
