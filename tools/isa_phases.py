@@ -31,7 +31,7 @@ for ln in lines[s:e]:
     if m:
         phase = m.group(1)
         continue
-    if not t or t[0] in ";." or t.endswith(":"):
+    if not t or t[0] in ";." or t.split()[0].endswith(":"):   # comments, directives, labels (with or without a comment)
         continue
     op = t.split()[0].replace("_e32", "").replace("_e64", "")
     counts.setdefault(phase, collections.Counter())[op] += 1
