@@ -458,7 +458,8 @@ __device__ __forceinline__ void bperm2x2(int addr, float a, float b, float& a0, 
       : "v"(addr), "v"(a), "v"(b), "n"(O0), "n"(O1));
 }
 // The same in two halves: the two ds_bpermute now, the wait where the values are needed.  The wait statement names the
-// values as operands, so nothing that reads them can be scheduled ahead of it.
+// values as operands, so nothing that reads them can be scheduled ahead of it; that the register allocator puts no copy or
+// spill of them in between either is checked on the generated ISA (tools/check_lds_windows.py, tests/test_dpp_hazards.py).
 template <int O0, int O1>
 __device__ __forceinline__ void bperm2_i_start(int addr, int v, int& r0, int& r1) {
   asm volatile(

@@ -1,7 +1,10 @@
-"""The hand-written DPP blocks of csrc/als_kernels.h (v_fmac_f32_dpp in factor_diag) rely on a gfx9 data
-hazard rule the compiler does not apply to inline asm: a DPP source register needs two wait states after
-a VALU write.  This compiles the device code to ISA (hipcc cross-compiles without a GPU) and checks
-every DPP instruction with tools/check_dpp_hazards.py."""
+"""Two properties of the generated ISA that hipcc does not guarantee for inline asm, checked on the device code compiled
+with the product's flags (hipcc cross-compiles without a GPU):
+ * the hand-written DPP blocks of csrc/als_kernels.h (v_fmac_f32_dpp in factor_diag) rely on a gfx9 data hazard rule: a
+   DPP source register needs two wait states after a VALU write (tools/check_dpp_hazards.py);
+ * the split column fetch of the gather issues its ds_bpermute in one asm statement and waits for them in another
+   (bperm2_i_start / bperm2_i_land): nothing -- not a register copy, not a spill -- may read the destinations in
+   between (tools/check_lds_windows.py, which checks every LDS destination of the listing)."""
 import os
 import shutil
 import subprocess
@@ -17,9 +20,39 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 def test_no_dpp_read_after_valu_write(tmp_path):
     out = tmp_path / "mals_api.s"
     src = os.path.join(ROOT, "myrrix-recommender_amd", "csrc", "mals_api.hip")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), src],
+    # the flags of csrc/Makefile: the scheduler's output is what is being checked
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", str(out), src],
                    check=True, capture_output=True, timeout=900)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), str(out)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "v_fmac_f32_dpp" in out.read_text()
+    text = out.read_text()
+    assert "v_fmac_f32_dpp" in text
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lds_windows.py"), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "ds_bpermute_b32" in text
+
+
+def test_lds_window_checker_sees_an_early_read(tmp_path):
+    """The checker itself: a copy of a ds_bpermute destination before the wait is reported, the same after it is not;
+    lgkmcnt(k) leaves the k youngest operations outstanding; a label resets the state."""
+    checker = os.path.join(ROOT, "tools", "check_lds_windows.py")
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("k:\n" + body + "\ts_endpgm\n")
+        return subprocess.run([sys.executable, checker, str(f)], capture_output=True, text=True)
+
+    bad = run("\tds_bpermute_b32 v3, v1, v2 offset:8\n\tv_mov_b32_e32 v9, v3\n\ts_waitcnt lgkmcnt(0)\n")
+    assert bad.returncode == 1 and "READ BEFORE WAIT" in bad.stdout
+    spill = run("\tds_bpermute_b32 v3, v1, v2\n\tscratch_store_dword off, v3, off offset:4\n\ts_waitcnt lgkmcnt(0)\n")
+    assert spill.returncode == 1
+    good = run("\tds_bpermute_b32 v3, v1, v2 offset:8\n\tv_mul_f32_e32 v5, v6, v7\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v9, v3\n")
+    assert good.returncode == 0, good.stdout
+    older = run("\tds_bpermute_b32 v3, v1, v2\n\tds_bpermute_b32 v4, v1, v2\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b32_e32 v9, v3\n")
+    assert older.returncode == 0, older.stdout
+    younger = run("\tds_bpermute_b32 v3, v1, v2\n\tds_bpermute_b32 v4, v1, v2\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b32_e32 v9, v4\n")
+    assert younger.returncode == 1
+    label = run("\tds_bpermute_b32 v3, v1, v2\n.LBB0_1:                 ; in Loop\n\tv_mov_b32_e32 v9, v3\n")
+    assert label.returncode == 0
