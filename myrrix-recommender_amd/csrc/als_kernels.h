@@ -1713,19 +1713,26 @@ __global__ __launch_bounds__(256) void gramian_reduce_slabs_kernel(const float* 
   out[(int64_t)q * elems + e] = acc;
 }
 
-template <int T, bool F64_LAYOUT>
+// PARTS threads per element, each summing a contiguous range of the partials in order; the PARTS sums are then added in
+// order -- a fixed association whatever the launch.  PARTS = 16 for the fp64 kernel's per-wave partials (up to 1024 of
+// them: with 4 ranges and 40 workgroups the finalize pass cost as much as the Gramian itself on C2).
+template <int T, bool F64_LAYOUT, int PARTS = 4>
 __global__ __launch_bounds__(256) void gramian_finalize_kernel(const double* __restrict__ partial, int64_t n_waves, int k,
                                                                double* __restrict__ G, float* __restrict__ Gf) {
-  __shared__ double part[4][64];
-  const int q = threadIdx.x >> 6, ln = threadIdx.x & 63;
-  const int e = blockIdx.x * 64 + ln;  // tri(T)*256 elements, a multiple of 64
-  const int64_t per = n_waves >> 2;    // n_waves is a multiple of 4
+  constexpr int EPB = 256 / PARTS;     // elements per workgroup
+  __shared__ double part[PARTS][EPB];
+  const int q = threadIdx.x / EPB, ln = threadIdx.x % EPB;
+  const int e = blockIdx.x * EPB + ln;  // tri(T)*256 elements, a multiple of 64
+  const int64_t per = (n_waves + PARTS - 1) / PARTS;
+  const int64_t w_end = (q + 1) * per < n_waves ? (q + 1) * per : n_waves;
   double acc = 0.0;
-  for (int64_t w = q * per; w < (q + 1) * per; ++w) acc += partial[w * (int64_t)(tri(T) * 256) + e];
+  for (int64_t w = q * per; w < w_end; ++w) acc += partial[w * (int64_t)(tri(T) * 256) + e];
   part[q][ln] = acc;
   __syncthreads();
   if (q != 0) return;
-  const double s = ((part[0][ln] + part[1][ln]) + part[2][ln]) + part[3][ln];
+  double s = part[0][ln];
+#pragma unroll
+  for (int i = 1; i < PARTS; ++i) s += part[i][ln];
   const int t = e >> 8, reg = (e >> 6) & 3, lane = e & 63;
   // decode tile (i,j) from t
   int i = 0, rem = t;

@@ -528,8 +528,9 @@ int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows
     HIPCHK(h, hipGetLastError());
     return MALS_OK;
   }
-  // waves: at least 64 rows each, at most 2048 waves
-  int64_t n_waves = std::min<int64_t>(2048, std::max<int64_t>(1, (n_rows + 255) / 256));
+  // waves: at least 64 rows each, at most 1024 waves (the finalize pass costs per partial).  (256 rows each until round 3: a 17 770-row Y then ran on 72 of the
+  // chip's 1024 SIMDs for 174 us at k = 100, C2's two matrices for 44 us each -- 7 % of its iteration.)
+  int64_t n_waves = std::min<int64_t>(1024, std::max<int64_t>(1, (n_rows + 63) / 64));
   n_waves = (n_waves + 3) & ~(int64_t)3;
   int64_t rows_per_wave = (n_rows + n_waves - 1) / n_waves;
   rows_per_wave = std::max<int64_t>(4, (rows_per_wave + 3) & ~(int64_t)3);
@@ -545,7 +546,7 @@ int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows
   if (ymax) HIPCHK(h, hipMemsetAsync(ymax, 0x7f, sizeof(unsigned), h->stream));
   hipLaunchKernelGGL((gramian_partial_kernel<T>), dim3((unsigned)(n_waves / 4)), dim3(256), 0, h->stream, M, n_rows, k,
                      rows_per_wave, s.partials);
-  hipLaunchKernelGGL((gramian_finalize_kernel<T, true>), dim3(elems / 64), dim3(256), 0, h->stream, s.partials, n_waves,
+  hipLaunchKernelGGL((gramian_finalize_kernel<T, true, 16>), dim3(elems / 16), dim3(256), 0, h->stream, s.partials, n_waves,
                      k, G_out, Gf_out);
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
