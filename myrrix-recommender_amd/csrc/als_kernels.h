@@ -50,11 +50,18 @@ struct WorkItem {   // one row (list A) or one segment of a long row (list B); 1
   int32_t len;      // entries
   int32_t id;       // list A: local row; list B: scratch slot
 };
-struct RowC {       // a long row to be finished from its segment partials
+struct RowC {       // a long row to be finished from its segment partials: slots first_slot + i * stride, i < nseg
   int64_t first_slot;
   int32_t row;
   int32_t nseg;
+  int32_t stride;   // 1, or FINISH_GROUP once als_prereduce_kernel has summed every group of slots into its first
+  int32_t pad_;
 };
+// A wave sums a row's partial slots one after the other (a dependent chain of ~0.7 us each): the most popular item of
+// C4 (7M entries, 1 700 segments) kept the finish kernel running for 1.15 ms with everything else long done.  Rows with
+// more than FINISH_GROUP segments are first reduced group-wise, one wave per group of FINISH_GROUP consecutive slots,
+// in place (als_prereduce_kernel); the finish kernel then walks the group leaders.
+constexpr int FINISH_GROUP = 32;
 
 struct SolveParams {
   const int64_t* row_ptr;   // local CSR
@@ -1276,7 +1283,43 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
   }
 }
 
-// list C: one wave per long row: sum the segment partials in order, then K3
+// groups of list C (RowC with stride 1, row unused): one wave per group sums its slots in order into the first
+template <int T>
+__global__ __launch_bounds__(256) void als_prereduce_kernel(SolveParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= p.n_work) return;
+  RowC rc = p.rowsC[wave];
+  rc.first_slot = uniform64(rc.first_slot);
+  rc.nseg = uniform(rc.nseg);
+  constexpr int SLOT = (tri(T) * 4 + T) * 64;
+  float* s0 = p.scratch + rc.first_slot * (int64_t)SLOT;
+  f32x4 acc[tri(T)];
+  float bcol[T];
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) acc[t] = reinterpret_cast<const f32x4*>(s0)[t * 64 + lane];
+#pragma unroll
+  for (int v = 0; v < T; ++v) bcol[v] = s0[(tri(T) * 4 + v) * 64 + lane];
+  for (int sgi = 1; sgi < rc.nseg; ++sgi) {
+    const float* s = s0 + sgi * (int64_t)SLOT;
+    f32x4 part[tri(T)];
+    float bp[T];
+#pragma unroll
+    for (int t = 0; t < tri(T); ++t) part[t] = reinterpret_cast<const f32x4*>(s)[t * 64 + lane];
+#pragma unroll
+    for (int v = 0; v < T; ++v) bp[v] = s[(tri(T) * 4 + v) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < tri(T); ++t) acc[t] += part[t];
+#pragma unroll
+    for (int v = 0; v < T; ++v) bcol[v] += bp[v];
+  }
+#pragma unroll
+  for (int t = 0; t < tri(T); ++t) reinterpret_cast<f32x4*>(s0)[t * 64 + lane] = acc[t];
+#pragma unroll
+  for (int v = 0; v < T; ++v) s0[(tri(T) * 4 + v) * 64 + lane] = bcol[v];
+}
+
+// list C: one wave per long row: sum the segment partials (or their group sums) in order, then K3
 template <int T>
 __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
   const int lane = threadIdx.x & 63;
@@ -1286,6 +1329,7 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
   rc.first_slot = uniform64(rc.first_slot);
   rc.row = uniform(rc.row);
   rc.nseg = uniform(rc.nseg);
+  rc.stride = uniform(rc.stride);
   f32x4 acc[tri(T)];
 #pragma unroll
   for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1294,7 +1338,7 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
   for (int v = 0; v < T; ++v) bcol[v] = 0.f;
   for (int sgi = 0; sgi < rc.nseg; ++sgi) {
     // all loads of a segment's slot first (16 bytes per lane and tile), then the adds
-    const float* s = p.scratch + (rc.first_slot + sgi) * (int64_t)((tri(T) * 4 + T) * 64);
+    const float* s = p.scratch + (rc.first_slot + (int64_t)sgi * rc.stride) * (int64_t)((tri(T) * 4 + T) * 64);
     f32x4 part[tri(T)];
     float bp[T];
 #pragma unroll

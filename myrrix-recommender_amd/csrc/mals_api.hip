@@ -72,6 +72,7 @@ struct SideState {
   // descending length throughout] [nZ further empty rows: x = 0, same verdict as the representative]
   struct ChunkRange {
     int64_t offA = 0, nA = 0, nnzA = 0, offB = 0, nB = 0, nnzB = 0, offC = 0, nC = 0;
+    int64_t offP = 0, nP = 0;  // groups of partial slots reduced ahead of the finish kernel (entries of rowsC as well)
     int64_t nD[4] = {0, 0, 0, 0}, nnzD[4] = {0, 0, 0, 0}, nZ = 0;
     int64_t n_dual() const { return nD[0] + nD[1] + nD[2] + nD[3]; }
     int64_t nnz_dual() const { return nnzD[0] + nnzD[1] + nnzD[2] + nnzD[3]; }
@@ -304,7 +305,7 @@ int build_work_lists(mals_handle h, SideState& s) {
   const std::vector<int64_t>& rp = s.h_row_ptr;
   std::vector<WorkItem> order;
   std::vector<WorkItem> segs;
-  std::vector<RowC> rowsC;
+  std::vector<RowC> rowsC, groups;
   order.reserve((size_t)n);
   int64_t slot = 0;
   s.chunks.assign((size_t)n_chunks, SideState::ChunkRange());
@@ -375,6 +376,8 @@ int build_work_lists(mals_handle h, SideState& s) {
         rc.first_slot = slot;
         rc.row = (int32_t)r;
         rc.nseg = 0;
+        rc.stride = 1;
+        rc.pad_ = 0;
         for (int64_t b = 0; b < len; b += per) {
           if (slot >= std::numeric_limits<int32_t>::max()) return fail(h, MALS_INVALID_ARG, "too many row segments");
           WorkItem sg;
@@ -383,6 +386,19 @@ int build_work_lists(mals_handle h, SideState& s) {
           sg.id = (int32_t)slot++;
           segs.push_back(sg);
           ++rc.nseg;
+        }
+        if (rc.nseg > FINISH_GROUP) {  // group sums first (als_prereduce_kernel), the finish kernel walks the leaders
+          for (int32_t g0 = 0; g0 < rc.nseg; g0 += FINISH_GROUP) {
+            RowC grp;
+            grp.first_slot = rc.first_slot + g0;
+            grp.row = (int32_t)r;
+            grp.nseg = std::min<int32_t>(FINISH_GROUP, rc.nseg - g0);
+            grp.stride = 1;
+            grp.pad_ = 0;
+            groups.push_back(grp);
+          }
+          rc.nseg = (rc.nseg + FINISH_GROUP - 1) / FINISH_GROUP;
+          rc.stride = FINISH_GROUP;
         }
         rowsC.push_back(rc);
       }
@@ -400,6 +416,10 @@ int build_work_lists(mals_handle h, SideState& s) {
     s.n_dual_rows += n_dual;
     cr.nB = (int64_t)segs.size() - cr.offB;
     cr.nC = (int64_t)rowsC.size() - cr.offC;
+    cr.offP = (int64_t)rowsC.size();  // the chunk's slot groups sit behind its rows in the same array
+    cr.nP = (int64_t)groups.size();
+    rowsC.insert(rowsC.end(), groups.begin(), groups.end());
+    groups.clear();
     // longest segments first
     std::stable_sort(segs.begin() + cr.offB, segs.end(), [](const WorkItem& a, const WorkItem& b) { return a.len > b.len; });
     s.nnzA += cr.nnzA;
@@ -609,9 +629,9 @@ int launch_persistent(mals_handle h, K kernel, KF fallback, const SolveParams& p
   return end_timed(h, pe);
 }
 
-template <typename KA, typename KB, typename KFA, typename KFB, typename KC>
+template <typename KA, typename KB, typename KFA, typename KFB, typename KC, typename KP>
 int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int which, KA rows_kernel, KB segments_kernel, KFA rows_fallback,
-                 KFB segments_fallback, KC finish_kernel) {
+                 KFB segments_fallback, KC finish_kernel, KP prereduce_kernel) {
   const double per = 4.0 * p.k + 8.0;  // gathered row + col idx + value; written row + row_ptr
   const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
   PendingEvent pe;
@@ -632,9 +652,14 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int whic
     if (int rc = launch_persistent(h, rows_kernel, rows_fallback, p, 0, (double)cr.nnz_dual() * per + (double)cr.n_dual() * per)) return rc;
   }
   if (longs && cr.nC) {
+    if (int rc = begin_timed(h, 2, (double)cr.nC * per, pe)) return rc;
+    if (cr.nP) {
+      p.n_work = cr.nP;
+      p.rowsC = s.rowsC + cr.offP;
+      hipLaunchKernelGGL(prereduce_kernel, dim3((unsigned)((cr.nP + 3) / 4)), dim3(256), 0, h->stream, p);
+    }
     p.n_work = cr.nC;
     p.rowsC = s.rowsC + cr.offC;
-    if (int rc = begin_timed(h, 2, (double)cr.nC * per, pe)) return rc;
     hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((cr.nC + 3) / 4)), dim3(256), 0, h->stream, p);
     if (int rc = end_timed(h, pe)) return rc;
   }
@@ -651,9 +676,10 @@ template <int T, int D, bool FULL>
 int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk, int which) {
   if (h->split_f16)
     return launch_lists(h, s, p, chunk, which, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>,
-                        als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>);
+                        als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>,
+                        als_prereduce_kernel<T>);
   return launch_lists(h, s, p, chunk, which, als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>,
-                      nullptr, nullptr, als_finish_kernel<T>);
+                      nullptr, nullptr, als_finish_kernel<T>, als_prereduce_kernel<T>);
 }
 
 template <int T, int D>
