@@ -54,7 +54,7 @@ struct RowC {       // a long row to be finished from its segment partials: slot
   int64_t first_slot;
   int32_t row;
   int32_t nseg;
-  int32_t stride;   // 1, or FINISH_GROUP once als_prereduce_kernel has summed every group of slots into its first
+  int32_t stride;   // 1, or the group length once als_prereduce_kernel has summed every group of slots into its first
   int32_t pad_;
 };
 // A wave sums a row's partial slots one after the other (a dependent chain of ~0.7 us each): the most popular item of

@@ -304,11 +304,13 @@ __global__ __launch_bounds__(256, 2) void rotate_rows_split_kernel(RotateSplitPa
 }
 
 // rows outside every work list that need no arithmetic: x = 0 (empty rows: b = 0)
+// (one wave per row, a lane per feature: a thread per element with its 64-bit division ran at 1.9 TB/s on C4's 1.4M
+// empty user rows)
 __global__ void zero_rows_kernel(const WorkItem* __restrict__ items, int64_t n, int k, float* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n * k) return;
-  const int64_t i = e / k;
-  out[(int64_t)items[i].id * k + (e - i * k)] = 0.f;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  float* o = out + (int64_t)items[i].id * k;
+  for (int c = threadIdx.x & 63; c < k; c += 64) o[c] = 0.f;
 }
 
 // z - (float)h.lo / z - (float)h.hi for a packed f16 pair h: one v_fma_mix_f32 each (f16 source 0, fp32 constant and addend)
