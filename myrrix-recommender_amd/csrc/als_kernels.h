@@ -1283,6 +1283,32 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
   }
 }
 
+// acc, bcol += one partial slot.  All loads of a pass first (16 bytes per lane and tile), then the adds; from T = 6 on in
+// two passes of half the tiles -- a whole slot in flight next to the accumulators is 2 x tri(T) x 4 registers, which put
+// the T = 7 finish kernel at one wave per SIMD (247 VGPRs + 92 AGPRs)
+template <int T>
+__device__ __forceinline__ void add_slot(const float* __restrict__ s, int lane, f32x4 (&acc)[tri(T)], float (&bcol)[T]) {
+  constexpr int PASSES = T >= 6 ? 2 : 1, PER = (tri(T) + PASSES - 1) / PASSES;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    f32x4 part[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+      if (ps * PER + t < tri(T)) part[t] = reinterpret_cast<const f32x4*>(s)[(ps * PER + t) * 64 + lane];
+    if (ps == 0) {
+      float bp[T];
+#pragma unroll
+      for (int v = 0; v < T; ++v) bp[v] = s[(tri(T) * 4 + v) * 64 + lane];
+#pragma unroll
+      for (int v = 0; v < T; ++v) bcol[v] += bp[v];
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+      if (ps * PER + t < tri(T)) acc[ps * PER + t] += part[t];
+    if (PASSES > 1) __builtin_amdgcn_sched_barrier(0);  // keep the passes apart (the scheduler would merge their loads again)
+  }
+}
+
 // groups of list C (RowC with stride 1, row unused): one wave per group sums its slots in order into the first
 template <int T>
 __global__ __launch_bounds__(256) void als_prereduce_kernel(SolveParams p) {
@@ -1301,17 +1327,7 @@ __global__ __launch_bounds__(256) void als_prereduce_kernel(SolveParams p) {
 #pragma unroll
   for (int v = 0; v < T; ++v) bcol[v] = s0[(tri(T) * 4 + v) * 64 + lane];
   for (int sgi = 1; sgi < rc.nseg; ++sgi) {
-    const float* s = s0 + sgi * (int64_t)SLOT;
-    f32x4 part[tri(T)];
-    float bp[T];
-#pragma unroll
-    for (int t = 0; t < tri(T); ++t) part[t] = reinterpret_cast<const f32x4*>(s)[t * 64 + lane];
-#pragma unroll
-    for (int v = 0; v < T; ++v) bp[v] = s[(tri(T) * 4 + v) * 64 + lane];
-#pragma unroll
-    for (int t = 0; t < tri(T); ++t) acc[t] += part[t];
-#pragma unroll
-    for (int v = 0; v < T; ++v) bcol[v] += bp[v];
+    add_slot<T>(s0 + sgi * (int64_t)SLOT, lane, acc, bcol);
   }
 #pragma unroll
   for (int t = 0; t < tri(T); ++t) reinterpret_cast<f32x4*>(s0)[t * 64 + lane] = acc[t];
@@ -1321,7 +1337,7 @@ __global__ __launch_bounds__(256) void als_prereduce_kernel(SolveParams p) {
 
 // list C: one wave per long row: sum the segment partials (or their group sums) in order, then K3
 template <int T>
-__global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
+__global__ __launch_bounds__(256, T >= 6 ? 2 : 1) void als_finish_kernel(SolveParams p) {  // (T >= 6: without the bound hipcc takes 290-370 registers)
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wave >= p.n_work) return;
@@ -1337,18 +1353,8 @@ __global__ __launch_bounds__(256) void als_finish_kernel(SolveParams p) {
 #pragma unroll
   for (int v = 0; v < T; ++v) bcol[v] = 0.f;
   for (int sgi = 0; sgi < rc.nseg; ++sgi) {
-    // all loads of a segment's slot first (16 bytes per lane and tile), then the adds
     const float* s = p.scratch + (rc.first_slot + (int64_t)sgi * rc.stride) * (int64_t)((tri(T) * 4 + T) * 64);
-    f32x4 part[tri(T)];
-    float bp[T];
-#pragma unroll
-    for (int t = 0; t < tri(T); ++t) part[t] = reinterpret_cast<const f32x4*>(s)[t * 64 + lane];
-#pragma unroll
-    for (int v = 0; v < T; ++v) bp[v] = s[(tri(T) * 4 + v) * 64 + lane];
-#pragma unroll
-    for (int t = 0; t < tri(T); ++t) acc[t] += part[t];
-#pragma unroll
-    for (int v = 0; v < T; ++v) bcol[v] += bp[v];
+    add_slot<T>(s, lane, acc, bcol);
   }
   const int n_u = uniform((int)(p.row_ptr[rc.row + 1] - p.row_ptr[rc.row]));
   // the row's own part first (its largest entry feeds the conditioning estimate), then the shared Gramian under it
