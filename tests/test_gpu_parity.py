@@ -292,8 +292,10 @@ def test_long_rows_split_into_segments_match_unsplit():
     val = rng.integers(1, 6, size=len(col)).astype(np.float32)
     Y0 = (rng.standard_normal((n_items, k)) / np.sqrt(k)).astype(np.float32)
     outs = []
-    for seg in (0, 64, 128):
-        with pkg.ALSCore(k, segment_nnz=seg) as core:
+    # (the 2 999-entry row is 47 segments of 64: more than 32 partial slots, summed in groups first -- als_prereduce_kernel;
+    # chunk_rows = 7 puts the long rows, their slots and their slot groups into different chunks of the work lists)
+    for seg, chunk_rows in ((0, 0), (64, 0), (128, 0), (64, 7)):
+        with pkg.ALSCore(k, segment_nnz=seg, chunk_rows=chunk_rows) as core:
             core.set_factor_rows(pkg.SIDE_X, n_users)
             core.set_factor_rows(pkg.SIDE_Y, n_items)
             core.set_matrix(pkg.SIDE_X, row_ptr, col, val)
@@ -304,6 +306,7 @@ def test_long_rows_split_into_segments_match_unsplit():
     for X in outs:
         assert rel(X, Xo) < REL_TOL, rel(X, Xo)
     assert rel(outs[1], outs[0]) < 1e-5 and rel(outs[2], outs[0]) < 1e-5
+    assert np.array_equal(outs[3], outs[1])     # the same kernels on the same lists, chunk by chunk
 
 
 def test_chunked_upload_equals_single_upload():
