@@ -307,10 +307,26 @@ __global__ __launch_bounds__(256, 2) void rotate_rows_split_kernel(RotateSplitPa
 // (one wave per row, a lane per feature: a thread per element with its 64-bit division ran at 1.9 TB/s on C4's 1.4M
 // empty user rows)
 __global__ void zero_rows_kernel(const WorkItem* __restrict__ items, int64_t n, int k, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
-  float* o = out + (int64_t)items[i].id * k;
-  for (int c = threadIdx.x & 63; c < k; c += 64) o[c] = 0.f;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int ROWS = 8;  // rows per wave
+  if ((k & 3) == 0 && k <= 256) {
+    // 16-byte stores, 64 / (k / 4) rows per instruction (k = 128: two): rows are k floats apart, 16-byte aligned
+    const int lanes_per_row = k >> 2, rows_per_inst = 64 / lanes_per_row;
+    const int sub = lane / lanes_per_row, c4 = lane - sub * lanes_per_row;
+    if (sub >= rows_per_inst) return;
+    for (int r = sub; r < ROWS; r += rows_per_inst) {
+      const int64_t i = wave * ROWS + r;
+      if (i < n) reinterpret_cast<f32x4*>(out + (int64_t)items[i].id * k)[c4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+    for (int r = 0; r < ROWS; ++r) {
+      const int64_t i = wave * ROWS + r;
+      if (i >= n) return;
+      float* o = out + (int64_t)items[i].id * k;
+      for (int c = lane; c < k; c += 64) o[c] = 0.f;
+    }
+  }
 }
 
 // z - (float)h.lo / z - (float)h.hi for a packed f16 pair h: one v_fma_mix_f32 each (f16 source 0, fp32 constant and addend)

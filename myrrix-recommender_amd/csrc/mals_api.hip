@@ -667,7 +667,7 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int whic
     if (int rc = end_timed(h, pe)) return rc;
   }
   if (own && cr.nZ) {
-    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((cr.nZ + 3) / 4)), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((cr.nZ + 31) / 32)), dim3(256), 0, h->stream,  // 8 rows per wave
                        s.itemsA + cr.offA + cr.nA + cr.n_dual(), cr.nZ, p.k, p.out);
   }
   HIPCHK(h, hipGetLastError());
