@@ -71,6 +71,7 @@ struct SolveParams {
                             // else its zero-padded copy (stride ldm = 16 T, pad_rows_kernel): every row starts on a
                             // 64-byte boundary and the last feature block loads like the others
   const float* Gf;          // fp32 image of G in acc layout: [upper tile][lane][reg]
+  const float* Gperm;       // the same image in the feature order of the LDS-staged k = 128 kernels (lds_kernels.h), or null
   float* out;               // this side's factor replica + row_offset*k
   const WorkItem* items;    // list A or B (whichever this launch handles), sorted by length (desc)
   const RowC* rowsC;        // list C
@@ -295,7 +296,10 @@ __device__ __forceinline__ f32x4 tile_ptq_h(const TileH& P, const TileH& Q, f32x
 // K3b: blocked right-looking Cholesky W = U^T U on the upper tiles.  On return the off-diagonal
 // tiles hold U_ij and the diagonal tiles hold U_ii^{-1}.  TRSM and SYRK run on the matrix cores.
 // SPLIT: the SYRK products on the f16 matrix pipe (the caller has scaled the system, row_scale).
-template <int T, bool SPLIT = false>
+#ifndef MALS_SYRK_RESPLIT_MINT
+#define MALS_SYRK_RESPLIT_MINT 8
+#endif
+template <int T, bool SPLIT = false, bool RESPLIT = (T >= MALS_SYRK_RESPLIT_MINT)>
 __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
 #pragma unroll
   for (int kb = 0; kb < T; ++kb) {
@@ -306,10 +310,7 @@ __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, f
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       acc[tidx(T, kb, j)] = tile_ptq(Uinv, acc[tidx(T, kb, j)], zero);
     }
-#ifndef MALS_SYRK_RESPLIT_MINT
-#define MALS_SYRK_RESPLIT_MINT 8
-#endif
-    if constexpr (SPLIT && T >= MALS_SYRK_RESPLIT_MINT) {
+    if constexpr (SPLIT && RESPLIT) {
       // T = 8: the split tiles of block row kb are made where they are used instead of being kept in q[T] -- 28 registers
       // next to 144 accumulators and the next row's 32 raw registers in flight.  +56 split_tile per row (~670 VALU),
       // 42 -> 15 spilled dwords, and the spill traffic was the larger cost: c5rank 168.2 -> 164.6 ms, its user-half
@@ -968,7 +969,9 @@ __device__ __forceinline__ float row_scale(f32x4 (&acc)[tri(T)], float (&bcol)[T
 // features is as ill-conditioned as anything (sweep cases 2145, 2550) and loses ~1e-6 per unit on the split-f16
 // factorization (case 3047): there the whole of W counts in full and the limit is a quarter (host).  Rows above
 // refine_limit are marked.
-template <int T>
+// PERM: xcol is in the feature order of lds_kernels.h (block v, lane c <-> feature 8c + (v ^ 4 (c >> 3)), T = 8, k = 128):
+// lane (g, c), g < 2, holds features 8c + 4g .. 8c + 4g + 3 in blocks 0..3 or 4..7 and writes them as 16 bytes
+template <int T, bool PERM = false>
 __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T], float minpiv, float wmax, int row, int lane) {
   if (!(minpiv > p.sing_threshold)) {
     // an fp32 pivot at the threshold is rounding noise once cond(W) passes ~1e7: the verdict belongs to the fp64
@@ -997,7 +1000,18 @@ __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T]
   // xcol[v] is the same in all four lane groups: group g writes blocks g, 4 + g -- (T + 3) / 4 full-wave stores, and only a
   // store that can reach the last block needs the feature bound (k > 16 (T - 1)); T quarter-wave stores under T
   // hoisted predicates cost 190-250 instructions per row, most of them reloads of spilled exec masks
-  {
+  if constexpr (PERM) {
+    static_assert(T == 8, "the permuted feature order belongs to the k = 128 kernels");
+    float* o = p.out + (int64_t)row * p.k;
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));
+    const int g = l2 >> 4, c = l2 & 15;
+    const bool hi = ((g ^ (c >> 3)) & 1) != 0;
+    f32x4 x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = hi ? xcol[4 + q] : xcol[q];
+    if (g < 2) *reinterpret_cast<f32x4*>(o + 8 * c + 4 * g) = x;
+  } else {
     float* o = p.out + (int64_t)row * p.k;
     int l2 = lane;
     asm volatile("" : "+v"(l2));  // (the masks and offsets below recomputed here, not kept live from the top of the row loop)
@@ -1013,16 +1027,16 @@ __device__ __forceinline__ void store_row(const SolveParams& p, float (&xcol)[T]
 }
 
 // ridge + factor + solve + store, no prefetch hook (used by the long-row finish kernel)
-template <int T>
+template <int T, bool PERM = false>
 __device__ __forceinline__ void finish_row(const SolveParams& p, f32x4 (&acc)[tri(T)], const float (&bcol)[T],
                                            int n_u, int row, int lane, float rmax = 0.f) {
-  add_ridge<T>(p, acc, n_u, lane);
+  add_ridge<T, PERM>(p, acc, n_u, lane);   // (PERM implies k = 128 = 16 T: the ridge is a plain diagonal)
   float minpiv = 3.0e38f;
   float xcol[T];
   const float wmax = fmaxf(rmax, p.gramian_weight * __int_as_float(max_entry_bits<T>(acc, lane)));
   cholesky_tiles<T>(acc, lane, minpiv);
   solve_tiles<T>(acc, bcol, xcol, lane);
-  store_row<T>(p, xcol, minpiv, wmax, row, lane);
+  store_row<T, PERM>(p, xcol, minpiv, wmax, row, lane);
 }
 
 __device__ __forceinline__ WorkItem load_item(const SolveParams& p, int64_t it) {
@@ -1336,11 +1350,15 @@ __global__ __launch_bounds__(256) void als_prereduce_kernel(SolveParams p) {
 }
 
 // list C: one wave per long row: sum the segment partials (or their group sums) in order, then K3
-template <int T>
+// PERM: the partial slots come from als_lds_kernel_h<1> (lds_kernels.h) -- its feature order, its Gramian image
+template <int T, bool PERM = false>
 __global__ __launch_bounds__(256, T >= 6 ? 2 : 1) void als_finish_kernel(SolveParams p) {  // (T >= 6: without the bound hipcc takes 290-370 registers)
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wave >= p.n_work) return;
+  // the slots are in the order of whichever segments kernel ran: the LDS-staged one (range flag set) or its fp32 twin
+  if (PERM && p.zscale[2] == 0.f) return;
+  if (!PERM && (p.flags & 8) && p.zscale[2] != 0.f) return;
   RowC rc = p.rowsC[wave];
   rc.first_slot = uniform64(rc.first_slot);
   rc.row = uniform(rc.row);
@@ -1360,11 +1378,11 @@ __global__ __launch_bounds__(256, T >= 6 ? 2 : 1) void als_finish_kernel(SolvePa
   // the row's own part first (its largest entry feeds the conditioning estimate), then the shared Gramian under it
   const float rmax = p.refine_flag ? __int_as_float(max_entry_bits<T>(acc, lane)) : 0.f;
   if (!(p.flags & 2)) {
-    const f32x4* G4 = reinterpret_cast<const f32x4*>(p.Gf) + lane;
+    const f32x4* G4 = reinterpret_cast<const f32x4*>(PERM ? p.Gperm : p.Gf) + lane;
 #pragma unroll
     for (int t = 0; t < tri(T); ++t) acc[t] += G4[t * 64];
   }
-  finish_row<T>(p, acc, bcol, n_u, rc.row, lane, rmax);
+  finish_row<T, PERM>(p, acc, bcol, n_u, rc.row, lane, rmax);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 #include "../../include/myrrix_als.h"
 #include "als_kernels.h"
 #include "dual_kernels.h"
+#include "lds_kernels.h"
 #include "host_eigen.h"
 #include "host_solver.h"
 #include "topn_kernels.h"
@@ -149,6 +150,13 @@ struct mals_handle_s {
   int dual_side = -1;         // what the rotated copy currently holds: solved side, version of the opposite G
   uint64_t dual_version = 0;
   bool dual_ok = false;       // the half-iteration's systems qualify for the dual path
+  // k = 128 with the split-precision gather: the rows / segments kernels that stage the gather through LDS (lds_kernels.h)
+  // and the Gramian image in their feature order (all zeros under lossIgnoresUnspecified), rebuilt when the opposite
+  // side's Gramian changes
+  bool lds_gather = false;
+  float* d_Gperm = nullptr;
+  int gperm_side = -1;
+  uint64_t gperm_version = 0;
   float* d_zscale = nullptr;  // {S, 1/S^2} of the split-precision gather (gather_scale_kernel)
   int zs_side = -1;           // what d_zscale currently holds: solved side, version of the opposite G, value bound
   uint64_t zs_version = 0;
@@ -674,8 +682,77 @@ int launch_lists(mals_handle h, SideState& s, SolveParams p, int chunk, int whic
   return MALS_OK;
 }
 
+// the persistent launch of an LDS-staged kernel (lds_kernels.h): one wave per workgroup, LDS-limited to 8 per CU, the same
+// 16x oversubscription as persistent_grid
+template <typename K, typename KF>
+int launch_persistent_lds(mals_handle h, K kernel, KF fallback, const SolveParams& p, int kind, double bytes) {
+  PendingEvent pe;
+  int per_cu = 8 * 16;
+  if (const char* e = std::getenv("MALS_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e)) * 4;  // tuning override (in 256-thread blocks)
+  unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(p.n_work, (int64_t)h->n_cu * per_cu));
+  if (int rc = begin_timed(h, kind, bytes, pe)) return rc;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, h->stream, p);
+  SolveParams pf = p;
+  pf.flags |= 8;
+  if (int rc = persistent_grid(h, fallback, p.n_work, &grid)) return rc;
+  grid = std::min<unsigned>(grid, (unsigned)h->n_cu * 8u);   // (as launch_persistent: the twin almost always returns at once)
+  hipLaunchKernelGGL(fallback, dim3(grid), dim3(256), 0, h->stream, pf);
+  return end_timed(h, pe);
+}
+
+// launch_lists for k = 128 through the LDS-staged kernels.  Their partial slots are in the kernels' own feature order, the
+// fp32 twins' (range flag 0) in the plain one: both finish kernels are enqueued and the range flag decides on the device
+// which of the two runs (bit 3 again: "only if the split-precision launch did not run").
+int launch_lists_lds(mals_handle h, SideState& s, SolveParams p, int chunk, int which) {
+  constexpr int T = 8, D = 2;
+  const double per = 4.0 * p.k + 8.0;
+  const SideState::ChunkRange& cr = s.chunks[(size_t)chunk];
+  PendingEvent pe;
+  const bool own = which & LISTS_ROWS, longs = which & LISTS_LONG, dual_rows_too = which & LISTS_DUAL_ROWS;
+  if (longs && cr.nB) {
+    p.n_work = cr.nB;
+    p.items = s.itemsB + cr.offB;
+    if (int rc = launch_persistent_lds(h, als_lds_kernel_h<1>, als_persistent_kernel<T, D, 1, true>, p, 1, (double)cr.nnzB * per)) return rc;
+  }
+  if (own && cr.nA) {
+    p.n_work = cr.nA;
+    p.items = s.itemsA + cr.offA;
+    if (int rc = launch_persistent_lds(h, als_lds_kernel_h<0>, als_persistent_kernel<T, D, 0, true>, p, 0, (double)cr.nnzA * per + (double)cr.nA * per)) return rc;
+  }
+  if (dual_rows_too && cr.n_dual()) {
+    p.n_work = cr.n_dual();
+    p.items = s.itemsA + cr.offA + cr.nA;
+    if (int rc = launch_persistent_lds(h, als_lds_kernel_h<0>, als_persistent_kernel<T, D, 0, true>, p, 0,
+                                       (double)cr.nnz_dual() * per + (double)cr.n_dual() * per)) return rc;
+  }
+  if (longs && cr.nC) {
+    if (int rc = begin_timed(h, 2, (double)cr.nC * per, pe)) return rc;
+    if (cr.nP) {
+      p.n_work = cr.nP;
+      p.rowsC = s.rowsC + cr.offP;
+      hipLaunchKernelGGL(als_prereduce_kernel<T>, dim3((unsigned)((cr.nP + 3) / 4)), dim3(256), 0, h->stream, p);
+    }
+    p.n_work = cr.nC;
+    p.rowsC = s.rowsC + cr.offC;
+    hipLaunchKernelGGL((als_finish_kernel<T, true>), dim3((unsigned)((cr.nC + 3) / 4)), dim3(256), 0, h->stream, p);
+    SolveParams pf = p;
+    pf.flags |= 8;
+    hipLaunchKernelGGL((als_finish_kernel<T, false>), dim3((unsigned)((cr.nC + 3) / 4)), dim3(256), 0, h->stream, pf);
+    if (int rc = end_timed(h, pe)) return rc;
+  }
+  if (own && cr.nZ) {
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((cr.nZ + 31) / 32)), dim3(256), 0, h->stream,
+                       s.itemsA + cr.offA + cr.nA + cr.n_dual(), cr.nZ, p.k, p.out);
+  }
+  HIPCHK(h, hipGetLastError());
+  return MALS_OK;
+}
+
 template <int T, int D, bool FULL>
 int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk, int which) {
+  if constexpr (T == 8 && FULL) {
+    if (h->split_f16 && h->lds_gather && p.Gperm) return launch_lists_lds(h, s, p, chunk, which);
+  }
   if (h->split_f16)
     return launch_lists(h, s, p, chunk, which, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>,
                         als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>,
@@ -1446,6 +1523,8 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
     return MALS_HIP_ERROR;
   }
   if (const char* e = std::getenv("MALS_REFINE_LIMIT")) h->refine_limit = std::max(0.f, (float)std::atof(e));
+  h->lds_gather = h->cfg.features == 128;   // the LDS-staged rows / segments kernels (lds_kernels.h); MALS_LDS_GATHER=0: A/B against the register-staged ones
+  if (const char* e = std::getenv("MALS_LDS_GATHER")) h->lds_gather = h->lds_gather && std::atoi(e) != 0;
   if (const char* e = std::getenv("MALS_OVERLAP")) h->overlap = std::atoi(e) != 0;
   if (h->overlap) {
     bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -1503,6 +1582,7 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_Gref);
   free_dev(h->d_gref_part);
   free_dev(h->d_zscale);
+  free_dev(h->d_Gperm);
   free_dev(h->d_maxabs);
   free_dev(h->d_colrange);
   free_dev(h->d_Mr);
@@ -1965,6 +2045,21 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
     p.ldm = 16 * h->T;
   }
   p.Gf = o.Gf;
+  p.Gperm = nullptr;
+  if (h->lds_gather && h->split_f16 && k == 128) {
+    if (!h->d_Gperm) HIPCHK(h, hipMalloc(&h->d_Gperm, sizeof(float) * (size_t)tri(8) * 256));
+    if (!resume && (h->gperm_side != side || h->gperm_version != o.G_version)) {
+      if (h->cfg.flags & MALS_FLAG_LOSS_IGNORES_UNSPECIFIED) {  // W does not start from G (ALS:524-539): an image of zeros
+        HIPCHK(h, hipMemsetAsync(h->d_Gperm, 0, sizeof(float) * (size_t)tri(8) * 256, h->stream));
+      } else {
+        hipLaunchKernelGGL(gramian_perm_kernel, dim3((unsigned)tri(8)), dim3(256), 0, h->stream, o.G, k, h->d_Gperm);
+        HIPCHK(h, hipGetLastError());
+      }
+      h->gperm_side = side;
+      h->gperm_version = o.G_version;
+    }
+    p.Gperm = h->d_Gperm;
+  }
   p.out = s.F + s.row_offset * k;
   p.items = nullptr;
   p.rowsC = s.rowsC;

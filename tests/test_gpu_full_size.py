@@ -25,6 +25,19 @@ def rel(a, b):
                  max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
+def independent_gramian(M, torch, dev, chunk=1_000_000):
+    """M^T M in fp64 by torch (a matmul of the widened rows, chunk by chunk) -- a checker that shares no code with the
+    library's Gramian kernels: what the oracle is handed where its own O(n k^2) pass does not finish in test time."""
+    G = None
+    n = M.shape[0]
+    for r0 in range(0, n, chunk):
+        blk = M[r0:r0 + chunk]
+        blk = (blk if torch.is_tensor(blk) else torch.as_tensor(blk)).to(dev).double()
+        part = blk.T @ blk
+        G = part if G is None else G + part
+    return G.cpu().numpy()
+
+
 def sub_csr(csr, rows, torch):
     rp = csr[0]
     rows_t = torch.as_tensor(rows, device=rp.device)
@@ -96,7 +109,11 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
         # --- X half (the oracle gets ITS OWN Gramian of the same Y0 wherever it can compute one in test time)
         core.solve_side(pkg.SIDE_X)
         core.check()
-        G_for_oracle = oracle.gramian(Y0) if n_items <= 1_000_000 else Gy
+        if n_items <= 1_000_000:
+            G_for_oracle = oracle.gramian(Y0)
+        else:   # not the library's own Gramian: an fp64 matmul on the device (and the two must agree)
+            G_for_oracle = independent_gramian(prob["Y0"], torch, dev)
+            assert rel(Gy, G_for_oracle) < 5e-7
         max_len_x = check_half(core, pkg.SIDE_X, prob["r_csr"], Y0, G_for_oracle, n_users, rng, torch)
 
         # --- Gramian of X: linearity over row ranges (what the k x k all-reduce relies on) + oracle on a slice
@@ -122,7 +139,11 @@ def test_full_size_half_iterations(name, n_users, n_items, nnz, k):
         assert np.all(np.isfinite(X))
         core.solve_side(pkg.SIDE_Y)
         core.check()
-        G_for_oracle = oracle.gramian(X) if n_users <= 1_000_000 else Gx
+        if n_users <= 1_000_000:
+            G_for_oracle = oracle.gramian(X)
+        else:
+            G_for_oracle = independent_gramian(X, torch, dev)
+            assert rel(Gx, G_for_oracle) < 5e-7
         max_len_y = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, G_for_oracle, n_items, rng, torch)
         if "C4" in name or "C3" in name:
             assert max_len_y > 4096, "C3 / C4 must exercise the long-row (segments) path"
@@ -168,7 +189,9 @@ def test_c5_rank_at_its_true_shape():
         core.gramian_partial(pkg.SIDE_Y, 12_345, 1_000_000, gs)
         torch.cuda.synchronize()
         assert rel(gs.cpu().numpy(), oracle.gramian(Y[12_345:1_012_345].cpu().numpy())) < 5e-7
-        check_half(core, pkg.SIDE_X, prob["r_csr"], Y, Gy, n_users, rng, torch, row_offset=u_off)
+        Gy_indep = independent_gramian(Y, torch, dev)   # the checker's own: an fp64 matmul, not the library's kernels
+        assert rel(Gy, Gy_indep) < 5e-7
+        check_half(core, pkg.SIDE_X, prob["r_csr"], Y, Gy_indep, n_users, rng, torch, row_offset=u_off)
 
         # --- item half: rows [i_off, i_off + 1.25M) of Y from the 100M-row X (the freshly solved user rows included)
         drv.half_iteration(pkg.SIDE_Y)
@@ -179,7 +202,9 @@ def test_c5_rank_at_its_true_shape():
         core.gramian_partial(pkg.SIDE_X, u_off + 777, 200_000, gs)
         torch.cuda.synchronize()
         assert rel(gs.cpu().numpy(), oracle.gramian(X[u_off + 777:u_off + 200_777].cpu().numpy())) < 5e-7
-        max_len = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, Gx, n_items, rng, torch, row_offset=i_off)
+        Gx_indep = independent_gramian(X, torch, dev)   # 100M x 128: 100 chunks of 1 GB in fp64
+        assert rel(Gx, Gx_indep) < 5e-7
+        max_len = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, Gx_indep, n_items, rng, torch, row_offset=i_off)
         assert max_len > 4096, "the popular items of the slice go through the long-row (segments) path"
 
         st = core.stats()

@@ -28,6 +28,25 @@ def rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
+# Next to the whole-matrix bar: no single row further than this from the oracle's (relative to its own norm; rows of
+# next to no weight -- empty rows solve to 0 -- against a hundredth of the matrix' rms row norm).  A Frobenius bar alone
+# lets one row of 900 be 3e-3 off; the refine / exact safety net (store_row's estimate) is an envelope tuned on 10 000
+# seeds, not a bound, and a per-row assertion is what catches its first miss.  The largest value seen in a session is
+# printed at its end (conftest.py: pytest_terminal_summary).
+ROW_TOL = 1e-3
+WORST_ROW = {"value": 0.0, "where": None}
+
+
+def worst_row(a, b, where=None):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    nb = np.linalg.norm(b, axis=1)
+    floor = 1e-2 * float(np.sqrt(np.mean(nb * nb))) + 1e-30
+    w = float(np.max(np.linalg.norm(a - b, axis=1) / np.maximum(nb, floor))) if len(a) else 0.0
+    if w > WORST_ROW["value"]:
+        WORST_ROW["value"], WORST_ROW["where"] = w, where
+    return w
+
+
 def draw_case(seed):
     rng = np.random.default_rng(100_000 + seed)
     k = int(rng.choice([1, 2, 3, 5, 8, 10, 15, 16, 17, 20, 24, 30, 31, 32, 33, 40, 47, 48, 49, 50, 63, 64, 65, 72, 80, 96, 97, 100,
@@ -114,6 +133,7 @@ def test_seeded_configuration_sweep(seed):
         X = core.get_factors(pkg.SIDE_X)
         assert np.all(np.isfinite(X))
         assert rel(X, Xo) < REL_TOL, (seed, k, cfg, rel(X, Xo))
+        assert worst_row(X, Xo, ("sweep X", seed)) < ROW_TOL, (seed, k, cfg, worst_row(X, Xo))
         # the second half from the SAME input as the oracle's: some of these item systems have cond(W) ~ 1e7, where
         # the 4e-7 by which X differs from Xo moves Y by 1e-2 -- in the reference just as here (its own answer is
         # 1e-2 away from exact arithmetic on seed 1085); parity is a statement about one half-iteration
@@ -128,6 +148,7 @@ def test_seeded_configuration_sweep(seed):
         Y = core.get_factors(pkg.SIDE_Y)
     assert np.all(np.isfinite(Y))
     assert rel(Y[:n_items], Yo) < REL_TOL, (seed, k, cfg, rel(Y[:n_items], Yo))
+    assert worst_row(Y[:n_items], Yo, ("sweep Y", seed)) < ROW_TOL, (seed, k, cfg, worst_row(Y[:n_items], Yo))
     if n_stale:
         assert np.array_equal(Y[n_items:], Y0[n_items:])   # stale rows are never re-solved (ALS:304-308)
 
@@ -165,6 +186,7 @@ def test_seeded_sweep_two_chained_halves(seed):
         X, Y = core.get_factors(pkg.SIDE_X), core.get_factors(pkg.SIDE_Y)
     assert rel(X, Xo) < REL_TOL, (seed, k, cfg, rel(X, Xo))
     assert rel(Y[:n_items], Yo) < REL_TOL, (seed, k, cfg, rel(Y[:n_items], Yo))
+    assert worst_row(X, Xo, ("chained X", seed)) < ROW_TOL and worst_row(Y[:n_items], Yo, ("chained Y", seed)) < ROW_TOL, (seed, k, cfg)
 
 
 # ---- call() (ALS:176-262): iteration count, convergence value and factors over several iterations ---------------------
@@ -224,6 +246,7 @@ def test_full_call_sweep(seed):
     assert it == it_o, (seed, k, cfg, it, it_o)
     assert abs(conv - conv_o) <= 1e-3 * max(abs(conv_o), 1e-6), (conv, conv_o)
     assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL, (seed, k, cfg, rel(X, Xo), rel(Y, Yo))
+    assert worst_row(X, Xo, ("call X", seed)) < ROW_TOL and worst_row(Y, Yo, ("call Y", seed)) < ROW_TOL, (seed, k, cfg)
 
 
 @pytest.mark.parametrize("seed", range(40, 64))
@@ -250,3 +273,4 @@ def test_group_sweep(seed):
         X = g.get_factors(pkg.SIDE_X, 0, n_users)
         Y = g.get_factors(pkg.SIDE_Y, 0, n_items)
     assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL, (seed, world, chunks, k, cfg, rel(X, Xo), rel(Y, Yo))
+    assert worst_row(X, Xo, ("group X", seed)) < ROW_TOL and worst_row(Y, Yo, ("group Y", seed)) < ROW_TOL, (seed, world, chunks, k, cfg)
