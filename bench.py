@@ -37,6 +37,10 @@ WORKLOADS = {
     # each) against the full 10M x 64 X -- what one rank computes per iteration when the exchange is free
     "c4rank": (1_250_000, 125_000, 250_000_000, 64, "one rank of C4 at 8 GPUs, both slices at true shape: 1.25M user rows x 1M items (125M entries) "
                "+ 125K item rows x 10M users (125M entries) gathering from the full 10M x 64 X replica (2.56 GB), k=64"),
+    # C5 WHOLE on one device (100M x 10M, 5e9 entries, k=128): ~80 GB of CSR + CSC, 56 GB of factors -- fits
+    # the 288 GB of one MI355X.  The N = 1 anchor of a C5 scaling curve and the first handle with more than 2^31 entries.
+    # Generated range by range (synth.torch_problem_sliced: one-shot generation does not fit next to the problem).
+    "c5": (100_000_000, 10_000_000, 5_000_000_000, 128, "C5 synthetic 100M x 10M, 5e9 interactions, k=128, WHOLE on one GPU"),
     "k128long": (1_000_000, 100_000, 400_000_000, 128, "k=128 with long rows (1M x 100K, 400M interactions requested)"),
     "k112": (2_000_000, 200_000, 200_000_000, 112, "k=112 (2M x 200K, 200M interactions requested)"),
     "k30": (10_000_000, 1_000_000, 1_000_000_000, 30, "the reference's default feature count on the C4 shape (10M x 1M, 1e9 interactions requested, k=30)"),
@@ -47,43 +51,60 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, budget_rows=(100000, 10000)):
-    """Reference's CPU path, restated (oracle = "port"), timed on this host's cores on a bounded
-    random sample of rows and extrapolated by row count.  The Gramian (serial in the reference,
-    ALS:342 -> MU:219-239) is timed on a row sample too."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, min_seconds=2.0, units_per_thread=16):
+    """Reference's CPU path, restated (oracle = "port"), timed on this host's cores on a bounded random sample of rows
+    and extrapolated by row count.  The sample is sized by TIME, not by count: per side at least `units_per_thread` of the
+    reference's 100-row work units (ALS:77, ALS:398-408) for every thread -- so that no thread of a 256-thread host sits
+    idle, as it did with a fixed 10 000-row sample -- doubled until the side's solve runs `min_seconds` (or every row is in
+    it).  The Gramian (serial in the reference, ALS:342 -> MU:219-239) is timed on a row sample too."""
     import numpy as np
     from oracle import oracle
     threads = os.cpu_count() or 1
     rng = np.random.default_rng(1234567890)
     total_t = 0.0
     sample_desc = []
-    for side, csr, M, n_rows, n_s in ((0, prob["r_csr"], Y, n_users, budget_rows[0]),
-                                      (1, prob["c_csr"], X, n_items, budget_rows[1])):
-        n_s = min(n_s, n_rows)
-        rows = torch.from_numpy(np.sort(rng.choice(n_rows, size=n_s, replace=False))).to(csr[0].device)
-        rp = csr[0]
-        lens = rp[rows + 1] - rp[rows]
-        sub_rp = torch.zeros(n_s + 1, dtype=torch.int64, device=rp.device)
-        torch.cumsum(lens, 0, out=sub_rp[1:])
-        # expand entry indices of the sampled rows
-        starts = rp[rows]
-        ent = torch.repeat_interleave(starts - sub_rp[:-1], lens) + torch.arange(int(sub_rp[-1]), device=rp.device)
-        sub_col = csr[1][ent].cpu().numpy()
-        sub_val = csr[2][ent].cpu().numpy()
-        sub_rp = sub_rp.cpu().numpy()
+    for side, csr, M, n_rows in ((0, prob["r_csr"], Y, n_users), (1, prob["c_csr"], X, n_items)):
         Mh = M.cpu().numpy()
         g_rows = min(Mh.shape[0], 200000)
         t0 = time.perf_counter()
         G = oracle.gramian(Mh[:g_rows])
         t_g = (time.perf_counter() - t0) * (Mh.shape[0] / g_rows)
         G = G * (Mh.shape[0] / g_rows)  # keep the systems well-posed for the timing run
-        t0 = time.perf_counter()
-        oracle.solve_rows(sub_rp, sub_col, sub_val, Mh, G, threads=threads)
-        t_s = (time.perf_counter() - t0) * (n_rows / n_s)
+        rp = csr[0]
+        perm = rng.permutation(n_rows)
+        n_s = min(n_rows, units_per_thread * 100 * threads)
+        while True:
+            rows = torch.from_numpy(np.sort(perm[:n_s])).to(rp.device)
+            lens = rp[rows + 1] - rp[rows]
+            sub_rp = torch.zeros(n_s + 1, dtype=torch.int64, device=rp.device)
+            torch.cumsum(lens, 0, out=sub_rp[1:])
+            # expand entry indices of the sampled rows
+            ent = torch.repeat_interleave(rp[rows] - sub_rp[:-1], lens) + torch.arange(int(sub_rp[-1]), device=rp.device)
+            sub_col = csr[1][ent].cpu().numpy()
+            sub_val = csr[2][ent].cpu().numpy()
+            sub_rp_h = sub_rp.cpu().numpy()
+            del ent, lens, rows, sub_rp
+            t0 = time.perf_counter()
+            oracle.solve_rows(sub_rp_h, sub_col, sub_val, Mh, G, threads=threads)
+            t_run = time.perf_counter() - t0
+            if t_run >= min_seconds or n_s >= n_rows or len(sub_col) > 600_000_000:
+                break
+            n_s = min(n_rows, max(2 * n_s, int(n_s * 1.3 * min_seconds / max(t_run, 1e-3))))
+        t_s = t_run * (n_rows / n_s)
         total_t += t_g + t_s
-        sample_desc.append("%d of %d %s rows (%d entries) + Gramian on %d of %d rows" %
-                           (n_s, n_rows, "user" if side == 0 else "item", len(sub_col), g_rows, Mh.shape[0]))
-    return {"value": (n_users + n_items) / total_t, "unit": "rows/s", "cores": threads, "kind": "port",
+        sample_desc.append("%d of %d %s rows (%d entries, %.1f work units of 100 rows per thread, %.2f s) + Gramian on %d of %d rows" %
+                           (n_s, n_rows, "user" if side == 0 else "item", len(sub_col), n_s / 100.0 / threads, t_run, g_rows, Mh.shape[0]))
+    return {"value": (n_users + n_items) / total_t, "unit": "rows/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
             "sample": "; ".join(sample_desc) + "; per-side times extrapolated by row count; Gramian single-threaded as in the reference"}
 
 
@@ -202,11 +223,14 @@ class RankDriver:
         return self.F[side]
 
 
-def unplanted_leg(torch, pkg, sharded, synth, n_users, n_items, nnz_req, k, args, gmode, smode, local_rank, device):
+def unplanted_leg(torch, pkg, sharded, synth, n_users, n_items, nnz_req, k, args, gmode, smode, local_rank, device, prob=None, label=None):
     """The same measurement on the plain SURVEY 8(d) workload (power-law item popularity, log-normal user activity, values
     1..5, NOTHING planted), beside the headline: the planted part makes 30 % of the X-half's gathers hit 2048 hot item rows
-    and moves ~110M entries onto the long-row kernel.  One GPU, same build, same steps."""
-    prob = synth.torch_problem(n_users, n_items, nnz_req, k, device, planted=0.0)
+    and moves ~110M entries onto the long-row kernel.  One GPU, same build, same steps.
+    With `prob` given: the same measurement on THAT problem under another arithmetic mode (roofline_fp32)."""
+    own = prob is None
+    if own:
+        prob = synth.torch_problem(n_users, n_items, nnz_req, k, device, planted=0.0)
     core = pkg.ALSCore(k, alpha=1.0, lam=0.1, device=local_rank, segment_nnz=args.segment_nnz, gramian_mode=gmode, solve_mode=smode)
     core.set_stream(torch.cuda.current_stream().cuda_stream)
     als = sharded.ShardedALS(core, n_users, n_items, k, rank=0, world=1, device=device)
@@ -231,15 +255,18 @@ def unplanted_leg(torch, pkg, sharded, synth, n_users, n_items, nnz_req, k, args
     achieved = st["rows_bytes"] / n_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     it_bytes = (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps
     ms = 1e3 * elapsed / args.steps
-    out = {"workload": "the same shape with nothing planted (SURVEY.md 8(d) as written)", "nnz": int(prob["nnz"]),
+    out = {"workload": label or "the same shape with nothing planted (SURVEY.md 8(d) as written)", "nnz": int(prob["nnz"]),
            "ms_per_step": ms, "value": (n_users + n_items) / (elapsed / args.steps), "unit": "rows/s",
            "kernel": "rows kernel (als_persistent_kernel_h, MODE 0)", "avg_launch_ms": avg_ms, "achieved": achieved, "peak": HBM_PEAK_GBS,
            "frac": achieved / HBM_PEAK_GBS, "iteration_frac": it_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian", "dual", "rotate")},
            "rows_refined_per_step": st["rows_refined"] / args.steps,
            "_all_rows_launches": (warm["rows_launches"] + st["rows_launches"], warm["rows_ms"] + st["rows_ms"])}
+    out["gather_scale"] = core.gather_scale() if gmode != 1 else None
     core.close()
-    del als, prob
+    del als
+    if own:
+        del prob
     torch.cuda.empty_cache()
     return out
 
@@ -264,6 +291,9 @@ def main():
                          "(power-law item popularity, log-normal user activity, values 1..5, nothing planted)")
     ap.add_argument("--no-unplanted", action="store_true",
                     help="N=1: skip the second, untimed-by-the-headline leg on the un-planted workload (roofline_unplanted)")
+    ap.add_argument("--one-compute-stream", action="store_true",
+                    help="group path: solve every chunk on ONE compute stream (A/B against the default, two alternating streams)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="N=1: skip the leg that re-runs the workload with --gramian-mode fp32 (roofline_fp32)")
     ap.add_argument("--exchange-chunks", type=int, default=4,
                     help="N>1: solve each slice in this many row chunks and all-gather a finished chunk while the next is solved")
     args = ap.parse_args()
@@ -322,6 +352,9 @@ def main():
     t_gen = time.perf_counter()
     if rank_shape:
         prob = rank_problem(torch, synth, n_users, n_items, nnz_req // 2, k, device, world_emulated=8, planted=args.planted)
+    elif args.workload == "c5":
+        assert world == 1, "the c5 workload is the whole problem on ONE device"
+        prob = synth.torch_problem_sliced(n_users, n_items, nnz_req, k, device, slices=8)
     else:
         prob = synth.torch_problem(n_users, n_items, nnz_req, k, device, planted=args.planted)
     torch.cuda.synchronize()
@@ -344,6 +377,8 @@ def main():
         grp = pkg.GroupALS.from_torch_distributed(k, local_rank, alpha=1.0, lam=0.1, segment_nnz=args.segment_nnz, gramian_mode=gmode,
                                                   solve_mode=smode, exchange_chunks=args.exchange_chunks, world=world, rank=rank,
                                                   one_rank_communicator=force)
+        if args.one_compute_stream:
+            grp.set_alternate_streams(False)
         grp.set_factor_rows(pkg.SIDE_X, n_users)
         grp.set_factor_rows(pkg.SIDE_Y, n_items)
         grp.set_matrix(pkg.SIDE_X, *prob["r_csr"])
@@ -409,7 +444,16 @@ def main():
     core.check()
     st = core.stats()
     add_tally(st)
+    # the same loop with the status check of every half-iteration INSIDE the timed region (mals_check: one D2H of the
+    # bad-row / suspect words + a stream sync per half, what mals_factorize and the group path always pay; ALS:346-361)
+    barrier()
+    t0 = time.perf_counter()
+    als.iterate(args.steps, check=True)
+    barrier()
+    elapsed_chk = time.perf_counter() - t0
+    add_tally(core.stats())
     core.enable_timing(False)
+    gscale = core.gather_scale()
     # untimed diagnostic pass: per-half kernel times (not part of the measured region)
     halves = {}
     if os.environ.get("MALS_BENCH_SPLIT", "1") == "1":
@@ -442,9 +486,9 @@ def main():
     rec_sum, rec_cnt = core.reconstruction_error()
     own_elapsed = elapsed
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
+        t = torch.tensor([elapsed, elapsed_chk], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_chk = float(t[0].item()), float(t[1].item())
         q = torch.tensor([rec_sum, float(rec_cnt)], dtype=torch.float64, device=red_device)
         dist.all_reduce(q)
         rec_sum, rec_cnt = float(q[0].item()), int(q[1].item())
@@ -514,6 +558,9 @@ def main():
             "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            # the same K steps again with mals_check after every half-iteration inside the timed region
+            "ms_per_step_with_check": 1e3 * elapsed_chk / args.steps,
+            "value_with_check": (n_users + n_items) / (elapsed_chk / args.steps),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -549,6 +596,9 @@ def main():
                         "effective_TFLOPs": (st["gramian_bytes"] / (4.0 * k)) * (T_blocks * (T_blocks + 1) // 2) * 512.0 / max(st["gramian_ms"], 1e-9) / 1e9,
                         "mfma_busy_frac": gram_busy,
                         "mfma_busy_source": "profiles/pmc_traffic.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), the Gramian kernel with the most time)" if gram_busy is not None else None},
+            # {S, 1/S^2, range flag, bound on |y|} of the last split-precision gather: flag 1 = the split-f16 kernels ran, 0 = their
+            # fp32 twins (c5rank / c4rank install the Gramian through mals_set_gramian: the bound is sqrt(max G_ff) there)
+            "gather_scale": gscale,
             "rows_dual_per_step": st["rows_dual"] / args.steps,
             "rows_refined_per_step": st["rows_refined"] / args.steps,   # ill-conditioned rows re-solved with fp64 residuals
             "eigen_host_ms_per_step": st["eigen_host_ms"] / args.steps,
@@ -568,6 +618,7 @@ def main():
         if one_device or transport:
             out["INVALID_AS_A_MEASUREMENT"] = ("test run: MALS_BENCH_ONE_DEVICE=%s (all ranks on device 0), MALS_BENCH_TRANSPORT=%s"
                                                % (os.environ.get("MALS_BENCH_ONE_DEVICE", "0"), transport or ""))
+        big = args.workload == "c5"    # no second problem / second arithmetic next to 200 GB of resident data
         if world == 1 and not rank_shape and not force and args.planted > 0 and prob.get("planted") and not args.no_unplanted:
             out["roofline_unplanted"] = unplanted_leg(torch, pkg, sharded, synth, n_users, n_items, nnz_req, k, args, gmode, smode, local_rank, device)
             out["roofline_unplanted"]["slower_than_planted_by"] = out["roofline_unplanted"]["ms_per_step"] / ms_per_step - 1.0
@@ -580,7 +631,16 @@ def main():
         # process (warm-up, timed, the untimed per-half pass, and the un-planted leg -- same kernel, same grid)
         out["roofline"]["all_launches_in_process"] = {"launches": tally[dom][0], "avg_ms": tally[dom][1] / max(tally[dom][0], 1),
                                                       "note": "compare with profiles/*_kernel_stats.txt; avg_launch_ms above is the timed region of the headline workload only"}
-        if world == 1 and not args.no_cpu_baseline and not rank_shape:
+        # the arithmetic closest to what "dtype": "f32" promises: the same workload with fp32 products in the per-row Gramian
+        # (v_mfma_f32_16x16x4_f32), so that the cost of the split-f16 choice is in the record
+        if world == 1 and not rank_shape and not force and split and args.gramian_mode == "auto" and not args.no_fp32_leg and not big:
+            leg = unplanted_leg(torch, pkg, sharded, synth, n_users, n_items, nnz_req, k, args, 1, smode, local_rank, device, prob=prob,
+                                label="the headline workload with --gramian-mode fp32 (per-row Gramian on v_mfma_f32_16x16x4_f32)")
+            leg.pop("_all_rows_launches", None)
+            leg["kernel"] = "rows kernel (als_persistent_kernel, MODE 0, fp32 gather)"
+            leg["slower_than_split_f16_by"] = leg["ms_per_step"] / ms_per_step - 1.0
+            out["roofline_fp32"] = leg
+        if world == 1 and not args.no_cpu_baseline and not rank_shape and not big:
             X = als.factors(pkg.SIDE_X)
             Y = als.factors(pkg.SIDE_Y)
             out["cpu_baseline"] = cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k)

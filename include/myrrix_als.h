@@ -27,13 +27,14 @@
 #ifndef MYRRIX_ALS_H
 #define MYRRIX_ALS_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define MALS_ABI_VERSION 2
+#define MALS_ABI_VERSION 3
 
 typedef struct mals_handle_s* mals_handle;
 
@@ -141,6 +142,14 @@ int mals_default_config(mals_config* cfg);
 /* Create a handle on cfg->device.  Replaces `new AlternatingLeastSquares(...)` (ALS:132-147). */
 int mals_create(const mals_config* cfg, mals_handle* out);
 int mals_destroy(mals_handle h);
+
+/* Why the last mals_create / mals_group_create / mals_group_create_rank / mals_group_unique_id ON THIS THREAD failed --
+ * there is no handle to ask then ("no HIP device", "device ordinal 3 outside 0..0", "librccl.so.1: cannot open ...",
+ * "ncclCommInitAll: ...").  Copies at most cap - 1 characters + NUL into buf, returns the full length ("" / 0 after a
+ * success).  mals_group_create_error is the same call under the group's name.  What the JVM adapter puts into the
+ * ExecutionException instead of a bare "create failed" (jni/myrrix_als_jni.c nativeCreateError). */
+int mals_create_error(char* buf, size_t cap);
+int mals_group_create_error(char* buf, size_t cap);
 
 /* Human-readable message for the last non-OK status on this handle ("" if none). */
 const char* mals_last_error(mals_handle h);
@@ -445,6 +454,11 @@ int mals_group_local(mals_group g, int32_t i, mals_handle* handle_out, int32_t* 
 /* Row chunks per slice (default 4).  Takes effect with the NEXT matrix upload of each side: a side that already
  * holds a matrix keeps the count its work lists were built for. */
 int mals_group_set_exchange_chunks(mals_group g, int32_t n_chunks);
+/* Consecutive chunks of a half-iteration are solved on two alternating compute streams (default on): a chunk's tail -- the
+ * last waves of its persistent kernels -- then overlaps the next chunk's head instead of draining the GPU at every chunk
+ * boundary; each chunk's completion event is handed to the exchange stream as before and the streams are joined at the end
+ * of the half-iteration.  0 = one stream (A/B; the factors are bitwise the same either way). */
+int mals_group_set_alternate_streams(mals_group g, int32_t on);
 /* Which shared library is loaded as RCCL: by default librccl.so.1 (a copy the process already mapped first).  A
  * process that wants a particular build -- or the tests' stand-in transport, tests/cpp/libmock_rccl.so -- says so
  * HERE, once, before its first group or unique id (MALS_INVALID_ARG afterwards); NULL = the default.  Deliberately
@@ -524,6 +538,27 @@ int mals_get_gather_scale(mals_handle h, float* out4);
  * computed it; 0 = none in this half-iteration), out4[3] reserved.  tests/test_gpu_group.py uses it to check that a
  * single-process group enqueues every member's kernels before any member's host work. */
 int mals_get_timeline(mals_handle h, double* out4);
+
+/* What call() logs per iteration in the reference -- "Finished iteration {}", "Avg absolute difference in estimate vs prior
+ * iteration: {}" (ALS:241-246), "{} X/tag rows computed" (ALS:351-358) -- needs values out of the library WHILE
+ * mals_factorize / mals_group_factorize run: the callback is called on the calling thread after every iteration's
+ * convergence statistic, before the stop rules (ALS:242-256) are applied.  seconds = host wall time of the iteration;
+ * rows / entries / algorithmic bytes of the iteration are what THIS process's members solved (a
+ * one-process group: everything).  fn = NULL removes it. */
+typedef struct mals_iteration_info {
+  int32_t struct_size;
+  int32_t iteration;             /* 1-based */
+  double avg_abs_difference;     /* DoubleWeightedMean of |new - old| over the convergence sample (ALS:230-238) */
+  double seconds;
+  int64_t x_rows, y_rows;        /* rows solved by the two half-iterations */
+  int64_t entries_gathered;
+  double algorithmic_bytes;
+  int32_t devices;               /* GPUs of this process taking part */
+  int32_t reserved;
+} mals_iteration_info;
+typedef void (*mals_iteration_fn)(void* user, const mals_iteration_info* info);
+int mals_set_iteration_callback(mals_handle h, mals_iteration_fn fn, void* user);
+int mals_group_set_iteration_callback(mals_group g, mals_iteration_fn fn, void* user);
 
 int mals_enable_timing(mals_handle h, int32_t on);
 int mals_reset_stats(mals_handle h);

@@ -10,6 +10,8 @@
  */
 package net.myrrix.common.math;
 
+import java.util.concurrent.locks.ReentrantReadWriteLock;
+
 public final class NativeSolver implements Solver, AutoCloseable {
 
   static {
@@ -18,6 +20,14 @@ public final class NativeSolver implements Solver, AutoCloseable {
 
   private long handle;
   private final int n;
+  /**
+   * Solves share the lock, close() takes it exclusively: the native factorization cannot be freed while a serving
+   * thread is inside mals_solver_solve_*.  That covers an explicit close() from another thread AND the finalizer: once
+   * handle() has returned, `this` is no longer referenced by the solving thread, so the JIT may treat it as unreachable
+   * during the native call and the collector may run finalize() -- which then blocks in close() until the solve has
+   * released its read lock (round 3 read the handle under a monitor and called the native solve outside it).
+   */
+  private final ReentrantReadWriteLock lifecycle = new ReentrantReadWriteLock();
 
   NativeSolver(long handle, int n) {
     this.handle = handle;
@@ -55,7 +65,12 @@ public final class NativeSolver implements Solver, AutoCloseable {
   public float[] solveDToF(double[] b) {
     checkLength(b.length);
     float[] x = new float[n];
-    check(nativeSolveDToF(handle(), b, x));
+    lifecycle.readLock().lock();
+    try {
+      check(nativeSolveDToF(handle(), b, x));
+    } finally {
+      lifecycle.readLock().unlock();
+    }
     return x;
   }
 
@@ -64,7 +79,12 @@ public final class NativeSolver implements Solver, AutoCloseable {
   public double[] solveFToD(float[] b) {
     checkLength(b.length);
     double[] x = new double[n];
-    check(nativeSolveFToD(handle(), b, x));
+    lifecycle.readLock().lock();
+    try {
+      check(nativeSolveFToD(handle(), b, x));
+    } finally {
+      lifecycle.readLock().unlock();
+    }
     return x;
   }
 
@@ -75,7 +95,8 @@ public final class NativeSolver implements Solver, AutoCloseable {
     }
   }
 
-  private synchronized long handle() {
+  /** Call with the read lock held. */
+  private long handle() {
     if (handle == 0L) {
       throw new IllegalStateException("solver already closed");
     }
@@ -89,10 +110,15 @@ public final class NativeSolver implements Solver, AutoCloseable {
   }
 
   @Override
-  public synchronized void close() {
-    if (handle != 0L) {
-      nativeDestroy(handle);
-      handle = 0L;
+  public void close() {
+    lifecycle.writeLock().lock();     // waits for every solve in flight
+    try {
+      if (handle != 0L) {
+        nativeDestroy(handle);
+        handle = 0L;
+      }
+    } finally {
+      lifecycle.writeLock().unlock();
     }
   }
 

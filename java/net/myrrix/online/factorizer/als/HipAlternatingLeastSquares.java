@@ -32,6 +32,8 @@ import java.util.concurrent.ExecutionException;
 import java.util.concurrent.FutureTask;
 
 import org.apache.commons.math3.random.RandomGenerator;
+import org.slf4j.Logger;
+import org.slf4j.LoggerFactory;
 
 import net.myrrix.common.collection.FastByIDFloatMap;
 import net.myrrix.common.collection.FastByIDMap;
@@ -44,6 +46,19 @@ import net.myrrix.online.factorizer.MatrixFactorizer;
 import org.apache.mahout.cf.taste.impl.common.LongPrimitiveIterator;
 
 public final class HipAlternatingLeastSquares implements MatrixFactorizer {
+
+  /** The reference logs under its own class name (ALS:68); an operator's logback / log4j filters keep working when the
+   *  logger NAME is the reference's.  -Dmodel.als.gpu.logAsReference=false logs under this class instead. */
+  private static final Logger log = LoggerFactory.getLogger(
+      Boolean.parseBoolean(System.getProperty("model.als.gpu.logAsReference", "true"))
+          ? "net.myrrix.online.factorizer.als.AlternatingLeastSquares"
+          : HipAlternatingLeastSquares.class.getName());
+
+  /** Called from native code (jni/myrrix_als_jni.c, on_iteration) after every iteration of nativeFactorize. */
+  interface IterationListener {
+    void iteration(int iteration, double avgAbsDifference, double seconds, long xRows, long yRows, long entriesGathered,
+                   double algorithmicBytes, int devices);
+  }
 
   // status codes of include/myrrix_als.h
   private static final int MALS_OK = 0;
@@ -73,6 +88,8 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
   // ---- native methods: one per mals_group_* entry point used (jni/myrrix_als_jni.c) ----------------
   private static native long nativeCreate(int features, double alpha, double lambda, double singularityThreshold,
                                           int flags, int[] devices, boolean peerCopy);
+  /** Why the last nativeCreate on this thread returned 0 (mals_group_create_error). */
+  private static native String nativeCreateError();
   private static native void nativeDestroy(long group);
   private static native String nativeLastError(long group);
   private static native int nativeSetRefineLimit(long group, double limit);
@@ -84,7 +101,7 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
   private static native int nativeGetFactors(long group, int side, long rowBegin, int nRows, float[] out);
   private static native int nativeFactorize(long group, double threshold, int maxIterations, boolean randomY,
                                             boolean iterate, long[] testUsers, long[] testItems,
-                                            int[] iterationsOut, double[] convergenceOut);
+                                            int[] iterationsOut, double[] convergenceOut, IterationListener listener);
   private static native int nativeCancel(long group);
   /** out = {side, row, apparentRank} of the last MALS_SINGULAR. */
   private static native int nativeSingularInfo(long group, long[] out);
@@ -203,16 +220,23 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
     if (Boolean.parseBoolean(System.getProperty("model.lossIgnoresUnspecified", "false"))) {
       flags |= FLAG_LOSS_IGNORES_UNSPECIFIED;
     }
+    final int[] devices = parseDevices(System.getProperty("model.als.gpus", "0"));
+    // ALS:193 logs "Iterating using {} threads"; the workers here are GPUs
+    log.info("Iterating using {} GPU(s) {} ({} features, {} users, {} items)", devices.length, java.util.Arrays.toString(devices),
+             features, userIDs.length, numItems);
     final long group = nativeCreate(features,
                                     doubleProperty("model.als.alpha", DEFAULT_ALPHA),
                                     doubleProperty("model.als.lambda", DEFAULT_LAMBDA),
                                     doubleProperty("common.matrix.singularityThreshold", 1.0e-5),
                                     flags,
-                                    parseDevices(System.getProperty("model.als.gpus", "0")),
+                                    devices,
                                     Boolean.parseBoolean(System.getProperty("model.als.gpu.peerCopy", "false")));
     if (group == 0L) {
+      // "no HIP device", "device ordinal 3 outside 0..0", "librccl.so.1: cannot open ...", "ncclCommInitAll: ..." --
+      // the library's own words (there is no CPU fallback to fall back to)
+      String why = nativeCreateError();
       throw new ExecutionException(new IllegalStateException(
-          "mals_group_create failed: a HIP device is required, there is no CPU fallback"));
+          "mals_group_create failed: " + (why == null || why.isEmpty() ? "unknown reason" : why)));
     }
     try {
       // rows whose system is too ill-conditioned for fp32 are solved again with fp64 residuals: the conditioning
@@ -233,13 +257,39 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
       final boolean rnd = randomY;
       final int[] iterationsOut = new int[1];
       final double[] convergenceOut = new double[1];
+      final int maxIt = maxIterations;
+      final double threshold = estimateErrorConvergenceThreshold;
+      // the reference's per-iteration lines (ALS:241-256) and its "rows computed" progress (ALS:351-358, 378-385: there
+      // every 10000 work units with the JVM heap; here once per half-iteration pair, with what a GPU operator watches:
+      // rows/s and the algorithmic GB/s of SURVEY.md 8(d))
+      final IterationListener listener = new IterationListener() {
+        @Override
+        public void iteration(int iteration, double avgAbsDifference, double seconds, long xRows, long yRows,
+                              long entriesGathered, double algorithmicBytes, int nDevices) {
+          log.info("{} X/tag rows computed, {} Y/tag rows computed ({} entries gathered in {} s on {} GPU(s): {} rows/s, {} GB/s)",
+                   xRows, yRows, entriesGathered, String.format("%.3f", seconds), nDevices,
+                   String.format("%.3g", (xRows + yRows) / Math.max(seconds, 1.0e-9)),
+                   String.format("%.1f", algorithmicBytes / Math.max(seconds, 1.0e-9) / 1.0e9));
+          log.info("Finished iteration {}", iteration);
+          if (maxIt > 0 && iteration >= maxIt) {
+            log.info("Reached iteration limit");
+            return;
+          }
+          log.info("Avg absolute difference in estimate vs prior iteration: {}", avgAbsDifference);
+          if (Double.isNaN(avgAbsDifference) || Double.isInfinite(avgAbsDifference)) {
+            log.warn("Invalid convergence value, aborting iteration! {}", avgAbsDifference);
+          } else if (!(rnd && iteration == 1) && avgAbsDifference < threshold) {
+            log.info("Converged");
+          }
+        }
+      };
       // the factorization runs on its own thread so that THIS thread stays interruptible: an interrupt
       // becomes mals_group_cancel, honoured between half-iterations (MatrixFactorizer.java:43-44)
       FutureTask<Integer> task = new FutureTask<Integer>(new Callable<Integer>() {
         @Override
         public Integer call() {
           return nativeFactorize(group, estimateErrorConvergenceThreshold, maxIterations, rnd, iter, tu, ti,
-                                 iterationsOut, convergenceOut);
+                                 iterationsOut, convergenceOut, listener);
         }
       });
       Thread worker = new Thread(task, "HipALS");
@@ -270,12 +320,19 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
     RandomGenerator random = RandomManager.getRandom();
     FastByIDMap<float[]> start;
     if (previous == null || previous.isEmpty()) {
+      log.info("Starting from new, random Y matrix");                                   // ALS:271
       start = new FastByIDMap<float[]>(RbyColumn.size());
     } else {
       int oldFeatures = previous.entrySet().iterator().next().getValue().length;
       if (oldFeatures == features) {
+        log.info("Starting from previous generation's Y matrix");                       // ALS:306
         start = previous;                      // reused in place; the caller passed a clone (DGM:419-422)
       } else {
+        if (oldFeatures > features) {                                                   // ALS:279, 290
+          log.info("Feature count has decreased to {}, projecting down previous generation's Y matrix", features);
+        } else {
+          log.info("Feature count has increased to {}, using previous generation's Y matrix as subspace", features);
+        }
         start = new FastByIDMap<float[]>(previous.size());
         for (FastByIDMap.MapEntry<float[]> entry : previous.entrySet()) {
           float[] old = entry.getValue();
@@ -297,6 +354,7 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
       farFrom.add(entry.getValue());
     }
     LongPrimitiveIterator it = RbyColumn.keySetIterator();
+    int fresher = 0;
     while (it.hasNext()) {
       long id = it.nextLong();
       if (!start.containsKey(id)) {
@@ -305,8 +363,12 @@ public final class HipAlternatingLeastSquares implements MatrixFactorizer {
         if (farFrom.size() < MAX_FAR_FROM_VECTORS) {
           farFrom.add(fresh);
         }
+        if (++fresher % 10000 == 0) {
+          log.info("Computed {} initial Y rows", fresher);                              // ALS:330
+        }
       }
     }
+    log.info("Constructed initial Y");                                                  // ALS:333
     return start;
   }
 

@@ -27,25 +27,44 @@
 
 static mals_group as_group(jlong handle) { return (mals_group)(intptr_t)handle; }
 
+/* Why the last nativeCreate of THIS thread returned 0 (mals_group_create_error: "no HIP device ...", "device ordinal 3
+ * outside 0..0", "librccl.so.1: cannot open shared object file", "ncclCommInitAll: ..."); "" after a success */
+static __thread char t_shim_error[256];   /* failures of the shim itself, before the library was asked */
+JNIEXPORT jstring JNICALL JNI_FN(nativeCreateError)(JNIEnv* env, jclass cls) {
+  (void)cls;
+  char why[1024];
+  why[0] = 0;
+  if (t_shim_error[0]) return (*env)->NewStringUTF(env, t_shim_error);
+  (void)mals_group_create_error(why, sizeof(why));
+  return (*env)->NewStringUTF(env, why);
+}
+static jlong shim_fail(const char* text) {
+  size_t i = 0;
+  for (; text[i] && i + 1 < sizeof(t_shim_error); ++i) t_shim_error[i] = text[i];
+  t_shim_error[i] = 0;
+  return 0;
+}
+
 /* mals_group_create: devices of one node, RCCL or peer copies; returns 0 on failure */
 JNIEXPORT jlong JNICALL JNI_FN(nativeCreate)(JNIEnv* env, jclass cls, jint features, jdouble alpha, jdouble lambda,
                                              jdouble singularity_threshold, jint flags, jintArray devices, jboolean peer_copy) {
   (void)cls;
   mals_config cfg;
-  if (mals_default_config(&cfg) != MALS_OK) return 0;
+  t_shim_error[0] = 0;
+  if (mals_default_config(&cfg) != MALS_OK) return shim_fail("mals_default_config failed");
   cfg.features = features;
   cfg.alpha = alpha;
   cfg.lambda = lambda;
   cfg.singularity_threshold = singularity_threshold;
   cfg.flags = flags;
   const jsize n = (*env)->GetArrayLength(env, devices);
-  if (n <= 0) return 0;
+  if (n <= 0) return shim_fail("model.als.gpus: empty device list");
   jint* dev = (*env)->GetIntArrayElements(env, devices, NULL);
-  if (!dev) return 0;
+  if (!dev) return shim_fail("out of memory (device list)");
   int32_t* list = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
   if (!list) {
     (*env)->ReleaseIntArrayElements(env, devices, dev, JNI_ABORT);
-    return 0;
+    return shim_fail("out of memory (device list)");
   }
   for (jsize i = 0; i < n; ++i) list[i] = dev[i];
   (*env)->ReleaseIntArrayElements(env, devices, dev, JNI_ABORT);
@@ -145,10 +164,26 @@ JNIEXPORT jint JNICALL JNI_FN(nativeGetFactors)(JNIEnv* env, jclass cls, jlong g
   return rc;
 }
 
+/* per-iteration values for the adapter's log lines (ALS:241-246, 351-358): mals_group_set_iteration_callback -> the
+ * listener's iteration(...) method, called on the thread that runs nativeFactorize (its JNIEnv is valid for the call) */
+typedef struct {
+  JNIEnv* env;
+  jobject listener;
+  jmethodID method;
+} iteration_ctx;
+static void on_iteration(void* user, const mals_iteration_info* info) {
+  iteration_ctx* c = (iteration_ctx*)user;
+  if (!c->listener || !c->method) return;
+  (*c->env)->CallVoidMethod(c->env, c->listener, c->method, (jint)info->iteration, (jdouble)info->avg_abs_difference, (jdouble)info->seconds,
+                            (jlong)info->x_rows, (jlong)info->y_rows, (jlong)info->entries_gathered, (jdouble)info->algorithmic_bytes,
+                            (jint)info->devices);
+  if ((*c->env)->ExceptionCheck(c->env)) (*c->env)->ExceptionClear(c->env);   /* a logging failure must not fail the build */
+}
+
 /* call() (ALS:176-262) */
 JNIEXPORT jint JNICALL JNI_FN(nativeFactorize)(JNIEnv* env, jclass cls, jlong group, jdouble threshold, jint max_iterations,
                                                jboolean random_y, jboolean iterate, jlongArray test_users, jlongArray test_items,
-                                               jintArray iterations_out, jdoubleArray convergence_out) {
+                                               jintArray iterations_out, jdoubleArray convergence_out, jobject listener) {
   (void)cls;
   const jsize nu = (*env)->GetArrayLength(env, test_users), ni = (*env)->GetArrayLength(env, test_items);
   jlong* tu = (*env)->GetLongArrayElements(env, test_users, NULL);
@@ -157,8 +192,16 @@ JNIEXPORT jint JNICALL JNI_FN(nativeFactorize)(JNIEnv* env, jclass cls, jlong gr
   if (tu && ti) {
     int32_t iterations = 0;
     double convergence = 0.0;
+    iteration_ctx ctx = {env, listener, NULL};
+    if (listener) {
+      jclass lc = (*env)->GetObjectClass(env, listener);
+      ctx.method = (*env)->GetMethodID(env, lc, "iteration", "(IDDJJJDI)V");
+      if (!ctx.method) (*env)->ExceptionClear(env);
+    }
+    (void)mals_group_set_iteration_callback(as_group(group), ctx.method ? on_iteration : NULL, &ctx);
     rc = mals_group_factorize(as_group(group), threshold, max_iterations, random_y ? 1 : 0, iterate ? 1 : 0, (const int64_t*)tu,
                               (int32_t)nu, (const int64_t*)ti, (int32_t)ni, &iterations, &convergence);
+    (void)mals_group_set_iteration_callback(as_group(group), NULL, NULL);
     const jint it = iterations;
     const jdouble cv = convergence;
     (*env)->SetIntArrayRegion(env, iterations_out, 0, 1, &it);

@@ -14,7 +14,7 @@ FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
 SOLVE_AUTO, SOLVE_DIRECT, SOLVE_DUAL = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 GROUP_RCCL, GROUP_PEER_COPY = 0, 1
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
@@ -63,6 +63,23 @@ class ModelView(ctypes.Structure):
                 ("item_cluster_centroids", ctypes.c_void_p)]
 
 
+class IterationInfo(ctypes.Structure):   # mals_iteration_info
+    _fields_ = [("struct_size", ctypes.c_int32), ("iteration", ctypes.c_int32), ("avg_abs_difference", ctypes.c_double),
+                ("seconds", ctypes.c_double), ("x_rows", ctypes.c_int64), ("y_rows", ctypes.c_int64),
+                ("entries_gathered", ctypes.c_int64), ("algorithmic_bytes", ctypes.c_double), ("devices", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+ITERATION_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(IterationInfo))
+
+
+def create_error():
+    """mals_create_error: why the last mals_create / mals_group_create* on this thread failed ("" after a success)."""
+    buf = ctypes.create_string_buffer(1024)
+    load().mals_create_error(buf, len(buf))
+    return buf.value.decode("utf-8", "replace")
+
+
 # every symbol include/myrrix_als.h declares: name -> (restype, argtypes)
 _H = ctypes.c_void_p
 _I64 = ctypes.c_int64
@@ -74,6 +91,10 @@ SYMBOLS = {
     "mals_create": (ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(_H)]),
     "mals_destroy": (ctypes.c_int, [_H]),
     "mals_last_error": (ctypes.c_char_p, [_H]),
+    "mals_create_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "mals_group_create_error": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "mals_set_iteration_callback": (ctypes.c_int, [_H, _P, _P]),
+    "mals_group_set_iteration_callback": (ctypes.c_int, [_H, _P, _P]),
     "mals_set_stream": (ctypes.c_int, [_H, _P]),
     "mals_set_factor_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64]),
     "mals_bind_factors": (ctypes.c_int, [_H, ctypes.c_int, _P, _I64]),
@@ -128,6 +149,7 @@ SYMBOLS = {
     "mals_ingest_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I32)]),
     "mals_plan_shards": (ctypes.c_int, [_P, _I64, _I32, ctypes.c_double, _I32, _P]),
+    "mals_group_set_alternate_streams": (ctypes.c_int, [_H, _I32]),
     "mals_group_create": (ctypes.c_int, [ctypes.POINTER(Config), _P, _I32, _I32, ctypes.POINTER(_H)]),
     "mals_group_unique_id": (ctypes.c_int, [_P]),
     "mals_group_create_rank": (ctypes.c_int, [ctypes.POINTER(Config), _I32, _I32, _P, ctypes.POINTER(_H)]),

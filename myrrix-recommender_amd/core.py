@@ -307,6 +307,21 @@ class ALSCore:
         self._chk(rc)
         return iters.value, conv.value
 
+    def set_iteration_callback(self, fn):
+        """mals_set_iteration_callback: fn(info: dict) after every iteration of factorize() -- iteration, avg_abs_difference,
+        seconds, x_rows, y_rows, entries_gathered, algorithmic_bytes, devices (what call() logs per iteration, ALS:241-246,
+        351-358); None removes it."""
+        if fn is None:
+            self._iter_cb = None
+            self._chk(self._L.mals_set_iteration_callback(self._h, None, None))
+            return
+
+        def tramp(_user, info):
+            i = info.contents
+            fn({name: getattr(i, name) for name, _ in _lib.IterationInfo._fields_ if name not in ("struct_size", "reserved")})
+        self._iter_cb = _lib.ITERATION_FN(tramp)      # keep the trampoline alive as long as the library may call it
+        self._chk(self._L.mals_set_iteration_callback(self._h, ctypes.cast(self._iter_cb, ctypes.c_void_p), None))
+
     def cancel(self):
         self._chk(self._L.mals_cancel(self._h))
 

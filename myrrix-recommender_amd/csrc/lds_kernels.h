@@ -128,7 +128,10 @@ __device__ __forceinline__ void ldsk_issue_pair(const lds_char* lds, unsigned ri
   const i32x4 cols = *reinterpret_cast<lds_i4>(lds + cols_at + 32 * E2);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const char* a = L.gsrc + (uint64_t)(uint32_t)cols[i] * (uint32_t)LDSK_ROW_BYTES;   // one v_mad_u64_u32
+    // gsrc + 512 col as ONE v_mad_u64_u32 (hipcc strength-reduces the constant product into v_mov + v_lshlrev_b64 +
+    // v_lshl_add_u64: three half-rate instructions per load)
+    const char* a;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(a) : "v"(cols[i]), "s"((unsigned)LDSK_ROW_BYTES), "v"(L.gsrc) : "vcc");
     glds16(a, ring + 4096 * E2 + 1024 * i);
   }
 }

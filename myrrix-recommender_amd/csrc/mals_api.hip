@@ -153,6 +153,14 @@ struct mals_handle_s {
   // k = 128 with the split-precision gather: the rows / segments kernels that stage the gather through LDS (lds_kernels.h)
   // and the Gramian image in their feature order (all zeros under lossIgnoresUnspecified), rebuilt when the opposite
   // side's Gramian changes
+  // Chunks of one half-iteration on alternating streams (mals_group.cpp): ev_ready = everything the half-iteration sets up
+  // once, in its first chunk (operand scale, padded / permuted images, the rotated copy of the dual path), is enqueued
+  // behind it -- a later chunk on the OTHER stream waits for it; ev_refine serialises the chunks' refinement blocks
+  // (gramian_ref_kernel's arrival ticket assumes one launch at a time)
+  hipEvent_t ev_ready = nullptr, ev_refine = nullptr;
+  bool refine_recorded = false;
+  mals_iteration_fn iter_fn = nullptr;   // mals_set_iteration_callback
+  void* iter_user = nullptr;
   bool lds_gather = false;
   float* d_Gperm = nullptr;
   int gperm_side = -1;
@@ -1155,6 +1163,8 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
   const WorkItem* base = s.itemsA + cr.offA + cr.nA;
   int64_t off = 0;
   PendingEvent pe;
+  // (Two classes in flight at a time on two streams -- one class's tail under the next one's head -- was built in round 4
+  // and measured flat on c4rank, 11.37 vs 11.36 ms: the dual kernels are issue bound, not tail bound.)
   for (int cls = 3; cls >= 0; --cls) {  // descending length, as stored
     if (!cr.nD[cls]) continue;
     dp.items = base + off;
@@ -1470,16 +1480,44 @@ int mals_default_config(mals_config* cfg) {
   return MALS_OK;
 }
 
+static thread_local std::string t_create_error;
+void malsi_set_create_error(const char* text) { t_create_error = text ? text : ""; }
+static int create_fail(int code, const std::string& msg) {
+  t_create_error = msg;
+  return code;
+}
+int mals_create_error(char* buf, size_t cap) {
+  if (buf && cap > 0) {
+    const size_t n = std::min(cap - 1, t_create_error.size());
+    std::memcpy(buf, t_create_error.data(), n);
+    buf[n] = 0;
+  }
+  return (int)t_create_error.size();
+}
+int mals_group_create_error(char* buf, size_t cap) { return mals_create_error(buf, cap); }
+
 int mals_create(const mals_config* cfg, mals_handle* out) {
-  if (!cfg || !out) return MALS_INVALID_ARG;
+  if (!cfg || !out) return create_fail(MALS_INVALID_ARG, "mals_create: null config or output pointer");
   *out = nullptr;
-  if (cfg->struct_size != (int32_t)sizeof(mals_config)) return MALS_INVALID_ARG;
-  if (cfg->features <= 0 || cfg->features > 128) return MALS_INVALID_ARG;  // ALS:139
-  if (!(cfg->lambda >= 0.0) || !std::isfinite(cfg->alpha)) return MALS_INVALID_ARG;
+  if (cfg->struct_size != (int32_t)sizeof(mals_config))
+    return create_fail(MALS_INVALID_ARG, "mals_create: mals_config.struct_size " + std::to_string(cfg->struct_size) + " is not this library's " +
+                                             std::to_string(sizeof(mals_config)) + " (mals_default_config fills it)");
+  if (cfg->features <= 0 || cfg->features > 128)   // ALS:139
+    return create_fail(MALS_INVALID_ARG, "mals_create: features must be in 1..128, got " + std::to_string(cfg->features));
+  if (!(cfg->lambda >= 0.0) || !std::isfinite(cfg->alpha)) return create_fail(MALS_INVALID_ARG, "mals_create: lambda must be >= 0 and alpha finite");
   int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || cfg->device < 0 || cfg->device >= n_dev) return MALS_HIP_ERROR;
+  {
+    const hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+      (void)hipGetLastError();
+      return create_fail(MALS_HIP_ERROR, std::string("mals_create: no HIP device (hipGetDeviceCount: ") + hipGetErrorString(e) +
+                                             "); a GPU is required, there is no CPU fallback");
+    }
+  }
+  if (cfg->device < 0 || cfg->device >= n_dev)
+    return create_fail(MALS_HIP_ERROR, "mals_create: device ordinal " + std::to_string(cfg->device) + " outside 0.." + std::to_string(n_dev - 1));
   mals_handle h = new (std::nothrow) mals_handle_s();
-  if (!h) return MALS_OOM;
+  if (!h) return create_fail(MALS_OOM, "mals_create: out of host memory");
   h->cfg = *cfg;
   h->cfg.flags &= 3;
 #ifdef MALS_PROFILING
@@ -1493,7 +1531,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
     case MALS_GRAMIAN_AUTO: h->split_f16 = h->T >= 2; break;  // k <= 16: one tile, the fp32 products are not the bottleneck (k = 30: split is 8 % faster, measured)
     case MALS_GRAMIAN_FP32: h->split_f16 = false; break;
     case MALS_GRAMIAN_SPLIT_F16: h->split_f16 = true; break;
-    default: delete h; return MALS_INVALID_ARG;
+    default: delete h; return create_fail(MALS_INVALID_ARG, "mals_create: unknown gramian_mode");
   }
   // a negative alpha (accepted by the reference, ALS:506-509) has no real sqrt(alpha |r|): fp32 gather
   if (cfg->alpha < 0.0) h->split_f16 = false;
@@ -1501,7 +1539,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
     case MALS_SOLVE_AUTO: h->dual_blocks = h->T >= 3 ? dual_max_blocks(h->T) : 0; break;
     case MALS_SOLVE_DIRECT: h->dual_blocks = 0; break;
     case MALS_SOLVE_DUAL: h->dual_blocks = dual_max_blocks(h->T); break;
-    default: delete h; return MALS_INVALID_ARG;
+    default: delete h; return create_fail(MALS_INVALID_ARG, "mals_create: unknown solve_mode");
   }
   if (h->cfg.flags != 0 || !(cfg->alpha > 0.0)) h->dual_blocks = 0;  // the dual path covers the default mode only
   {
@@ -1518,11 +1556,18 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
       hipMalloc(&h->d_refined, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&h->d_gref_state, 4 * sizeof(int)) != hipSuccess || hipMemset(h->d_gref_state, 0, 4 * sizeof(int)) != hipSuccess ||
       hipMemset(h->d_refined, 0, sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(h->d_zscale, 0, 4 * sizeof(float)) != hipSuccess ||   // (mals_get_gather_scale before any split-precision gather: zeros)
       hipMemset(h->d_bad, 0xff, 4 * sizeof(unsigned long long)) != hipSuccess) {
+    const hipError_t e = hipGetLastError();
     delete h;
-    return MALS_HIP_ERROR;
+    return create_fail(MALS_HIP_ERROR, "mals_create: device " + std::to_string(cfg->device) + ": " + hipGetErrorString(e));
   }
   if (const char* e = std::getenv("MALS_REFINE_LIMIT")) h->refine_limit = std::max(0.f, (float)std::atof(e));
+  if (hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_refine, hipEventDisableTiming) != hipSuccess) {
+    delete h;
+    return create_fail(MALS_HIP_ERROR, "mals_create: hipEventCreate failed");
+  }
   h->lds_gather = h->cfg.features == 128;   // the LDS-staged rows / segments kernels (lds_kernels.h); MALS_LDS_GATHER=0: A/B against the register-staged ones
   if (const char* e = std::getenv("MALS_LDS_GATHER")) h->lds_gather = h->lds_gather && std::atoi(e) != 0;
   if (const char* e = std::getenv("MALS_OVERLAP")) h->overlap = std::atoi(e) != 0;
@@ -1539,6 +1584,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
     (void)hipMemset(h->d_trace, 0, 64 * 64 * 6 * sizeof(unsigned long long));
   }
 #endif
+  t_create_error.clear();
   *out = h;
   return MALS_OK;
 }
@@ -1583,6 +1629,8 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_gref_part);
   free_dev(h->d_zscale);
   free_dev(h->d_Gperm);
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  if (h->ev_refine) (void)hipEventDestroy(h->ev_refine);
   free_dev(h->d_maxabs);
   free_dev(h->d_colrange);
   free_dev(h->d_Mr);
@@ -2128,6 +2176,8 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
     HIPCHK(h, hipEventRecord(h->ev_G, h->stream));
   }
   if (phase == SOLVE_BEGIN && chunk_end != chunk_begin + 1) return fail(h, MALS_INVALID_ARG, "solve BEGIN takes one chunk");
+  // everything a half-iteration sets up once is enqueued by now unless the dual preparation is still to come (below)
+  if (!resume && !(want_dual && dual_stale)) HIPCHK(h, hipEventRecord(h->ev_ready, h->stream));
   const int64_t want_chunk_rows = s.chunk_rows_override >= 0 ? s.chunk_rows_override : h->cfg.chunk_rows;
   const int64_t rows_per_chunk = want_chunk_rows > 0 ? want_chunk_rows : std::max<int64_t>(s.n_local, 1);  // as build_work_lists
   for (int c = chunk_begin; c < chunk_end; ++c) {
@@ -2135,7 +2185,8 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
     const int64_t row0 = std::min<int64_t>(s.n_local, (int64_t)c * rows_per_chunk);
     const int64_t row1 = std::min<int64_t>(s.n_local, (int64_t)(c + 1) * rows_per_chunk);
     if (!resume && p.refine_flag && row1 > row0) HIPCHK(h, hipMemsetAsync(s.refine + row0, 0, (size_t)(row1 - row0), h->stream));
-    bool dual_now = want_dual && !dual_stale && h->dual_ok;
+    // (per chunk, not per call: once the first chunk of a multi-chunk call has prepared the dual path the later ones use it)
+    bool dual_now = want_dual && h->dual_ok && h->dual_side == side && h->dual_version == o.G_version;
     if (!resume)
       if (int rc = fork_streams(h)) return rc;
     if (want_dual && dual_stale && c == chunk_begin) {
@@ -2159,6 +2210,7 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
       {
         SideStream dual_rows(h, 1);
         if (int rc = prepare_dual_device(h, side)) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_ready, h->stream));   // (with MALS_OVERLAP: the side stream the rotation is on)
         dual_now = h->dual_ok;
         if (dual_now) {
           if (int rc = launch_dual_chunk(h, side, c)) return rc;
@@ -2179,6 +2231,7 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
     }
     if (int rc = join_streams(h)) return rc;
     if (p.refine_flag && row1 > row0) {  // behind every kernel of the chunk (the un-rotation of the dual rows included)
+      if (h->refine_recorded) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_refine, 0));   // one chunk's block at a time
       if (!h->d_Gref) {   // before the parameter block below takes the pointers
         const size_t kp2 = (size_t)(16 * h->T) * (size_t)(16 * h->T);
         HIPCHK(h, hipMalloc(&h->d_Gref, sizeof(double) * kp2));
@@ -2200,6 +2253,8 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
       if (!no_gramian && h->refine_limit > 0.f)
         if (int rc = launch_refine(h, q)) return rc;      // marks 1; may raise a mark to 2
       if (int rc = launch_exact(h, q, no_gramian ? 1 : 2)) return rc;
+      HIPCHK(h, hipEventRecord(h->ev_refine, h->stream));
+      h->refine_recorded = true;
     }
     h->stats.rows_solved += cr.nA + cr.nC + cr.n_dual() + cr.nZ;
     h->stats.nnz_gathered += cr.nnzA + cr.nnzB + cr.nnz_dual();
@@ -2232,6 +2287,7 @@ int malsi_solve_chunk_end(mals_handle h, int side, int32_t chunk) {
   return solve_chunks(h, side, chunk, chunk + 1, SOLVE_END);
 }
 int malsi_dual_pending(mals_handle h) { return h && h->dual_pending ? 1 : 0; }
+void* malsi_ready_event(mals_handle h) { return h ? (void*)h->ev_ready : nullptr; }
 int malsi_ymax_slots(void) { return YMAX_SLOTS; }
 int malsi_dual_host(mals_handle h, int side, mals_handle from) {
   CHECK_SIDE(h, side);
@@ -2493,6 +2549,8 @@ int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iter
   std::vector<double> fresh(est.size());
   int it = 0;
   for (;;) {
+    const double t_it = now_us();
+    const int64_t rows0 = h->stats.rows_solved, nnz0 = h->stats.nnz_gathered;
     if (h->cancelled.load()) return fail(h, MALS_CANCELLED, "cancelled");
     if (int rc = mals_half_iteration(h, MALS_SIDE_X)) return rc;  // ALS:228
     if (h->cancelled.load()) return fail(h, MALS_CANCELLED, "cancelled");
@@ -2511,6 +2569,21 @@ int mals_factorize(mals_handle h, double convergence_threshold, int32_t max_iter
     ++it;
     if (iterations_out) *iterations_out = it;
     if (convergence_out) *convergence_out = mean;
+    if (h->iter_fn) {   // what the reference logs per iteration (ALS:241-246, 351-358)
+      mals_iteration_info info;
+      std::memset(&info, 0, sizeof(info));
+      info.struct_size = (int32_t)sizeof(info);
+      info.iteration = it;
+      info.avg_abs_difference = mean;
+      info.seconds = (now_us() - t_it) * 1e-6;
+      info.x_rows = h->side[MALS_SIDE_X].n_local;
+      info.y_rows = h->side[MALS_SIDE_Y].n_local;
+      info.entries_gathered = h->stats.nnz_gathered - nnz0;
+      info.algorithmic_bytes = (double)info.entries_gathered * (4.0 * h->cfg.features + 8.0) +
+                               (double)(h->stats.rows_solved - rows0) * (4.0 * h->cfg.features + 8.0);
+      info.devices = 1;
+      h->iter_fn(h->iter_user, &info);
+    }
     if (max_iterations > 0 && it >= max_iterations) break;                 // ALS:242-245
     if (!std::isfinite(mean)) break;                                       // ALS:248-251
     if (!(random_y && it == 1) && mean < convergence_threshold) break;     // ALS:253-256
@@ -2651,6 +2724,13 @@ int mals_symmetric_eigen(const double* A, int32_t n, double* evals_out, double* 
 int mals_cancel(mals_handle h) {
   if (!h) return MALS_INVALID_ARG;
   h->cancelled.store(1);
+  return MALS_OK;
+}
+
+int mals_set_iteration_callback(mals_handle h, mals_iteration_fn fn, void* user) {
+  if (!h) return MALS_INVALID_ARG;
+  h->iter_fn = fn;
+  h->iter_user = user;
   return MALS_OK;
 }
 

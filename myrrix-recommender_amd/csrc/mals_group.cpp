@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -111,7 +112,9 @@ struct Member {
   int device = 0;
   int rank = 0;
   hipStream_t compute = nullptr, comm = nullptr;
+  hipStream_t compute2 = nullptr;   // odd chunks of a half-iteration (alternate_streams)
   hipEvent_t ev_solved = nullptr, ev_exchanged = nullptr;
+  hipEvent_t ev_half = nullptr, ev_join = nullptr;
   ncclComm_t nccl = nullptr;
   double* d_gp = nullptr;    // k*k: partial Gramian / all-reduce buffer
   double* d_stat = nullptr;  // 4 doubles: value statistics, status
@@ -138,7 +141,13 @@ struct mals_group_s {
   int exchange_chunks = 4;        // what the NEXT matrix upload of a side is cut into
   int side_chunks[2] = {4, 4};    // what each side's CURRENT matrix was cut into (plan_side): the members' work lists are
                                   // built for this count, so the solve loop, the exchange ranges and the members agree
+  // Consecutive chunks of a half-iteration on two alternating compute streams: every chunk boundary otherwise drains the
+  // persistent kernels (rows, long rows, dual classes each have a tail) -- +3.7 % at 4 chunks on C4 (round 3).  A chunk's
+  // completion event goes to the exchange stream as before; the streams are joined before anything that assumes one.
+  bool alternate_streams = true;
   std::atomic<int> cancelled{0};
+  mals_iteration_fn iter_fn = nullptr;   // mals_group_set_iteration_callback
+  void* iter_user = nullptr;
   std::string err;
 };
 
@@ -187,14 +196,22 @@ void chunk_range(const mals_group g, int side, int rank, int c, int64_t* lo, int
 }
 
 int init_member(mals_group g, Member& mb, const mals_config& cfg, int device, int rank) {
-  mb.device = device;
+  mb.device = -1;   // until the handle exists: destroy_member must not select a device that may not be there
   mb.rank = rank;
   mals_config c = cfg;
   c.device = device;
-  if (int rc = mals_create(&c, &mb.h)) return gfail(g, rc, "mals_create failed on device " + std::to_string(device));
+  if (int rc = mals_create(&c, &mb.h)) {
+    char why[512];
+    (void)mals_create_error(why, sizeof(why));
+    return gfail(g, rc, std::string(why[0] ? why : "mals_create failed") + " (group member " + std::to_string(rank) + ", device " + std::to_string(device) + ")");
+  }
+  mb.device = device;
   GHIP(g, hipSetDevice(device));
   GHIP(g, hipStreamCreateWithFlags(&mb.compute, hipStreamNonBlocking));
   GHIP(g, hipStreamCreateWithFlags(&mb.comm, hipStreamNonBlocking));
+  GHIP(g, hipStreamCreateWithFlags(&mb.compute2, hipStreamNonBlocking));
+  GHIP(g, hipEventCreateWithFlags(&mb.ev_half, hipEventDisableTiming));
+  GHIP(g, hipEventCreateWithFlags(&mb.ev_join, hipEventDisableTiming));
   GHIP(g, hipEventCreateWithFlags(&mb.ev_solved, hipEventDisableTiming));
   GHIP(g, hipEventCreateWithFlags(&mb.ev_exchanged, hipEventDisableTiming));
   GHIP(g, hipEventRecord(mb.ev_exchanged, mb.comm));
@@ -209,6 +226,7 @@ int init_member(mals_group g, Member& mb, const mals_config& cfg, int device, in
 void destroy_member(Member& mb) {
   if (mb.device >= 0) (void)hipSetDevice(mb.device);
   if (mb.compute) (void)hipStreamSynchronize(mb.compute);
+  if (mb.compute2) (void)hipStreamSynchronize(mb.compute2);
   if (mb.comm) (void)hipStreamSynchronize(mb.comm);
   if (mb.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(mb.nccl);
   if (mb.h) (void)mals_destroy(mb.h);
@@ -218,6 +236,9 @@ void destroy_member(Member& mb) {
   if (mb.d_stat) (void)hipFree(mb.d_stat);
   if (mb.d_ymax) (void)hipFree(mb.d_ymax);
   if (mb.ev_solved) (void)hipEventDestroy(mb.ev_solved);
+  if (mb.ev_half) (void)hipEventDestroy(mb.ev_half);
+  if (mb.ev_join) (void)hipEventDestroy(mb.ev_join);
+  if (mb.compute2) (void)hipStreamDestroy(mb.compute2);
   if (mb.ev_exchanged) (void)hipEventDestroy(mb.ev_exchanged);
   if (mb.comm) (void)hipStreamDestroy(mb.comm);
   if (mb.compute) (void)hipStreamDestroy(mb.compute);
@@ -492,11 +513,20 @@ int mals_plan_shards(const int64_t* row_ptr, int64_t n_rows, int32_t world, doub
 }
 
 int mals_group_create(const mals_config* cfg, const int32_t* devices, int32_t n_devices, int32_t backend, mals_group* out) {
-  if (!cfg || !devices || !out || n_devices <= 0) return MALS_INVALID_ARG;
+  if (!cfg || !devices || !out || n_devices <= 0) {
+    malsi_set_create_error("mals_group_create: null argument or empty device list");
+    return MALS_INVALID_ARG;
+  }
   *out = nullptr;
-  if (backend != MALS_GROUP_RCCL && backend != MALS_GROUP_PEER_COPY) return MALS_INVALID_ARG;
+  if (backend != MALS_GROUP_RCCL && backend != MALS_GROUP_PEER_COPY) {
+    malsi_set_create_error("mals_group_create: backend must be MALS_GROUP_RCCL or MALS_GROUP_PEER_COPY");
+    return MALS_INVALID_ARG;
+  }
   mals_group g = new (std::nothrow) mals_group_s();
-  if (!g) return MALS_OOM;
+  if (!g) {
+    malsi_set_create_error("mals_group_create: out of host memory");
+    return MALS_OOM;
+  }
   g->cfg = *cfg;
   g->world = n_devices;
   g->backend = backend;
@@ -530,10 +560,13 @@ int mals_group_create(const mals_config* cfg, const int32_t* devices, int32_t n_
   }
   if (rc != MALS_OK) {
     std::fprintf(stderr, "mals_group_create: %s\n", g->err.c_str());
+    malsi_set_create_error(("mals_group_create: " + g->err).c_str());
     for (Member& mb : g->m) destroy_member(mb);
     delete g;
+    (void)hipGetLastError();   // a failed create leaves no sticky error behind for the next group of this process
     return rc;
   }
+  malsi_set_create_error("");
   *out = g;
   return MALS_OK;
 }
@@ -542,18 +575,30 @@ int mals_group_unique_id(void* id_out_128_bytes) {
   if (!id_out_128_bytes) return MALS_INVALID_ARG;
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   std::string e;
-  if (!g_rccl.load(e)) return MALS_COMM_ERROR;
+  if (!g_rccl.load(e)) {
+    malsi_set_create_error(("mals_group_unique_id: " + e).c_str());
+    return MALS_COMM_ERROR;
+  }
   ncclUniqueId id;
-  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return MALS_COMM_ERROR;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) {
+    malsi_set_create_error("mals_group_unique_id: ncclGetUniqueId failed");
+    return MALS_COMM_ERROR;
+  }
   std::memcpy(id_out_128_bytes, &id, sizeof(id));
   return MALS_OK;
 }
 
 int mals_group_create_rank(const mals_config* cfg, int32_t world, int32_t rank, const void* id_128_bytes, mals_group* out) {
-  if (!cfg || !out || world <= 0 || rank < 0 || rank >= world || (world > 1 && !id_128_bytes)) return MALS_INVALID_ARG;
+  if (!cfg || !out || world <= 0 || rank < 0 || rank >= world || (world > 1 && !id_128_bytes)) {
+    malsi_set_create_error("mals_group_create_rank: null argument, rank outside 0..world-1, or no unique id for world > 1");
+    return MALS_INVALID_ARG;
+  }
   *out = nullptr;
   mals_group g = new (std::nothrow) mals_group_s();
-  if (!g) return MALS_OOM;
+  if (!g) {
+    malsi_set_create_error("mals_group_create_rank: out of host memory");
+    return MALS_OOM;
+  }
   g->cfg = *cfg;
   g->world = world;
   g->backend = MALS_GROUP_RCCL;
@@ -574,10 +619,13 @@ int mals_group_create_rank(const mals_config* cfg, int32_t world, int32_t rank, 
   }
   if (rc != MALS_OK) {
     std::fprintf(stderr, "mals_group_create_rank: %s\n", g->err.c_str());
+    malsi_set_create_error(("mals_group_create_rank: " + g->err).c_str());
     destroy_member(g->m[0]);
     delete g;
+    (void)hipGetLastError();
     return rc;
   }
+  malsi_set_create_error("");
   *out = g;
   return MALS_OK;
 }
@@ -586,6 +634,19 @@ int mals_group_destroy(mals_group g) {
   if (!g) return MALS_INVALID_ARG;
   for (Member& mb : g->m) destroy_member(mb);
   delete g;
+  return MALS_OK;
+}
+
+int mals_group_set_alternate_streams(mals_group g, int32_t on) {
+  if (!g) return MALS_INVALID_ARG;
+  g->alternate_streams = on != 0;
+  return MALS_OK;
+}
+
+int mals_group_set_iteration_callback(mals_group g, mals_iteration_fn fn, void* user) {
+  if (!g) return MALS_INVALID_ARG;
+  g->iter_fn = fn;
+  g->iter_user = user;
   return MALS_OK;
 }
 
@@ -806,7 +867,22 @@ int mals_group_half_iteration(mals_group g, int side) {
           GHIP(g, hipStreamWaitEvent(mb.compute, other.ev_exchanged, 0));
         }
     if (int rc = group_gramian(g, 1 - side, &solve_rc, &solve_msg)) return rc;  // ALS:342 / ALS:369
+    const bool alternate = g->alternate_streams && g->side_chunks[side] > 1;
+    if (alternate)
+      for (Member& mb : g->m) {   // the second stream starts behind everything the first has seen so far
+        GHIP(g, hipSetDevice(mb.device));
+        GHIP(g, hipEventRecord(mb.ev_half, mb.compute));
+        GHIP(g, hipStreamWaitEvent(mb.compute2, mb.ev_half, 0));
+      }
     for (int c = 0; c < g->side_chunks[side]; ++c) {
+      const bool odd = alternate && (c & 1);
+      if (alternate)
+        for (Member& mb : g->m) {
+          GHIP(g, hipSetDevice(mb.device));
+          if (int rc = mals_set_stream(mb.h, odd ? mb.compute2 : mb.compute)) return mfail(g, mb, rc);
+          // ... and behind what the half-iteration sets up once, in its first chunk (operand scale, images, rotated copy)
+          if (c == 1) GHIP(g, hipStreamWaitEvent(mb.compute2, (hipEvent_t)malsi_ready_event(mb.h), 0));
+        }
       // Like the reference's pool, where every worker is started before any result is awaited (ALS:186-191,391-410):
       // the direct kernels of EVERY member are enqueued before any host work; the k x k eigendecomposition of the
       // dual path (the same G on every member after the all-reduce) is then computed once, under those kernels, and
@@ -841,11 +917,18 @@ int mals_group_half_iteration(mals_group g, int side) {
         GHIP(g, hipSetDevice(mb.device));
         if (has[i])
           if (int rc = malsi_solve_chunk_end(mb.h, side, c)) member_failed(mb, rc);
-        GHIP(g, hipEventRecord(mb.ev_solved, mb.compute));
+        GHIP(g, hipEventRecord(mb.ev_solved, odd ? mb.compute2 : mb.compute));
         GHIP(g, hipStreamWaitEvent(mb.comm, mb.ev_solved, 0));
       }
       if (int rc = exchange_chunk(g, side, c)) return rc;
     }
+    if (alternate)
+      for (Member& mb : g->m) {   // join: everything after this half-iteration assumes the one compute stream
+        GHIP(g, hipSetDevice(mb.device));
+        GHIP(g, hipEventRecord(mb.ev_join, mb.compute2));
+        GHIP(g, hipStreamWaitEvent(mb.compute, mb.ev_join, 0));
+        if (int rc = mals_set_stream(mb.h, mb.compute)) return mfail(g, mb, rc);
+      }
     for (Member& mb : g->m) {
       GHIP(g, hipSetDevice(mb.device));
       GHIP(g, hipEventRecord(mb.ev_exchanged, mb.comm));
@@ -859,6 +942,7 @@ int mals_group_half_iteration(mals_group g, int side) {
   };
   const int local_rc = run();
   const std::string local_msg = g->err;
+  for (Member& mb : g->m) (void)mals_set_stream(mb.h, mb.compute);   // (also after a failure in the middle of the chunk loop)
   // a communication failure cannot be agreed upon over the same communicator
   if (local_rc == MALS_COMM_ERROR || local_rc == MALS_HIP_ERROR) return local_rc;
   return agree_status(g, local_rc, local_msg);
@@ -929,6 +1013,14 @@ int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max
   std::vector<double> est((size_t)n_test_users * (size_t)n_test_items, 0.0), fresh(est.size());
   int it = 0;
   for (;;) {
+    const auto t_it = std::chrono::steady_clock::now();
+    mals_stats st0;
+    std::vector<std::pair<int64_t, int64_t>> before;   // (rows_solved, nnz_gathered) of every local member
+    if (g->iter_fn)
+      for (Member& mb : g->m) {
+        (void)mals_get_stats(mb.h, &st0);
+        before.emplace_back(st0.rows_solved, st0.nnz_gathered);
+      }
     // a cancellation is local knowledge: agree on it before entering a collective
     if (int rc = agree_status(g, g->cancelled.load() ? MALS_CANCELLED : MALS_OK, "cancelled")) return rc;
     if (int rc = mals_group_half_iteration(g, MALS_SIDE_X)) return rc;  // ALS:228
@@ -952,6 +1044,26 @@ int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max
     ++it;
     if (iterations_out) *iterations_out = it;
     if (convergence_out) *convergence_out = mean;
+    if (g->iter_fn) {   // what the reference logs per iteration (ALS:241-246, 351-358)
+      mals_iteration_info info;
+      std::memset(&info, 0, sizeof(info));
+      info.struct_size = (int32_t)sizeof(info);
+      info.iteration = it;
+      info.avg_abs_difference = mean;
+      info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_it).count();
+      int64_t rows = 0;
+      for (size_t i = 0; i < g->m.size(); ++i) {
+        (void)mals_get_stats(g->m[i].h, &st0);
+        rows += st0.rows_solved - before[i].first;
+        info.entries_gathered += st0.nnz_gathered - before[i].second;
+      }
+      const int64_t x_all = g->n_rows[MALS_SIDE_X], y_all = g->n_rows[MALS_SIDE_Y];
+      info.x_rows = g->single_process ? x_all : rows * x_all / std::max<int64_t>(1, x_all + y_all);
+      info.y_rows = rows - info.x_rows;
+      info.algorithmic_bytes = (double)(info.entries_gathered + rows) * (4.0 * g->cfg.features + 8.0);
+      info.devices = (int32_t)g->m.size();
+      g->iter_fn(g->iter_user, &info);
+    }
     if (max_iterations > 0 && it >= max_iterations) break;              // ALS:242-245
     if (!std::isfinite(mean)) break;                                    // ALS:248-251
     if (!(random_y && it == 1) && mean < convergence_threshold) break;  // ALS:253-256

@@ -21,4 +21,9 @@ __attribute__((visibility("hidden"))) int malsi_gramian_partial(mals_handle h, i
                                                               unsigned* device_max);
 __attribute__((visibility("hidden"))) int malsi_ymax_slots(void);
 __attribute__((visibility("hidden"))) int malsi_set_gramian(mals_handle h, int side, const double* G, int mem_kind, const unsigned* device_max);
+// the event behind which everything a half-iteration sets up once (in its first chunk) is enqueued: a later chunk solved on
+// ANOTHER stream waits for it (mals_group.cpp alternates two compute streams between consecutive chunks)
+__attribute__((visibility("hidden"))) void* malsi_ready_event(mals_handle h);
+// the thread's "why did create fail" text (mals_create_error): set by whichever create call fails, cleared by one that succeeds
+__attribute__((visibility("hidden"))) void malsi_set_create_error(const char* text);
 }

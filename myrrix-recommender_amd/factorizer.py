@@ -9,6 +9,7 @@ this image, so this mirror stands where the Java adapter of INTEGRATION.md would
 densifies ids, streams CSR over the C-ABI and copies factors back -- all arithmetic of the hot path
 runs in the HIP library.
 """
+import logging
 import math
 
 import numpy as np
@@ -16,6 +17,10 @@ import numpy as np
 from . import _lib
 from .random_mt import MersenneTwister
 from .core import ALSCore, Cancelled, MalsError, SingularSystem
+
+
+# the reference logs under its own class name (ALS:68)
+log = logging.getLogger("net.myrrix.online.factorizer.als.AlternatingLeastSquares")
 
 
 class _System:
@@ -325,6 +330,25 @@ class AlternatingLeastSquares(MatrixFactorizer):
             core.set_matrix(_lib.SIDE_X, *r_csr)
             core.set_matrix(_lib.SIDE_Y, *c_csr)
             core.set_factors(_lib.SIDE_Y, Y0m)
+            log.info("Iterating using 1 GPU(s) [%d] (%d features, %d users, %d items)", self.device, k, n_users, n_items)  # ALS:193
+            threshold, max_it = self.estimateErrorConvergenceThreshold, self.maxIterations
+
+            def on_iteration(info):   # the reference's per-iteration lines, ALS:241-256, 351-358
+                secs = max(info["seconds"], 1e-9)
+                log.info("%d X/tag rows computed, %d Y/tag rows computed (%d entries gathered in %.3f s: %.3g rows/s, %.1f GB/s)",
+                         info["x_rows"], info["y_rows"], info["entries_gathered"], info["seconds"],
+                         (info["x_rows"] + info["y_rows"]) / secs, info["algorithmic_bytes"] / secs / 1e9)
+                log.info("Finished iteration %d", info["iteration"])
+                if max_it > 0 and info["iteration"] >= max_it:
+                    log.info("Reached iteration limit")
+                    return
+                log.info("Avg absolute difference in estimate vs prior iteration: %s", info["avg_abs_difference"])
+                if not math.isfinite(info["avg_abs_difference"]):
+                    log.warning("Invalid convergence value, aborting iteration! %s", info["avg_abs_difference"])
+                elif not (random_y and info["iteration"] == 1) and info["avg_abs_difference"] < threshold:
+                    log.info("Converged")
+            self.iterationLog = []
+            core.set_iteration_callback(lambda info: (self.iterationLog.append(info), on_iteration(info)))
             self.iterations, self.convergenceValue = core.factorize(
                 self.estimateErrorConvergenceThreshold, self.maxIterations, random_y, tu, ti,
                 iterate=iterate)

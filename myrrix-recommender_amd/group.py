@@ -74,10 +74,15 @@ class GroupALS:
         g = ctypes.c_void_p()
         rc = L.mals_group_create(ctypes.byref(cfg), devs, len(devices), int(backend), ctypes.byref(g))
         if rc != _lib.OK:
-            raise MalsError(rc, "mals_group_create failed (devices %s)" % (list(devices),))
+            raise MalsError(rc, "mals_group_create failed (devices %s): %s" % (list(devices), _lib.create_error()))
         self = cls(features, g, len(devices))
         self._chk(L.mals_group_set_exchange_chunks(g, int(exchange_chunks)))
         return self
+
+    def set_alternate_streams(self, on):
+        """mals_group_set_alternate_streams: consecutive chunks of a half-iteration on two alternating compute streams
+        (default on) or on one (A/B)."""
+        self._chk(self._L.mals_group_set_alternate_streams(self._g, 1 if on else 0))
 
     @staticmethod
     def use_transport(library_path):
@@ -116,7 +121,7 @@ class GroupALS:
         g = ctypes.c_void_p()
         rc = L.mals_group_create_rank(ctypes.byref(cfg), int(world), int(rank), buf, ctypes.byref(g))
         if rc != _lib.OK:
-            raise MalsError(rc, "mals_group_create_rank failed (rank %d of %d)" % (rank, world))
+            raise MalsError(rc, "mals_group_create_rank failed (rank %d of %d): %s" % (rank, world, _lib.create_error()))
         self = cls(features, g, world)
         self._chk(L.mals_group_set_exchange_chunks(g, int(exchange_chunks)))
         return self

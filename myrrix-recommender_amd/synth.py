@@ -176,6 +176,60 @@ def torch_slice(n_rows, n_cols, nnz, device, rows="items", seed=SEED + 1, chunk=
     return rp, c, vals
 
 
+def torch_problem_sliced(n_users, n_items, nnz, k, device, slices=8, seed=SEED):
+    """The same kind of problem for sizes whose one-shot generation does not fit next to the problem itself (C5 whole on
+    one GPU: 100M x 10M, 5e9 entries -- 40 GB per orientation): R is generated `slices` contiguous user ranges at a time
+    (torch_slice, rows="users", one seed per range) straight into preallocated CSR arrays, and R^T is built from it by a
+    counting sort over the items -- per range a stable sort by item, scattered behind the entries the earlier ranges left
+    for that item, so that every item row is ascending by user like torch_problem's.  Both orientations hold exactly the
+    same `nnz` entries (every int64 offset beyond 2^31 is exercised from 2.15e9 entries on).  Nothing is planted."""
+    import torch
+    assert n_users % slices == 0 and nnz % slices == 0
+    per_u, per_nnz = n_users // slices, nnz // slices
+    r_rp = torch.zeros(n_users + 1, dtype=torch.int64, device=device)
+    r_col = torch.empty(nnz, dtype=torch.int32, device=device)
+    r_val = torch.empty(nnz, dtype=torch.float32, device=device)
+    item_count = torch.zeros(n_items, dtype=torch.int64, device=device)
+    for s_ in range(slices):
+        rp, col, val = torch_slice(per_u, n_items, per_nnz, device, rows="users", seed=seed + 17 * (s_ + 1))
+        assert int(rp[-1]) == per_nnz
+        r_rp[s_ * per_u + 1:(s_ + 1) * per_u + 1] = rp[1:] + s_ * per_nnz
+        r_col[s_ * per_nnz:(s_ + 1) * per_nnz] = col
+        r_val[s_ * per_nnz:(s_ + 1) * per_nnz] = val
+        item_count += torch.bincount(col, minlength=n_items)
+        del rp, col, val
+        torch.cuda.empty_cache()
+    c_rp = torch.zeros(n_items + 1, dtype=torch.int64, device=device)
+    torch.cumsum(item_count, 0, out=c_rp[1:])
+    del item_count
+    c_col = torch.empty(nnz, dtype=torch.int32, device=device)
+    c_val = torch.empty(nnz, dtype=torch.float32, device=device)
+    filled = torch.zeros(n_items, dtype=torch.int64, device=device)
+    for s_ in range(slices):
+        lo, hi = s_ * per_nnz, (s_ + 1) * per_nnz
+        items = r_col[lo:hi].long()
+        lens = r_rp[s_ * per_u + 1:(s_ + 1) * per_u + 1] - r_rp[s_ * per_u:(s_ + 1) * per_u]
+        users = torch.repeat_interleave(torch.arange(s_ * per_u, (s_ + 1) * per_u, device=device, dtype=torch.int32), lens)
+        del lens
+        order = torch.argsort(items, stable=True)            # by item, users ascending inside an item
+        items = items[order]
+        cnt = torch.bincount(items, minlength=n_items)
+        start = torch.cumsum(cnt, 0) - cnt                      # first position of every item inside this range's sorted run
+        pos = c_rp[:-1][items] + filled[items] + (torch.arange(per_nnz, device=device) - start[items])
+        del start, items
+        c_col[pos] = users[order]
+        c_val[pos] = r_val[lo:hi][order]
+        filled += cnt
+        del pos, order, users, cnt
+        torch.cuda.empty_cache()
+    del filled
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    Y0 = torch.randn(n_items, k, generator=g, device=device, dtype=torch.float32)
+    Y0 /= Y0.norm(dim=1, keepdim=True)
+    return {"r_csr": (r_rp, r_col, r_val), "c_csr": (c_rp, c_col, c_val), "Y0": Y0, "nnz": nnz, "planted": None}
+
+
 def planted_reconstruction_error(prob, X, Y, sample=4_000_000):
     """Mean of max(0, 1 - x_u . y_i) over (a sample of) the stored entries of the planted part: core items
     of the user's own cluster.  torch on the device; diagnostics only."""

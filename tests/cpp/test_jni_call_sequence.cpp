@@ -9,6 +9,9 @@
 //   mals_group_factorize                                    call()
 //   mals_group_get_factors(X), (Y)                          getX() / getY()
 //   mals_group_destroy
+// and, since round 4: a create that must fail (device ordinal outside the box) whose reason nativeCreateError hands to the
+// JVM (mals_group_create_error), and the per-iteration callback behind the adapter's log lines
+// (mals_group_set_iteration_callback -> IterationListener.iteration, ALS:241-246, 351-358).
 // on the reference's known-answer cases (AlternatingLeastSquaresTest.java:42-77, NegativeInputTest.java:71-79;
 // tests/golden/reference_known_answers.json, written to a text file by tests/test_jni_sequence.py):
 // X*Y^T must equal the expected matrix to the reference's own 1e-6.
@@ -16,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/myrrix_als.h"
@@ -66,9 +70,33 @@ int main(int argc, char** argv) {
   cfg.features = features;
   cfg.flags = flags;
   std::vector<int32_t> devices((size_t)n_members, 0);
+  {   // nativeCreate with -Dmodel.als.gpus=4095: returns 0, and the JVM learns WHY (nativeCreateError)
+    std::vector<int32_t> nowhere(1, 4095);
+    mals_group bad = nullptr;
+    char why[512];
+    if (mals_group_create(&cfg, nowhere.data(), 1, backend, &bad) == MALS_OK || bad) {
+      std::printf("a group on device 4095 must not exist\n");
+      return 4;
+    }
+    const int need = mals_group_create_error(why, sizeof(why));
+    if (need <= 0 || !std::strstr(why, "4095")) {
+      std::printf("mals_group_create_error does not name the reason: \"%s\"\n", why);
+      return 4;
+    }
+    std::printf("create on device 4095: %s\n", why);
+  }
   if (mals_group_create(&cfg, devices.data(), n_members, backend, &g) != MALS_OK) {
-    std::printf("mals_group_create failed: a HIP device is required, there is no CPU fallback\n");
+    char why[512];
+    (void)mals_group_create_error(why, sizeof(why));
+    std::printf("mals_group_create failed: %s\n", why);
     return 3;
+  }
+  {
+    char why[8];
+    if (mals_group_create_error(why, sizeof(why)) != 0 || why[0]) {
+      std::printf("mals_group_create_error must be empty after a success\n");
+      return 4;
+    }
   }
   REQUIRE_OK(mals_group_set_refine_limit(g, 128.0));   // -Dmodel.als.gpu.refineLimit, when set
   REQUIRE_OK(mals_group_set_factor_rows(g, MALS_SIDE_X, n_users));
@@ -105,8 +133,32 @@ int main(int argc, char** argv) {
   for (int i = 0; i < n_items; ++i) test_items[(size_t)i] = i;
   int32_t iterations = 0;
   double convergence = 0.0;
+  struct Seen {
+    int calls = 0, last_iteration = 0;
+    double last_value = 0.0;
+    long long rows = 0;
+    bool ok = true;
+  } seen;
+  // nativeFactorize: the listener behind the adapter's "Finished iteration {}" / "Avg absolute difference ..." lines
+  REQUIRE_OK(mals_group_set_iteration_callback(g, [](void* user, const mals_iteration_info* info) {
+    Seen* sn = static_cast<Seen*>(user);
+    sn->ok = sn->ok && info->struct_size == (int32_t)sizeof(mals_iteration_info) && info->iteration == sn->last_iteration + 1 &&
+             info->seconds > 0.0 && info->devices >= 1 && info->algorithmic_bytes > 0.0;
+    ++sn->calls;
+    sn->last_iteration = info->iteration;
+    sn->last_value = info->avg_abs_difference;
+    sn->rows = (long long)(info->x_rows + info->y_rows);
+  }, &seen));
   REQUIRE_OK(mals_group_factorize(g, threshold, max_iterations, /*random_y=*/0, /*iterate=*/1, test_users.data(), n_users,
                                   test_items.data(), n_items, &iterations, &convergence));
+  REQUIRE_OK(mals_group_set_iteration_callback(g, nullptr, nullptr));
+  if (!seen.ok || seen.calls != iterations || seen.last_iteration != iterations || seen.last_value != convergence ||
+      seen.rows != (long long)n_users + n_items) {
+    std::printf("iteration callback: %d calls for %d iterations, last value %.17g vs %.17g, rows %lld\n", seen.calls, iterations,
+                seen.last_value, convergence, seen.rows);
+    return 5;
+  }
+  std::printf("iteration callback: %d calls, last avg abs difference %.6g\n", seen.calls, seen.last_value);
   std::vector<float> X((size_t)n_users * features), Y((size_t)n_items * features);
   for (int r0 = 0; r0 < n_users; r0 += piece)
     REQUIRE_OK(mals_group_get_factors(g, MALS_SIDE_X, r0, r0 + piece < n_users ? piece : n_users - r0, X.data() + (size_t)r0 * features));

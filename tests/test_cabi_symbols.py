@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(L, name), name
-    assert _lib.load().mals_abi_version() == 2
+    assert _lib.load().mals_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -53,6 +53,30 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.mals_create(ctypes.byref(cfg), ctypes.byref(h)) == _lib.INVALID_ARG
     assert L.mals_destroy(None) == _lib.INVALID_ARG
     assert L.mals_solve_side(None, 0) == _lib.INVALID_ARG
+
+
+def test_create_failures_say_why():
+    """mals_create_error / mals_group_create_error: a create that fails leaves no handle to ask -- the reason (which the
+    JNI shim hands to the JVM, jni/myrrix_als_jni.c nativeCreateError) is kept per thread."""
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    cfg = _lib.Config()
+    L.mals_default_config(ctypes.byref(cfg))
+    cfg.features = 129
+    assert L.mals_create(ctypes.byref(cfg), ctypes.byref(h)) == _lib.INVALID_ARG
+    assert "features" in _lib.create_error() and "129" in _lib.create_error()
+    buf = ctypes.create_string_buffer(8)                      # a short buffer: truncated, NUL-terminated, full length returned
+    assert L.mals_group_create_error(buf, 8) > 8 and len(buf.value) == 7
+    cfg.features = 16
+    cfg.device = 4095
+    rc = L.mals_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc == _lib.HIP_ERROR
+    why = _lib.create_error()
+    assert "4095" in why or "no HIP device" in why, why      # no GPU here: "no HIP device"; on a GPU box: the ordinal
+    g = ctypes.c_void_p()
+    devs = (ctypes.c_int32 * 1)(4095)
+    assert L.mals_group_create(ctypes.byref(cfg), devs, 1, 1, ctypes.byref(g)) != _lib.OK and not g.value
+    assert _lib.create_error().startswith("mals_group_create")
 
 
 def test_no_cpu_fallback_without_gpu():

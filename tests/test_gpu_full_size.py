@@ -48,12 +48,14 @@ def sub_csr(csr, rows, torch):
     return sub_rp.cpu().numpy(), csr[1][ent].cpu().numpy(), csr[2][ent].cpu().numpy()
 
 
-def check_half(core, side, csr, M, G, n_rows, rng, torch, n_sample=300, n_long=8, row_offset=0):
+def check_half(core, side, csr, M, G, n_rows, rng, torch, n_sample=300, n_long=8, row_offset=0, max_long_len=None):
     """Compare sampled + longest rows of `side` against the oracle.  M: the opposite factors, a host array or --
     when the replica is too large to copy (C5's X: 51 GB) -- a device tensor, of which only the rows the sample
     touches are fetched (columns renumbered; a row's system only depends on the rows it references and on G)."""
     lens = (csr[0][1:] - csr[0][:-1])
-    longest = torch.topk(lens, n_long).indices.cpu().numpy()
+    # (max_long_len: the longest rows the ORACLE finishes in test time -- one thread per row, n_u k^2 fp64 FMAs each)
+    cand = lens if max_long_len is None else torch.where(lens <= max_long_len, lens, torch.zeros_like(lens))
+    longest = torch.topk(cand, n_long).indices.cpu().numpy()
     sample = rng.choice(n_rows, size=n_sample, replace=False)
     rows = np.unique(np.concatenate([sample, longest])).astype(np.int64)
     rp, col, val = sub_csr(csr, rows, torch)
@@ -226,3 +228,58 @@ def test_c5_rank_at_its_true_shape():
         free2, _ = torch.cuda.mem_get_info()
         assert (total - free2) < 0.75 * total, ((total - free2) / 1e9, total / 1e9)
         del rotated_copy
+
+
+def test_c5_whole_on_one_device():
+    """C5 as a WHOLE problem on one MI355X (ALS:340-389): 100M users x 10M items, 5e9 entries, k = 128 --
+    80 GB of CSR + CSC, 56 GB of factors, resident together.  The first handle with more than 2^31 entries: every int64
+    offset (row_ptr, WorkItem.begin, the work-list counting sort, the segment slots) is exercised at that size.  Both
+    half-iterations against the oracle on sampled rows + the longest rows the oracle finishes in test time (2M entries:
+    ~490 segments, the grouped pre-reduction of the finish kernel), the Gramians against an independent fp64 matmul."""
+    import torch
+    dev = torch.device("cuda", 0)
+    free, total = torch.cuda.mem_get_info()
+    if total < 250e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    rng = np.random.default_rng(1234567890)
+    n_users, n_items, nnz, k = 100_000_000, 10_000_000, 5_000_000_000, 128
+    prob = synth.torch_problem_sliced(n_users, n_items, nnz, k, dev, slices=8)
+    assert prob["r_csr"][1].numel() == nnz == prob["c_csr"][1].numel() and nnz > 2 ** 31
+    assert int(prob["r_csr"][0][-1]) == nnz and int(prob["c_csr"][0][-1]) == nnz
+    # the two orientations hold the same entries: the same multiset of values per item, checked on a few item rows
+    for item in (0, 4_999_999, n_items - 1):
+        a, b = int(prob["c_csr"][0][item]), int(prob["c_csr"][0][item + 1])
+        users = prob["c_csr"][1][a:b].long()
+        assert bool((users[1:] > users[:-1]).all())
+        u0 = int(users[0]) if b > a else None
+        if u0 is not None:
+            ra, rb = int(prob["r_csr"][0][u0]), int(prob["r_csr"][0][u0 + 1])
+            assert item in prob["r_csr"][1][ra:rb].tolist()
+    with pkg.ALSCore(k, device=0) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_matrix(pkg.SIDE_X, *prob["r_csr"])
+        core.set_matrix(pkg.SIDE_Y, *prob["c_csr"])
+        core.set_factors(pkg.SIDE_Y, prob["Y0"])
+        core.reset_stats()
+        core.half_iteration(pkg.SIDE_X)
+        core.check()
+        Gy = independent_gramian(prob["Y0"], torch, dev)
+        check_half(core, pkg.SIDE_X, prob["r_csr"], prob["Y0"].cpu().numpy(), Gy, n_users, rng, torch)
+        ptr, n = core.factor_device_ptr(pkg.SIDE_X)
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (n, k), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        X = torch.as_tensor(_View(), device=dev)
+        assert bool(torch.isfinite(X).all())
+        core.half_iteration(pkg.SIDE_Y)
+        core.check()
+        Gx = independent_gramian(X, torch, dev)
+        assert rel(core.gramian(pkg.SIDE_X, fetch=True), Gx) < 5e-7
+        max_len = check_half(core, pkg.SIDE_Y, prob["c_csr"], X, Gx, n_items, rng, torch, n_long=4, max_long_len=2_000_000)
+        assert max_len > 4096 * 32, "the popular items go through the grouped finish of the long-row path"
+        st = core.stats()
+        assert st["rows_solved"] == n_users + n_items and st["nnz_gathered"] == 2 * nnz
+        assert st["rows_dual"] > 0
+        free2, _ = torch.cuda.mem_get_info()
+        assert (total - free2) < 0.9 * total, ((total - free2) / 1e9, total / 1e9)

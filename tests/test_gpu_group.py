@@ -60,6 +60,35 @@ def test_peer_copy_group_matches_oracle(world, k, chunks):
     assert np.array_equal(Y[n_items:], stale)
 
 
+@pytest.mark.parametrize("k,world", [(64, 1), (64, 3), (128, 2), (50, 2)])
+def test_chunks_on_alternating_streams_leave_the_factors_bitwise_alone(k, world):
+    """Consecutive chunks of a half-iteration run on two alternating compute streams (a chunk's tail overlaps the next
+    chunk's head; mals_group_set_alternate_streams).  Neither that nor the chunking itself may change a single bit: every
+    row is solved from the same inputs by the same kernel whichever chunk and stream it is in.  4 chunks on two streams vs
+    4 chunks on one vs 1 chunk, three iterations, every path live (dual rows, direct rows, long rows in fixed 64-entry
+    segments, refinement of planted ill-conditioned rows)."""
+    n_users, n_items = 6000, 900
+    r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 90000, k, seed=4242 + k, negatives=0.05)
+    res = {}
+    for name, chunks, alternate in (("two streams", 4, True), ("one stream", 4, False), ("one chunk", 1, True)):
+        with pkg.GroupALS.single_process(k, [0] * world, backend=_lib.GROUP_PEER_COPY, exchange_chunks=chunks, segment_nnz=64) as g:
+            g.set_alternate_streams(alternate)
+            g.set_factor_rows(pkg.SIDE_X, n_users)
+            g.set_factor_rows(pkg.SIDE_Y, n_items)
+            g.set_matrix(pkg.SIDE_X, *r_csr)
+            g.set_matrix(pkg.SIDE_Y, *c_csr)
+            g.set_factors(pkg.SIDE_Y, Y0)
+            g.iterate(3)
+            res[name] = (g.get_factors(pkg.SIDE_X, 0, n_users), g.get_factors(pkg.SIDE_Y, 0, n_items))
+            st = g.local(0)[0].stats()
+            assert st["rows_solved"] > 0
+    for name in ("one stream", "one chunk"):
+        assert np.array_equal(res["two streams"][0], res[name][0]), (name, rel(res["two streams"][0], res[name][0]))
+        assert np.array_equal(res["two streams"][1], res[name][1]), (name, rel(res["two streams"][1], res[name][1]))
+    Xo, Yo = oracle_iterations(r_csr, c_csr, Y0, 3)
+    assert rel(res["two streams"][0], Xo) < REL_TOL and rel(res["two streams"][1], Yo) < REL_TOL
+
+
 def test_group_result_does_not_depend_on_the_sharding():
     k, n_users, n_items = 64, 2000, 600
     r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 25000, k, seed=77)

@@ -144,6 +144,8 @@ def test_bench_script_as_the_driver_launches_it(world):
     d = json.loads(lines[-1])
     assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "rows/s" and d["value"] > 0 and d["scaling"] == "strong"
+    # the same steps timed once more with the status check of every half-iteration inside the region
+    assert d["ms_per_step_with_check"] > 0 and d["value_with_check"] > 0
     assert "INVALID_AS_A_MEASUREMENT" in d          # the line says what it is
     assert "RCCL below the C-ABI" in d["config"]["sharding"]
     xb = d["config"]["slices"]["x_bounds"]
@@ -157,3 +159,29 @@ def test_bench_script_as_the_driver_launches_it(world):
     assert sum(r["x_nnz"] for r in rk["per_rank"]) == d["config"]["nnz"] == sum(r["y_nnz"] for r in rk["per_rank"])
     assert all(r["pci_bus_id"] for r in rk["per_rank"]) and 0 < rk["ms_per_step_min"] <= rk["ms_per_step_max"]
     assert 0.0 <= d["reconstruction_error"]["mean"] <= 1.0
+
+
+def test_bench_line_on_one_gpu_says_what_it_leaves_out():
+    """`python bench.py` (N = 1) on the small workload: the line carries the time with the per-half status check inside the
+    timed region, the CPU baseline sampled by time (work units per thread, CPU model, threads), the fp32-arithmetic leg
+    beside the split-f16 headline, and the operand scale / range flag of the last split-precision gather."""
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MALS_BENCH_TRANSPORT", "MALS_BENCH_ONE_DEVICE"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload", "small"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["ms_per_step"] > 0 and d["ms_per_step_with_check"] > 0
+    assert 0.5 * d["ms_per_step"] < d["ms_per_step_with_check"] < 3.0 * d["ms_per_step"]
+    rf, r32 = d["roofline"], d["roofline_fp32"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1.2 and rf["peak"] == 8000.0
+    assert r32["ms_per_step"] > 0 and 0 < r32["frac"] < 1.2 and "fp32" in r32["workload"]
+    assert r32["nnz"] == d["config"]["nnz"]                      # the same problem, another arithmetic
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "rows/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["cpu_model"]
+    assert "work units of 100 rows per thread" in cb["sample"]
+    gs = d["gather_scale"]
+    assert len(gs) == 4 and gs[2] == 1.0 and gs[0] > 0          # the split-f16 kernels ran, not their fp32 twins
+    assert "roofline_unplanted" in d

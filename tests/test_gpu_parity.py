@@ -68,6 +68,25 @@ def test_reference_known_answers(name):
     assert err <= case["tol"], (name, err, als.iterations)   # the reference's own 1e-6 (MyrrixTest.java:34)
 
 
+def test_call_logs_the_reference_lines_per_iteration(caplog):
+    """SURVEY.md section 5 "Metrics/logging": the per-iteration lines of call() (ALS:193, 241-256, 351-358) come out of the
+    host mirror while the native loop runs -- through mals_set_iteration_callback, under the reference's logger name --
+    with the same convergence values mals_factorize returns."""
+    import logging
+    case = GOLDEN["als_default"]
+    with caplog.at_level(logging.INFO, logger="net.myrrix.online.factorizer.als.AlternatingLeastSquares"):
+        _, als = build_test_xyt_product(case)
+    text = [r.getMessage() for r in caplog.records]
+    assert any(m.startswith("Iterating using 1 GPU(s)") for m in text)
+    assert sum(m.startswith("Finished iteration ") for m in text) == als.iterations == len(als.iterationLog)
+    assert [i["iteration"] for i in als.iterationLog] == list(range(1, als.iterations + 1))
+    assert als.iterationLog[-1]["avg_abs_difference"] == als.convergenceValue
+    assert any(m == "Converged" or m == "Reached iteration limit" for m in text)
+    assert any("X/tag rows computed" in m and "rows/s" in m for m in text)
+    diffs = [m for m in text if m.startswith("Avg absolute difference in estimate vs prior iteration: ")]
+    assert len(diffs) >= als.iterations - 1
+
+
 def test_gramian_known_answer_and_vs_oracle():
     g = GOLDEN["gramian"]
     M = np.array(g["M"], dtype=np.float32)

@@ -13,7 +13,7 @@ for wl in $WLS; do
     spec=$lib; envs=""; case "$lib" in *@*) spec=${lib%%@*}; envs=${lib#*@};; esac
     if [ "$spec" = "default" ]; then unset MALS_LIB; else export MALS_LIB=$ROOT/myrrix-recommender_amd/csrc/$spec; fi
     for kv in $(echo "$envs" | tr ',' ' '); do export "$kv"; done
-    timeout 600 python bench.py --workload $wl --no-cpu-baseline --no-unplanted --steps 5 --warmup 2 "$@" > $OUT/${wl}_${lib}.json 2> $OUT/${wl}_${lib}.err
+    timeout 600 python bench.py --workload $wl --no-cpu-baseline --no-unplanted --no-fp32-leg --steps 5 --warmup 2 "$@" > $OUT/${wl}_${lib}.json 2> $OUT/${wl}_${lib}.err
     python - <<PY
 import json
 try:
