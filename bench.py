@@ -529,9 +529,12 @@ def main():
             # one "launch" = the dual kernels of one half-iteration (up to 4 row classes back to back)
             n_launch = max(st["rows_launches"], 1) if st["rows_launches"] else max(st["dual_launches"], 1)
         else:
-            kernel_name = ("mals::als_persistent_kernel_h<T=%d,MODE=0> (fused gather + split-f16 Gramian + Cholesky, rows)"
-                           if split else
-                           "mals::als_persistent_kernel<T=%d,D,MODE=0> (fused gather + fp32 Gramian + Cholesky, rows)") % ((k + 15) // 16)
+            if split and k == 128 and os.environ.get("MALS_LDS_GATHER", "1") != "0":
+                kernel_name = "mals::als_lds_kernel_h<MODE=0> (k = 128: gather staged through LDS by global_load_lds, split-f16 Gramian in 32-entry super-steps + Cholesky, rows)"
+            else:
+                kernel_name = ("mals::als_persistent_kernel_h<T=%d,MODE=0> (fused gather + split-f16 Gramian + Cholesky, rows)"
+                               if split else
+                               "mals::als_persistent_kernel<T=%d,D,MODE=0> (fused gather + fp32 Gramian + Cholesky, rows)") % ((k + 15) // 16)
             n_launch = max(st["rows_launches"], 1)
         avg_ms = st[dom + "_ms"] / n_launch
         bytes_per_launch = st[dom + "_bytes"] / n_launch

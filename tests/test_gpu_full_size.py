@@ -260,12 +260,13 @@ def test_c5_whole_on_one_device():
         core.set_factor_rows(pkg.SIDE_Y, n_items)
         core.set_matrix(pkg.SIDE_X, *prob["r_csr"])
         core.set_matrix(pkg.SIDE_Y, *prob["c_csr"])
-        core.set_factors(pkg.SIDE_Y, prob["Y0"])
+        Y0 = prob["Y0"].cpu().numpy()
+        core.set_factors(pkg.SIDE_Y, Y0)
         core.reset_stats()
         core.half_iteration(pkg.SIDE_X)
         core.check()
         Gy = independent_gramian(prob["Y0"], torch, dev)
-        check_half(core, pkg.SIDE_X, prob["r_csr"], prob["Y0"].cpu().numpy(), Gy, n_users, rng, torch)
+        check_half(core, pkg.SIDE_X, prob["r_csr"], Y0, Gy, n_users, rng, torch)
         ptr, n = core.factor_device_ptr(pkg.SIDE_X)
 
         class _View:
