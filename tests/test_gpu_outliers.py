@@ -126,9 +126,15 @@ def test_heavy_confidence_weights_are_refined(k, flags, segment_nnz, solve_mode)
     assert rel(Y, Yo) <= rel(Y_off, Yo) * 1.05
 
 
-@pytest.mark.parametrize("seed,solve_mode,gramian_mode", [(103, _lib.SOLVE_DIRECT, _lib.GRAMIAN_FP32), (103, _lib.SOLVE_DUAL, 0), (103, 0, 0),
-                                                          (175, 0, 0), (175, _lib.SOLVE_DUAL, _lib.GRAMIAN_FP32), (176, 0, 0)])
-def test_systems_the_fp32_path_alone_gets_wrong(seed, solve_mode, gramian_mode):
+@pytest.mark.parametrize("seed,solve_mode,gramian_mode,alone_wrong", [
+    (103, _lib.SOLVE_DIRECT, _lib.GRAMIAN_FP32, True),
+    # seed 103 draws chunk_rows = 97: until round 4 only the FIRST chunk of a multi-chunk half-iteration took the dual path
+    #  and the direct fp32 kernel missed the bar on the others' short rows; with the dual path in every chunk the
+    # short rows -- S = I + Z Z^T is well conditioned where W is not -- are within 1e-6 without any refinement
+    (103, _lib.SOLVE_DUAL, 0, False),
+    (103, 0, 0, False),   # (AUTO = dual at k = 49: the same 436 short rows in every chunk)
+    (175, 0, 0, True), (175, _lib.SOLVE_DUAL, _lib.GRAMIAN_FP32, True), (176, 0, 0, True)])
+def test_systems_the_fp32_path_alone_gets_wrong(seed, solve_mode, gramian_mode, alone_wrong):
     """Cases of the seeded sweep (tests/test_gpu_fuzz.py) on which the fp32 accumulation + factorization alone misses
     the 1e-4 bar by up to 8x (cond(W) 3e3 .. 7e4), in every arithmetic and solve mode: with the marks and
     als_refine_kernel the same kernels land within 1e-6 of the reference."""
@@ -152,8 +158,9 @@ def test_systems_the_fp32_path_alone_gets_wrong(seed, solve_mode, gramian_mode):
             core.half_iteration(pkg.SIDE_Y)
             core.check()
             err[limit] = (rel(core.get_factors(pkg.SIDE_Y)[:n_items], Yo), core.stats()["rows_refined"])
-    assert err[0.0][0] > 8e-5 and err[0.0][1] == 0, err
-    assert err[None][0] < 1e-5 and err[None][1] > 0, err
+    assert err[0.0][1] == 0, err
+    assert (err[0.0][0] > 8e-5) if alone_wrong else (err[0.0][0] < 1e-5), err
+    assert err[None][0] < 1e-5 and (err[None][1] > 0 or not alone_wrong), err
 
 
 # 2145, 2550: reconstructR on a Gramian of fewer factor rows than features -- the reference's M^T M rounds every product
