@@ -61,12 +61,12 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, min_seconds=2.0, units_per_thread=16):
+def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, min_seconds=2.0, units_per_thread=16, max_seconds=12.0):
     """Reference's CPU path, restated (oracle = "port"), timed on this host's cores on a bounded random sample of rows
     and extrapolated by row count.  The sample is sized by TIME, not by count: per side at least `units_per_thread` of the
     reference's 100-row work units (ALS:77, ALS:398-408) for every thread -- so that no thread of a 256-thread host sits
-    idle, as it did with a fixed 10 000-row sample -- doubled until the side's solve runs `min_seconds` (or every row is in
-    it).  The Gramian (serial in the reference, ALS:342 -> MU:219-239) is timed on a row sample too."""
+    idle, as it did with a fixed 10 000-row sample -- doubled until the side's solve has run `min_seconds` with that many
+    units (or every row is in it, or a run has taken `max_seconds`: the whole baseline stays within ~30 s of CPU work).  The Gramian (serial in the reference, ALS:342 -> MU:219-239) is timed on a row sample too."""
     import numpy as np
     from oracle import oracle
     threads = os.cpu_count() or 1
@@ -82,7 +82,11 @@ def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, min_seconds=2.0, u
         G = G * (Mh.shape[0] / g_rows)  # keep the systems well-posed for the timing run
         rp = csr[0]
         perm = rng.permutation(n_rows)
-        n_s = min(n_rows, units_per_thread * 100 * threads)
+        # first sample: ~40M entries' worth of rows, never fewer than 4 work units per thread, never more than the
+        # `units_per_thread` the loop below aims for; then doubled until it has BOTH run min_seconds and given every thread
+        # its units -- or has taken max_seconds (long item rows: 16 units x 256 threads x 1000 entries would be a minute)
+        avg_len = max(1.0, float(int(rp[-1])) / max(n_rows, 1))
+        n_s = int(min(n_rows, max(4 * 100 * threads, min(units_per_thread * 100 * threads, 40e6 / avg_len))))
         while True:
             rows = torch.from_numpy(np.sort(perm[:n_s])).to(rp.device)
             lens = rp[rows + 1] - rp[rows]
@@ -97,9 +101,10 @@ def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, min_seconds=2.0, u
             t0 = time.perf_counter()
             oracle.solve_rows(sub_rp_h, sub_col, sub_val, Mh, G, threads=threads)
             t_run = time.perf_counter() - t0
-            if t_run >= min_seconds or n_s >= n_rows or len(sub_col) > 600_000_000:
+            enough = t_run >= min_seconds and n_s >= units_per_thread * 100 * threads
+            if enough or t_run >= max_seconds or n_s >= n_rows or len(sub_col) > 600_000_000:
                 break
-            n_s = min(n_rows, max(2 * n_s, int(n_s * 1.3 * min_seconds / max(t_run, 1e-3))))
+            n_s = min(n_rows, 2 * n_s)
         t_s = t_run * (n_rows / n_s)
         total_t += t_g + t_s
         sample_desc.append("%d of %d %s rows (%d entries, %.1f work units of 100 rows per thread, %.2f s) + Gramian on %d of %d rows" %
@@ -446,6 +451,7 @@ def main():
     add_tally(st)
     # the same loop with the status check of every half-iteration INSIDE the timed region (mals_check: one D2H of the
     # bad-row / suspect words + a stream sync per half, what mals_factorize and the group path always pay; ALS:346-361)
+    core.reset_stats()       # (st above keeps the timed region's tallies)
     barrier()
     t0 = time.perf_counter()
     als.iterate(args.steps, check=True)
@@ -466,6 +472,8 @@ def main():
             halves[name] = {kk: round(h[kk + "_ms"], 3) for kk in ("rows", "segments", "finish", "gramian", "dual", "rotate")}
             halves[name]["rows_dual"] = h["rows_dual"]
             halves[name]["rows_GBps"] = round(h["rows_bytes"] / max(h["rows_ms"], 1e-9) / 1e6, 1)
+            halves[name]["segments_GBps"] = round(h["segments_bytes"] / max(h["segments_ms"], 1e-9) / 1e6, 1) if h["segments_bytes"] else None
+            halves[name]["dual_GBps"] = round(h["dual_bytes"] / max(h["dual_ms"], 1e-9) / 1e6, 1) if h["dual_bytes"] else None
             add_tally(h)
         core.enable_timing(False)
     # untimed: the exchange on its own ("report all-gather time separately") -- the
