@@ -448,8 +448,9 @@ int build_work_lists(mals_handle h, SideState& s) {
   s.nB = (int64_t)segs.size();
   s.nC = (int64_t)rowsC.size();
   if (std::getenv("MALS_DEBUG_LISTS")) {  // work decomposition of the upload (tuning aid)
-    int64_t nd[4] = {0, 0, 0, 0}, ed[4] = {0, 0, 0, 0}, na = 0, nz = 0;
+    int64_t nd[4] = {0, 0, 0, 0}, ed[4] = {0, 0, 0, 0}, na = 0, nz = 0, n_long = 0;   // (s.nC also counts the slot groups)
     for (const SideState::ChunkRange& cr : s.chunks) {
+      n_long += cr.nC;
       for (int c = 0; c < 4; ++c) {
         nd[c] += cr.nD[c];
         ed[c] += cr.nnzD[c];
@@ -460,7 +461,7 @@ int build_work_lists(mals_handle h, SideState& s) {
     std::fprintf(stderr, "[lists] rows %lld: direct %lld (%lld entries), dual 1-16: %lld (%lld) 17-32: %lld (%lld) 33-48: %lld (%lld) 49-64: %lld (%lld), "
                          "zero-filled %lld, segments %lld of %lld long rows (%lld entries)\n",
                  (long long)n, (long long)na, (long long)s.nnzA, (long long)nd[0], (long long)ed[0], (long long)nd[1], (long long)ed[1], (long long)nd[2],
-                 (long long)ed[2], (long long)nd[3], (long long)ed[3], (long long)nz, (long long)s.nB, (long long)s.nC, (long long)s.nnzB);
+                 (long long)ed[2], (long long)nd[3], (long long)ed[3], (long long)nz, (long long)s.nB, (long long)n_long, (long long)s.nnzB);
   }
   if (s.nA) {
     HIPCHK(h, hipMalloc(&s.itemsA, sizeof(WorkItem) * order.size()));
