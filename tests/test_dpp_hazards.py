@@ -32,6 +32,29 @@ def test_no_dpp_read_after_valu_write(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "ds_bpermute_b32" in text
+    check_lds_gather_windows(text)
+
+
+def check_lds_gather_windows(text):
+    """csrc/lds_kernels.h retires its LDS-DMA loads with COUNTED waits (s_waitcnt vmcnt(12)): on gfx9 loads complete in
+    order among themselves but not with respect to stores, so no store of any kind -- a scratch spill included -- may sit
+    inside the gather loop.  The loop body is the basic block with the super-step's 108 matrix instructions: it must hold
+    16 global_load_lds_dwordx4, the four counted waits, and no store; and every kernel must drain its LDS-DMA
+    (vmcnt(0)) before it ends, or a late load would land in another workgroup's LDS."""
+    import re
+    for mode in (0, 1):
+        name = "_ZN4mals16als_lds_kernel_hILi%dEEEvNS_11SolveParamsE" % mode
+        a = text.index("\n" + name + ":")
+        body = text[a:text.index("s_endpgm", a)]
+        blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
+        loops = [b for b in blocks if b.count("v_mfma_f32_16x16x32") == 108]
+        assert len(loops) == 1, (mode, [b.count("v_mfma") for b in blocks if "v_mfma" in b])
+        loop = loops[0]
+        assert loop.count("global_load_lds_dwordx4") == 16
+        assert loop.count("s_waitcnt vmcnt(12)") == 4
+        for op in ("scratch_store", "global_store", "buffer_store", "flat_store", "scratch_load"):
+            assert op not in loop, (mode, op)
+        assert "s_waitcnt vmcnt(0)" in body.split("global_load_lds")[-1], mode   # drained after the last LDS-DMA
 
 
 def test_lds_window_checker_sees_an_early_read(tmp_path):
