@@ -86,7 +86,11 @@ def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, min_seconds=2.0, u
         # `units_per_thread` the loop below aims for; then doubled until it has BOTH run min_seconds and given every thread
         # its units -- or has taken max_seconds (long item rows: 16 units x 256 threads x 1000 entries would be a minute)
         avg_len = max(1.0, float(int(rp[-1])) / max(n_rows, 1))
-        n_s = int(min(n_rows, max(4 * 100 * threads, min(units_per_thread * 100 * threads, 40e6 / avg_len))))
+        target = units_per_thread * 100 * threads                 # what the loop aims for: every thread its units
+        floor_units = 4 if avg_len <= 500 else 2                  # long rows (C4's items: ~1000 entries) cost ~6 s per unit per thread
+        n_s = int(min(n_rows, max(floor_units * 100 * threads, min(target, 40e6 / avg_len))))
+        if n_s >= 0.9 * target:
+            n_s = min(n_rows, target)
         while True:
             rows = torch.from_numpy(np.sort(perm[:n_s])).to(rp.device)
             lens = rp[rows + 1] - rp[rows]
@@ -101,7 +105,7 @@ def cpu_baseline(torch, pkg, prob, X, Y, n_users, n_items, k, min_seconds=2.0, u
             t0 = time.perf_counter()
             oracle.solve_rows(sub_rp_h, sub_col, sub_val, Mh, G, threads=threads)
             t_run = time.perf_counter() - t0
-            enough = t_run >= min_seconds and n_s >= units_per_thread * 100 * threads
+            enough = t_run >= min_seconds and n_s >= min(n_rows, target)
             if enough or t_run >= max_seconds or n_s >= n_rows or len(sub_col) > 600_000_000:
                 break
             n_s = min(n_rows, 2 * n_s)
