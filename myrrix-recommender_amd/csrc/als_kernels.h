@@ -303,6 +303,13 @@ template <int T, bool SPLIT = false, bool RESPLIT = (T >= MALS_SYRK_RESPLIT_MINT
 __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
 #pragma unroll
   for (int kb = 0; kb < T; ++kb) {
+#ifdef MALS_DOUBLE_DIAG   // ablation by duplication (exp builds): what one more factor_diag per tile costs in place
+    {
+      float mp2 = minpiv;
+      const f32x4 twice = factor_diag(acc[tidx(T, kb, kb)], lane, mp2);
+      asm volatile("" ::"v"(twice[0]), "v"(twice[1]), "v"(twice[2]), "v"(twice[3]), "v"(mp2));
+    }
+#endif
     const f32x4 Uinv = factor_diag(acc[tidx(T, kb, kb)], lane, minpiv);
     acc[tidx(T, kb, kb)] = Uinv;
 #pragma unroll
