@@ -132,10 +132,27 @@ __device__ __forceinline__ float reduce_row16(float x) {  // all 16 lanes of a r
   x += row_ror<1>(x);
   return x;
 }
-__device__ __forceinline__ float reduce_groups(float x, int lane) {  // sum over the 4 lane groups
+#ifndef MALS_REDUCE_GROUPS_BPERM
+#define MALS_REDUCE_GROUPS_BPERM 0
+#endif
+// sum over the 4 lane groups (same c), every lane gets the total.  gfx950's v_permlane32_swap / v_permlane16_swap move
+// whole 32- / 16-lane halves between two registers on the VALU: with both operands = x the pair comes back as
+// ([x0 x1 x0 x1], [x2 x3 x2 x3]) resp. ([s0 s0 s2 s2], [s1 s1 s3 s3]) (rows of 16 lanes), so two swap + add stages
+// replace two dependent ds_bpermute round trips (the block solves chain 16 of these per row).
+__device__ __forceinline__ float reduce_groups(float x, int lane) {
+#if MALS_REDUCE_GROUPS_BPERM
   x += bperm((lane ^ 16) << 2, x);
   x += bperm((lane ^ 32) << 2, x);
   return x;
+#else
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned xi = __float_as_uint(x);
+  const u32x2 a = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned si = __float_as_uint(s);
+  const u32x2 b = __builtin_amdgcn_permlane16_swap(si, si, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+#endif
 }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

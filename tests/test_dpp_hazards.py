@@ -79,3 +79,23 @@ def test_lds_window_checker_sees_an_early_read(tmp_path):
     assert younger.returncode == 1
     label = run("\tds_bpermute_b32 v3, v1, v2\n.LBB0_1:                 ; in Loop\n\tv_mov_b32_e32 v9, v3\n")
     assert label.returncode == 0
+
+
+def test_dpp_checker_sees_range_and_swap_writes(tmp_path):
+    """The checker itself on synthetic listings: a write through a register range (v_pk_fma_f32 v[10:11]) or through the
+    second operand of a v_permlane*_swap is a VALU write of the DPP source; an s_nop 1 or two other instructions clear it."""
+    tool = os.path.join(ROOT, "tools", "check_dpp_hazards.py")
+    dpp = "v_fmac_f32_dpp v3, v11, v4 row_newbcast:0 row_mask:0xf bank_mask:0xf"
+    cases = [
+        (["v_pk_fma_f32 v[10:11], v[0:1], v[2:3], v[4:5]", dpp], 1),
+        (["v_permlane16_swap_b32_e32 v1, v11", dpp], 1),
+        (["v_permlane32_swap_b32_e32 v11, v2", "v_add_f32_e32 v9, v1, v2", dpp], 1),
+        (["v_mov_b32_e32 v11, v2", "s_nop 1", dpp], 0),
+        (["v_mov_b32_e32 v11, v2", "v_add_f32_e32 v9, v1, v2", "v_add_f32_e32 v8, v1, v2", dpp], 0),
+        (["v_readlane_b32 s4, v11, 3", dpp], 0),
+    ]
+    for i, (body, want) in enumerate(cases):
+        f = tmp_path / ("case%d.s" % i)
+        f.write_text("k:\n\t" + "\n\t".join(body) + "\n\ts_endpgm\n")
+        r = subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
+        assert r.returncode == want, (body, r.stdout)

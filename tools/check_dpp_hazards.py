@@ -7,6 +7,30 @@ import re
 import sys
 
 
+def regs(op):
+    """v7 -> {v7}; v[10:13] -> {v10..v13}; anything else -> {}"""
+    m = re.fullmatch(r"v(\d+)", op)
+    if m:
+        return {op}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", op)
+    if m:
+        return {"v%d" % i for i in range(int(m.group(1)), int(m.group(2)) + 1)}
+    return set()
+
+
+def written(instr):
+    """vector registers a VALU instruction writes: its first operand (a register or a range); v_permlane*_swap and
+    v_swap write both of theirs"""
+    parts = instr.split(None, 1)
+    if len(parts) < 2:
+        return set()
+    ops = [o.strip() for o in parts[1].split(",")]
+    out = regs(ops[0])
+    if "swap" in parts[0] and len(ops) > 1:
+        out |= regs(ops[1].split()[0])
+    return out
+
+
 def main():
     lines = open(sys.argv[1]).read().splitlines()
     instr = []                                     # (text, wait states it provides)
@@ -38,8 +62,7 @@ def main():
                 if pm:
                     slots += int(pm.group(1)) + 1
                     continue
-                wm = re.match(r"v_\S+\s+(v\d+)(?:,|$)", prev)
-                if wm and wm.group(1) == src and "readlane" not in prev:
+                if prev.startswith("v_") and "readlane" not in prev and src in written(prev):
                     bad += 1
                     print("HAZARD:", prev, "->", t)
                 slots += 1
