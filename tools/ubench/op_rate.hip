@@ -31,6 +31,19 @@ __global__ void k(float* out, int iters, float kk) {
     if (MODE == 13) OP8(asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a[i])))
     if (MODE == 14) OP8(asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i])))
     if (MODE == 15) OP8(asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i])))
+    if (MODE == 19) OP8(asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(a[i]) : "v"(b[i]), "v"(kk)))
+    if (MODE == 20) OP8(asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(a[i]) : "v"(b[i]), "v"(kk)))
+    if (MODE == 21) OP8(asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(a[i]) : "v"(b[i]), "v"(kk), "v"(b[(i + 1) & 7])))
+    // one entry pair of the split-precision conversion, as the kernels do it (8 instructions incl. the two RHS FMAs) ...
+    if (MODE == 22) OP8(asm volatile("v_mul_f32 %0, %2, %4\n\tv_mul_f32 %1, %3, %4\n\tv_cvt_pkrtz_f16_f32 %2, %0, %1\n\t"
+                                     "v_fma_mix_f32 %0, %2, -1.0, %0 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, -1.0, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                                     "v_cvt_pkrtz_f16_f32 %3, %0, %1\n\tv_fmac_f32 %0, %4, %2\n\tv_fmac_f32 %1, %4, %3"
+                                     : "+v"(a[i]), "+v"(b[i]), "+v"(a[(i + 1) & 7]), "+v"(b[(i + 1) & 7]) : "v"(kk)))
+    // ... and on v_fma_mixlo/mixhi_f16 (hi = RNE(y s), lo = RNE(y s - hi) from the exact product; 6 instructions)
+    if (MODE == 23) OP8(asm volatile("v_fma_mixlo_f16 %0, %2, %4, 0\n\tv_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+                                     "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                                     "v_fmac_f32 %2, %4, %3\n\tv_fmac_f32 %3, %4, %2"
+                                     : "+v"(a[i]), "+v"(b[i]), "+v"(a[(i + 1) & 7]), "+v"(b[(i + 1) & 7]) : "v"(kk)))
   }
   float s = 0;
 #pragma unroll
@@ -55,5 +68,7 @@ int main() {
   run<10>("v_max_f32", d, it); run<8>("v_min3_f32", d, it); run<3>("v_cndmask_b32", d, it); run<7>("v_mov_b32", d, it);
   run<6>("v_xor_b32", d, it); run<15>("v_and_b32", d, it); run<4>("v_cvt_pkrtz_f16_f32", d, it); run<13>("v_cvt_f32_f16", d, it);
   run<5>("v_fma_mix_f32", d, it); run<12>("v_pk_mul_f32", d, it); run<16>("v_cndmask_b32_e64 sgpr", d, it); run<17>("v_cmp + 8 v_cndmask vcc", d, it); run<18>("v_readlane + s_nop 3", d, it); run<9>("v_rcp_f32", d, it); run<14>("v_sqrt_f32", d, it);
+  run<19>("v_fma_mixlo_f16", d, it); run<20>("v_fma_mixhi_f16", d, it); run<21>("v_fma_mixlo_f16 f16 src2", d, it);
+  run<22>("pair: mul/cvt/mix/cvt (8)", d, it); run<23>("pair: mixlo/mixhi (6)", d, it);
   return 0;
 }
