@@ -355,6 +355,9 @@ __device__ __forceinline__ DualEntries<TN> dual_load_entries(const DualParams& p
     const int n = 16 * b + c;
     const int nn = n < w.len ? n : w.len - 1;
     e.col[b] = __builtin_nontemporal_load(p.col + w.begin + nn);
+#ifdef MALS_DUAL_CACHED_COLS   // ablation (exp builds, wrong results): every dual gather hits the cache
+    e.col[b] &= 0xfff;
+#endif
     e.r[b] = __builtin_nontemporal_load(p.val + w.begin + nn);
   }
   return e;
