@@ -236,6 +236,38 @@ def test_operand_range_check_switches_to_the_fp32_gather():
     assert np.array_equal(C, B)
 
 
+@pytest.mark.parametrize("lds_gather", ["1", "0"])
+def test_forced_range_flag_at_k128_is_the_fp32_gather_bit_for_bit(lds_gather):
+    """The same switch at k = 128, where the split-precision kernels are the LDS-staged ones (csrc/lds_kernels.h, feature order
+    permuted, their own Gramian image and finish kernels): with the device-side flag down every one of them returns at once
+    and the fp32 kernels queued behind them produce the GRAMIAN_FP32 result bit for bit -- fused rows, segmented rows
+    (three rows long enough for the segments + finish path at this segment size) and both settings of MALS_LDS_GATHER."""
+    k = 128
+    rng = np.random.default_rng(6)
+    lengths = np.concatenate([rng.integers(65, 400, size=300), [3000, 5000, 9000]])
+    csr, M = rows_problem(lengths, 20000, k, seed=27)
+    kw = dict(solve_mode=_lib.SOLVE_DIRECT, segment_nnz=1024)
+    old = os.environ.get("MALS_LDS_GATHER")
+    os.environ["MALS_LDS_GATHER"] = lds_gather
+    try:
+        B, _ = solve_x(k, csr, M, gramian_mode=_lib.GRAMIAN_FP32, **kw)
+        A, _ = solve_x(k, csr, M, **kw)
+        assert not np.array_equal(A, B) and rel(A, B) < 1e-5, rel(A, B)     # ordinary data: the split kernels ran
+        Xo = oracle.half_iteration(*csr, M, threads=4)
+        assert rel(A, Xo) < 1e-5 and rel(B, Xo) < 1e-5, (rel(A, Xo), rel(B, Xo))
+        os.environ["MALS_FORCE_RANGE_FLAG"] = "0"
+        try:
+            C, _ = solve_x(k, csr, M, **kw)
+        finally:
+            del os.environ["MALS_FORCE_RANGE_FLAG"]
+        assert np.array_equal(C, B)
+    finally:
+        if old is None:
+            del os.environ["MALS_LDS_GATHER"]
+        else:
+            os.environ["MALS_LDS_GATHER"] = old
+
+
 def test_negative_alpha_runs_the_fp32_gather():
     """alpha < 0 (accepted by the reference, ALS:506-509) has no real sqrt(alpha |r|)."""
     k = 64
