@@ -1939,10 +1939,10 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
   for (int t = 0; t < tri(T); ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   int pw = 100;  // current scale 2^pw: max |z| <= 2^14
   int slab_max = 0;  // bit pattern of the largest |element| of the slab (-> ymax: operand bound of the split-precision gather)
-  for (int64_t r = r0; r < r1; r += 16) {
-    // all 4T loads of the step first, no arithmetic on them in between (a use right behind each load makes the
-    // compiler wait for every one in turn: 13 us per step instead of one memory latency)
-    float raw[T][4];
+  // Loads ahead of their use (until round 4 a step waited for its own loads: 8 waves x 4 KB per CU in flight, 4.6 TB/s): a step's
+  // raw registers are reloaded as soon as it has converted them, under its matrix instructions.  Steps past the end of the
+  // slab read clamped rows and contribute zeros.
+  auto load_step = [&](int64_t r, float (&raw)[T][4]) {
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const int64_t row = r + 4 * g + s4;
@@ -1953,7 +1953,8 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
         raw[v][s4] = p[f < k ? f : k - 1];
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto do_step = [&](int64_t r, float (&raw)[T][4], int64_t reload) {
     float amax = 0.f;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -1997,6 +1998,11 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
       zl[v].r[0] = __builtin_bit_cast(int, __builtin_convertvector(r01, f16x2));  // v_cvt_pk_f16_f32: round to nearest
       zl[v].r[1] = __builtin_bit_cast(int, __builtin_convertvector(r23, f16x2));
     }
+    // the raw registers are free: the step after the next (T <= 6: two buffers) or the next one (T = 7, 8: one buffer, the
+    // accumulators leave no room for a second) is requested now and lands during the 3 tri(T) matrix instructions below
+    __builtin_amdgcn_sched_barrier(0);
+    load_step(reload, raw);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
@@ -2009,6 +2015,19 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
     for (int i = 0; i < T; ++i)
 #pragma unroll
       for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<4>(zl[i], zh[j], acc[tidx(T, i, j)]);
+  };
+  if constexpr (T <= 6) {
+    float ra[T][4], rb[T][4];
+    load_step(r0, ra);
+    load_step(r0 + 16, rb);
+    for (int64_t r = r0; r < r1; r += 32) {
+      do_step(r, ra, r + 32);
+      do_step(r + 16, rb, r + 48);
+    }
+  } else {
+    float ra[T][4];
+    load_step(r0, ra);
+    for (int64_t r = r0; r < r1; r += 16) do_step(r, ra, r + 16);
   }
   int d2 = pw == 100 ? 0 : -2 * pw;
   d2 = d2 < -126 ? -126 : (d2 > 126 ? 126 : d2);
