@@ -276,16 +276,27 @@ typedef int i32x2h __attribute__((ext_vector_type(2)));
 struct TileH {
   i32x2h h, l;  // contraction index 4g + r: reg 0 = (r0 | r1 << 16), reg 1 = (r2 | r3 << 16)
 };
-__device__ __forceinline__ int pk_rtz16(float a, float b) { return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+// two floats -> packed f16, round to nearest even (gfx950's v_cvt_pk_f16_f32; same issue cost as v_cvt_pkrtz_f16_f32,
+// tools/ubench/op_rate.hip).  BOTH halves of every split are rounded.  Until round 4 they were truncated (v_cvt_pkrtz): a truncated
+// residual makes hi + lo fall short of the value by up to 2^-22 of it, always towards zero -- a bias every product of a
+// half-iteration shares, which ten chained iterations showed as a linear drift away from the oracle's chain (+1.6e-7 per
+// iteration, tests/test_gpu_multi_iteration.py).  Rounded low half: no sign, no drift; rounded high half as well: the residual is at
+// most half an f16 ulp, one more bit for the low half -- one half-iteration 4.2e-7 -> 2.7e-7 from the oracle, ten 2.3e-6 -> 1.1e-6.
+__device__ __forceinline__ int pk_rn16(float a, float b) {
+  typedef float f32x2r __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
+  const f32x2r v = {a, b};
+  return __builtin_bit_cast(int, __builtin_convertvector(v, f16x2r));
+}
 __device__ __forceinline__ TileH split_tile(const f32x4& t) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  // top 11 significand bits (round toward zero straight into f16), then what is left (v_fma_mix_f32 /
+  // the value rounded to f16 (pk_rn16), then what is left (v_fma_mix_f32 /
   // v_cvt_f32_f16 + v_sub).  Kept in scalars: with the halves read back out of the int2 vector hipcc
   // (ROCm 7.2) subtracts the first pair from both (seen in the ISA, caught by the parity tests).
-  const int h01 = pk_rtz16(t[0], t[1]), h23 = pk_rtz16(t[2], t[3]);
+  const int h01 = pk_rn16(t[0], t[1]), h23 = pk_rn16(t[2], t[3]);
   const h2 a = __builtin_bit_cast(h2, h01), b = __builtin_bit_cast(h2, h23);
-  const int l01 = pk_rtz16(t[0] - (float)a[0], t[1] - (float)a[1]);
-  const int l23 = pk_rtz16(t[2] - (float)b[0], t[3] - (float)b[1]);
+  const int l01 = pk_rn16(t[0] - (float)a[0], t[1] - (float)a[1]);
+  const int l23 = pk_rn16(t[2] - (float)b[0], t[3] - (float)b[1]);
   TileH o;
   o.h[0] = h01;
   o.h[1] = h23;
@@ -639,7 +650,7 @@ __device__ __forceinline__ void gather_row(const SolveParams& p, int64_t begin, 
 // bound, not HBM bound.  The f16 matrix pipe does a 16x16x32 product in 17 cycles, 16x the
 // contraction depth per cycle.  Here the per-row Gramian  sum_n w_n y_n y_n^T  is therefore computed
 // as  sum_n z_n z_n^T  with z_n = sqrt(w_n) S y_n  split into two f16 numbers z = zh + zl
-// (zh = the top 11 significand bits of z, zl = the next 11, round-toward-zero) and three f16 MFMAs
+// (zh = z rounded to f16, zl = the exact residual z - zh rounded to f16: pk_rn16) and three f16 MFMAs
 // per tile:  zh zh^T + zh zl^T + zl zh^T  (fp32 accumulate; the dropped zl zl^T term is < 2^-22
 // relative).  Every f16 x f16 product is exact in fp32, so the only error is the 22-bit
 // representation of z: ~4x the rounding error of the fp32 path, still two orders of magnitude
@@ -677,9 +688,6 @@ __device__ __forceinline__ f32x4 mfma_h(const ZOp<E>& a, const ZOp<E>& b, f32x4 
   } else {
     return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
   }
-}
-__device__ __forceinline__ int pk_rtz(float a, float b) {  // v_cvt_pkrtz_f16_f32
-  return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 #ifndef MALS_SPLIT8_MAXT
 #define MALS_SPLIT8_MAXT 7
@@ -754,13 +762,13 @@ __device__ __forceinline__ void convert_pair_h(const SolveParams& p, const Chunk
   for (int v = 0; v < T; ++v) {
     const float y0 = raw[v][2 * E2], y1 = raw[v][2 * E2 + 1];
     const float z0 = y0 * s0, z1 = y1 * s1;
-    // zh = the top 11 significand bits (round toward zero straight into f16), zl = what is left: written
+    // zh = z rounded to f16 (pk_rn16), zl = what is left: written
     // as an FMA on the widened half so that hipcc emits one v_fma_mix_f32 per value (and folds the
     // scaling in: zl is the residual of the exact product)
-    const int hp = pk_rtz(z0, z1);
+    const int hp = pk_rn16(z0, z1);
     const f16x2 hh = __builtin_bit_cast(f16x2, hp);
     zh[v].r[E2] = hp;
-    zl[v].r[E2] = pk_rtz(fmaf((float)hh[0], -1.f, z0), fmaf((float)hh[1], -1.f, z1));
+    zl[v].r[E2] = pk_rn16(fmaf((float)hh[0], -1.f, z0), fmaf((float)hh[1], -1.f, z1));
     bpart[v] = fmaf(c0, y0, bpart[v]);
     bpart[v] = fmaf(c1, y1, bpart[v]);
   }
@@ -1913,8 +1921,8 @@ __global__ __launch_bounds__(256) void gramian_ref_kernel(const float* __restric
 }
 
 // K1 for LARGE matrices on the f16 matrix pipe.  The fp64 instruction above costs 64 cycles per 16x16x4 block and
-// is 8 % of a k = 128 iteration; v_mfma_f32_16x16x16_f16 on operands split into two f16 halves (hi = round toward
-// zero, lo = round to nearest of the exact residual: 22 significand bits, unbiased, every product exact) does a
+// is 8 % of a k = 128 iteration; v_mfma_f32_16x16x16_f16 on operands split into two f16 halves (hi = the value rounded
+// to f16, lo = the exact residual rounded to f16: 22 significand bits, unbiased, every product exact) does a
 // 16x16x16 block in 3 x 16 cycles.  What fp64 bought -- no rounding in the sum -- is kept where it matters: a wave
 // accumulates in fp32 only over its slab of rows_per_slab rows (512: 32 steps), the slab partials are summed in fp64
 // in a fixed order by gramian_finalize_kernel.  Per slab the fp32 sum carries <= 6e-8 x sqrt(32) relative (random);
@@ -1990,7 +1998,7 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
     for (int v = 0; v < T; ++v) {
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       const float z0 = raw[v][0] * sc, z1 = raw[v][1] * sc, z2 = raw[v][2] * sc, z3 = raw[v][3] * sc;
-      const int h01 = pk_rtz(z0, z1), h23 = pk_rtz(z2, z3);
+      const int h01 = pk_rn16(z0, z1), h23 = pk_rn16(z2, z3);
       const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
       const f32x2 r01 = {z0 - (float)a[0], z1 - (float)a[1]}, r23 = {z2 - (float)b[0], z3 - (float)b[1]};
       zh[v].r[0] = h01;

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void rotate_rows_kernel(RotateParams p) {
 //   A (rows): lane (g,c) reads features 32 q + 8 g .. + 7 of row c of a 16-row tile (two 16-byte loads), times a
 //             power of two sA with max |value| sA <= 2^14 -- forward: max |y| <= sqrt(max_f G_ff) from the host;
 //             un-rotation: the largest |x'| the dual kernels stored (a device scalar they maintain) -- then
-//             hi = round toward zero, lo = round to nearest of the exact residual;
+//             hi = the value rounded to f16, lo = the exact residual rounded to f16 (pk_rn16);
 //   B (Q):    split once on the host into the operand layout  Bs[q][t][hi|lo][lane] (16 bytes each), scale 2^13.
 // One wave per NT 16-row tiles that share every B operand.
 struct RotateSplitParams {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void rotate_rows_split_kernel(RotateSplitPa
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const f32x4 z = raw[h][u] * sa;
-          const int h01 = pk_rtz(z[0], z[1]), h23 = pk_rtz(z[2], z[3]);
+          const int h01 = pk_rn16(z[0], z[1]), h23 = pk_rn16(z[2], z[3]);
           const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
           typedef float f32x2 __attribute__((ext_vector_type(2)));
           const f32x2 r01 = {z[0] - (float)a[0], z[1] - (float)a[1]}, r23 = {z[2] - (float)b[0], z[3] - (float)b[1]};
@@ -460,11 +460,11 @@ __global__ __launch_bounds__(256, dual_waves(T, TN)) void als_dual_kernel(DualPa
           // whole-vector products (v_pk_mul_f32: two values per issue slot); the residuals z - (float)zh as
           // v_fma_mix_f32 on the packed halves, written out: hipcc only finds that form on scalar products
           const f32x4 z4 = raw[b][j] * d4 * ws[b];
-          const int h01 = pk_rtz(z4[0], z4[1]), h23 = pk_rtz(z4[2], z4[3]);
+          const int h01 = pk_rn16(z4[0], z4[1]), h23 = pk_rn16(z4[2], z4[3]);
           zh[b][j >> 1].r[2 * (j & 1)] = h01;
           zh[b][j >> 1].r[2 * (j & 1) + 1] = h23;
-          zl[b][j >> 1].r[2 * (j & 1)] = pk_rtz(residual_lo(h01, z4[0]), residual_hi(h01, z4[1]));
-          zl[b][j >> 1].r[2 * (j & 1) + 1] = pk_rtz(residual_lo(h23, z4[2]), residual_hi(h23, z4[3]));
+          zl[b][j >> 1].r[2 * (j & 1)] = pk_rn16(residual_lo(h01, z4[0]), residual_hi(h01, z4[1]));
+          zl[b][j >> 1].r[2 * (j & 1) + 1] = pk_rn16(residual_lo(h23, z4[2]), residual_hi(h23, z4[3]));
         } else {  // odd T: the upper half of the last 32-feature chunk is padding
           zh[b][j >> 1].r[2 * (j & 1)] = 0;
           zh[b][j >> 1].r[2 * (j & 1) + 1] = 0;

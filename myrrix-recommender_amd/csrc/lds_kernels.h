@@ -148,10 +148,10 @@ __device__ __forceinline__ void ldsk_convert_half(const f32x4& ya, const f32x4& 
     const int v = V0 + q;
     const float y0 = ya[q], y1 = yb[q];
     const float z0 = y0 * s0, z1 = y1 * s1;
-    const int hp = pk_rtz(z0, z1);
+    const int hp = pk_rn16(z0, z1);
     const f16x2 hh = __builtin_bit_cast(f16x2, hp);
     zh[v].r[E2] = hp;
-    zl[v].r[E2] = pk_rtz(fmaf((float)hh[0], -1.f, z0), fmaf((float)hh[1], -1.f, z1));
+    zl[v].r[E2] = pk_rn16(fmaf((float)hh[0], -1.f, z0), fmaf((float)hh[1], -1.f, z1));
     bpart[v] = fmaf(c0, y0, bpart[v]);
     bpart[v] = fmaf(c1, y1, bpart[v]);
   }

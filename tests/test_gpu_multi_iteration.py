@@ -80,3 +80,53 @@ def test_three_chained_iterations_match_the_oracle(k, n_users, n_items, nnz):
         lens = np.diff(c_csr[0])
         assert int(lens.max()) > 4096, "the popular items go through the long-row (segments) path"
     print("chained iterations k=%d: %s" % (k, "; ".join("it %d X %.2e Y %.2e worst rows %.2e / %.2e" % t for t in seen)))
+
+
+@pytest.mark.parametrize("k,n_users,n_items,nnz", [(64, 40_000, 6_000, 1_000_000), (128, 25_000, 6_000, 800_000)])
+def test_ten_chained_iterations_do_not_drift(k, n_users, n_items, nnz):
+    """The same chain ten times over at a smaller shape.  Every fp32 implementation of a half-iteration injects about one
+    rounding error per factor element, and ALS -- far from its fixed point, where the benchmark's iterations run -- neither
+    damps nor amplifies such a perturbation much (measured: a single 3e-7 perturbation of Y0 stays at 3.3e-7 .. 3.9e-7 for ten
+    iterations), so two correct implementations drift apart like a random walk, ~sqrt(half-iterations) x one step.  The yardstick
+    is therefore a CONTROL: the oracle's own chain with every factor element perturbed by 3e-7 relative (Gaussian) after every
+    half-iteration, i.e. "another fp32 implementation".  After each of the ten iterations the device's distance to the oracle's
+    chain must be within 2.5x the control's (+3e-7), and below 1e-5 outright; a systematic (linear) accumulation of the 22-bit
+    products' errors would leave the control behind by iteration 10."""
+    import torch
+    dev = torch.device("cuda", 0)
+    threads = min(256, os.cpu_count() or 8)
+    prob = synth.torch_problem(n_users, n_items, nnz, k, dev)
+    r_csr = tuple(t.cpu().numpy() for t in prob["r_csr"])
+    c_csr = tuple(t.cpu().numpy() for t in prob["c_csr"])
+    Y0 = prob["Y0"].cpu().numpy()
+    kw = dict(alpha=1.0, lam=0.1, flags=0, threads=threads)
+    rng = np.random.default_rng(99)
+
+    def jitter(F):
+        return (F * (1.0 + np.float32(3e-7) * rng.standard_normal(F.shape).astype(np.float32))).astype(np.float32)
+    Yc = Y0
+    seen, ctrl = [], []
+    with pkg.ALSCore(k, device=0) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_matrix(pkg.SIDE_X, *prob["r_csr"])
+        core.set_matrix(pkg.SIDE_Y, *prob["c_csr"])
+        core.set_factors(pkg.SIDE_Y, Y0)
+        Yo = Y0
+        for it in range(10):
+            core.half_iteration(pkg.SIDE_X)
+            core.half_iteration(pkg.SIDE_Y)
+            core.check()
+            Xo = oracle.half_iteration(*r_csr, Yo, **kw)
+            Yo = oracle.half_iteration(*c_csr, Xo, **kw)
+            Xc = jitter(oracle.half_iteration(*r_csr, Yc, **kw))
+            Yc = jitter(oracle.half_iteration(*c_csr, Xc, **kw))
+            X, Y = core.get_factors(pkg.SIDE_X), core.get_factors(pkg.SIDE_Y)
+            seen.append((rel(X, Xo), rel(Y, Yo), worst_row(X, Xo), worst_row(Y, Yo)))
+            ctrl.append((rel(Xc, Xo), rel(Yc, Yo)))
+    print("ten chained iterations k=%d: device X %s | control X %s | device Y %s | control Y %s" % (
+        k, " ".join("%.1e" % s[0] for s in seen), " ".join("%.1e" % c[0] for c in ctrl),
+        " ".join("%.1e" % s[1] for s in seen), " ".join("%.1e" % c[1] for c in ctrl)))
+    for it in range(10):
+        assert seen[it][0] < 1e-5 and seen[it][1] < 1e-5 and seen[it][2] < ROW_TOL and seen[it][3] < ROW_TOL, (k, it + 1, seen)
+        assert seen[it][0] < 2.5 * ctrl[it][0] + 3e-7 and seen[it][1] < 2.5 * ctrl[it][1] + 3e-7, (k, it + 1, seen, ctrl)

@@ -46,6 +46,7 @@ __global__ void k(float* out, int iters, float kk) {
     if (MODE == 36) OP8(asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i])))
     if (MODE == 37) OP8(asm volatile("v_lshlrev_b32 %0, 2, %0" : "+v"(a[i])))
     if (MODE == 38) OP8(asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*reinterpret_cast<double*>(&a[i & 6])) : "v"(*reinterpret_cast<double*>(&b[i & 6]))))
+    if (MODE == 39) OP8(asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i])))
     if (MODE == 19) OP8(asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(a[i]) : "v"(b[i]), "v"(kk)))
     if (MODE == 20) OP8(asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(a[i]) : "v"(b[i]), "v"(kk)))
     if (MODE == 21) OP8(asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(a[i]) : "v"(b[i]), "v"(kk), "v"(b[(i + 1) & 7])))
@@ -87,6 +88,7 @@ int main() {
   run<28>("v_cmp_gt_f32_e32 (vcc)", d, it); run<29>("v_cmp_gt_f32_e64 (sgpr)", d, it); run<30>("v_add_co_u32_e32", d, it); run<31>("v_addc_co_u32_e32", d, it);
   run<32>("v_lshl_add_u64", d, it); run<33>("v_mad_u64_u32", d, it); run<34>("v_mov_b32_dpp", d, it); run<35>("v_fmac_f32_dpp", d, it);
   run<36>("v_add_u32", d, it); run<37>("v_lshlrev_b32", d, it); run<38>("v_pk_fma_f32", d, it);
+  run<39>("v_cvt_pk_f16_f32 (RNE)", d, it);
   run<19>("v_fma_mixlo_f16", d, it); run<20>("v_fma_mixhi_f16", d, it); run<21>("v_fma_mixlo_f16 f16 src2", d, it);
   run<22>("pair: mul/cvt/mix/cvt (8)", d, it); run<23>("pair: mixlo/mixhi (6)", d, it);
   return 0;
