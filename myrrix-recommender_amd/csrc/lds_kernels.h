@@ -25,7 +25,7 @@
 //
 // LDS ring and the entry <-> slot map.  A super-step is 32 entries n = 4 e + g (lane group g converts entries 4e+g,
 // e = 0..7, as in gather_row_h: its weights sit in its own 16 lanes of the row-major chunk).  They are converted pair by
-// pair (E2 = e >> 1: the two entries a v_cvt_pkrtz packs), and as soon as pair E2 -- 8 entries -- has been read, its 4 KB are
+// pair (E2 = e >> 1: the two entries one v_cvt_pk_f16_f32 packs), and as soon as pair E2 -- 8 entries -- has been read, its 4 KB are
 // refilled with the same pair of the NEXT super-step: four global_load_lds_dwordx4, instruction i covering entry
 // (g = i, e' = 0) with lanes 0-31 and (g = i, e' = 1) with lanes 32-63 (the destination is lane-linear: M0 + 16 lane).  So
 //     slot(n) = 8 E2 + 2 g + e'      (512 bytes each),

@@ -1,19 +1,17 @@
 """numpy restatement of the dual ("short row") solve path of csrc/dual_kernels.h, arithmetic step by step:
 fp64 eigendecomposition of G, fp32 rotated rows, the d_f(n) table, the power-of-two operand scale, operands split
-into two f16 halves (hi toward zero, lo toward zero as v_cvt_pkrtz does in the kernel), S = I + Z Z^T from the three
+into two f16 halves (both rounded to nearest, as v_cvt_pk_f16_f32 does in the kernel), S = I + Z Z^T from the three
 exact products in fp32, fp32 Cholesky + solves, x' = D^1/2 Z^T v, x = Q x'.  Test infrastructure (CPU): checked
 against the oracle in tests/test_dual_emulation.py so that the ALGORITHM is validated without a GPU."""
 import numpy as np
 
 
 def split22(z):
-    """z (fp32) -> (hi, lo): hi = the top 11 significand bits of z (round toward zero), lo = the top 11 bits of z - hi."""
+    """z (fp32) -> (hi, lo): hi = z rounded to f16, lo = the exact residual z - hi rounded to f16 (pk_rn16 in the kernels;
+    the operand scale keeps both inside f16's normal range)."""
     z = z.astype(np.float32)
-    m, e = np.frexp(z)
-    hi = np.ldexp(np.trunc(m * 2048.0) / 2048.0, e).astype(np.float32)
-    r = (z - hi).astype(np.float32)
-    m, e = np.frexp(r)
-    lo = np.ldexp(np.trunc(m * 2048.0) / 2048.0, e).astype(np.float32)
+    hi = z.astype(np.float16).astype(np.float32)
+    lo = (z - hi).astype(np.float32).astype(np.float16).astype(np.float32)
     return hi, lo
 
 

@@ -67,7 +67,7 @@ def test_split_f16_operands_never_overflow_and_keep_22_bits():
     z = (y * np.float32(np.sqrt(w_max)) * S).astype(np.float32)
     assert np.max(np.abs(z)) <= 2.0 ** 14 and float(S) * float(S) * float(inv_s2) == 1.0
     h = (z.view(np.uint32) & np.uint32(0xffffe000)).view(np.float32)
-    zh, zl = we.f16_rtz(h), we.f16_rtz(z - h)
+    zh, zl = we.f16_rn(h), we.f16_rn(z - h)
     assert np.all(zh == h)                                # the masked top bits are exact in f16
     big = np.abs(z) > 2.0 ** -3                           # full precision down to 2^-17 of the largest
     assert np.all(np.abs(z - (zh + zl))[big] <= np.abs(z[big]) * 2.0 ** -21)

@@ -92,13 +92,10 @@ def wave_gram_rhs(Yg, w, cb, k):
     return acc, bcol
 
 
-def f16_rtz(x):
-    """v_cvt_pkrtz_f16_f32 on each element: round toward zero to f16 (returned as fp32 values)."""
-    x = np.asarray(x, np.float32)
-    h = x.astype(np.float16)
-    over = np.abs(h.astype(np.float32)) > np.abs(x)
-    h = np.where(over, np.nextafter(h, np.float16(0)), h)
-    return h.astype(np.float32)
+def f16_rn(x):
+    """v_cvt_pk_f16_f32 on each element: round to nearest even to f16 (returned as fp32 values).  (Until round 4 the kernels
+    truncated -- v_cvt_pkrtz_f16_f32 --, which biased every operand towards zero: csrc/als_kernels.h, pk_rn16.)"""
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
 
 
 def gather_scale(Gd, k, w_max):
@@ -130,7 +127,7 @@ def mfma_16x16x32_f16(a, b, acc):
 
 def wave_gram_rhs_split(Yg, w, cb, k, zscale, inv_s2):
     """Split-precision gather (gather_row_h): super-steps of 32 entries, lane (g,c) slot e = entry
-    4e+g; z = sqrt(w)*S*y split as zh (round toward zero to f16 = top 11 significand bits) + zl (the rest, toward zero);
+    4e+g; z = sqrt(w)*S*y split as zh (rounded to f16) + zl (the rest, rounded to f16);
     acc += zh zh^T + zh zl^T + zl zh^T on the f16 matrix pipe; RHS from the raw rows in fp32.
     Returns the UNSCALED tiles (acc / S^2) and bcol."""
     T = (k + 15) // 16
@@ -151,9 +148,9 @@ def wave_gram_rhs_split(Yg, w, cb, k, zscale, inv_s2):
                 f = 16 * v + C_
                 y = np.where(f < k, Yg[nn, np.minimum(f, k - 1)], 0.0).astype(np.float32)
                 z = (y * swn).astype(np.float32)
-                zh[v][e] = f16_rtz(z)                             # v_cvt_pkrtz_f16_f32
+                zh[v][e] = f16_rn(z)                              # v_cvt_pk_f16_f32
                 # v_fma_mix_f32: the residual of the EXACT product y * sqrt(w) S, rounded once
-                zl[v][e] = f16_rtz((y.astype(np.float64) * swn.astype(np.float64) - zh[v][e]).astype(np.float32))
+                zl[v][e] = f16_rn((y.astype(np.float64) * swn.astype(np.float64) - zh[v][e]).astype(np.float32))
                 bpart[v] = (bpart[v] + cbn * y).astype(np.float32)
         for a_, b_ in ((zh, zh), (zh, zl), (zl, zh)):
             for i in range(T):
@@ -239,8 +236,8 @@ def mfma_16x16x16_f16(a, b, acc):
 def split_tile(t):
     """split_tile: every register of an acc-layout tile -> (top 11 significand bits, next 11 toward zero)."""
     t = np.asarray(t, np.float32)
-    h = f16_rtz(t)
-    return h, f16_rtz((t - h).astype(np.float32))
+    h = f16_rn(t)
+    return h, f16_rn((t - h).astype(np.float32))
 
 
 def row_scale(acc, bcol, T):
