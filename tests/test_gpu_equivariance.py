@@ -67,3 +67,27 @@ def test_row_order_is_invisible(k, n_users, n_items, nnz, chunk_rows):
     lens = (prob["c_csr"][0][1:] - prob["c_csr"][0][:-1])
     assert int(lens.max()) > 4096, "some item rows take the long-row path"
     assert np.array_equal(Yp, Y[permi.cpu().numpy()]), int(np.argmax(np.any(Yp != Y[permi.cpu().numpy()], axis=1)))
+
+
+@pytest.mark.parametrize("k,n_users,n_items,nnz", [(64, 10_000_000, 1_000_000, 1_000_000_000), (128, 2_000_000, 200_000, 200_000_000)])
+def test_a_full_iteration_run_twice_is_bit_identical(k, n_users, n_items, nnz):
+    """Idempotence at full size: fixed work assignment, fixed summation orders (the Gramian's slab partials are summed in slab
+    order), no float atomics -- two handles fed the same problem produce the same bits after a whole iteration, Gramians included."""
+    import torch
+    dev = torch.device("cuda", 0)
+    prob = synth.torch_problem(n_users, n_items, nnz, k, dev)
+    out = []
+    for _ in range(2):
+        with pkg.ALSCore(k, device=0) as core:
+            core.set_factor_rows(pkg.SIDE_X, n_users)
+            core.set_factor_rows(pkg.SIDE_Y, n_items)
+            core.set_matrix(pkg.SIDE_X, *prob["r_csr"])
+            core.set_matrix(pkg.SIDE_Y, *prob["c_csr"])
+            core.set_factors(pkg.SIDE_Y, prob["Y0"].cpu().numpy())
+            core.half_iteration(pkg.SIDE_X)
+            core.half_iteration(pkg.SIDE_Y)
+            core.check()
+            G = core.gramian(pkg.SIDE_Y, fetch=True)
+            out.append((core.get_factors(pkg.SIDE_X), core.get_factors(pkg.SIDE_Y), G))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.all(np.isfinite(out[0][1])) and float(np.abs(out[0][1]).max()) > 0.0 and out[0][2].shape == (k, k) and out[0][2][0, 0] > 0.0
