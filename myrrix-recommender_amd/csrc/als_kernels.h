@@ -288,15 +288,24 @@ __device__ __forceinline__ int pk_rn16(float a, float b) {
   const f32x2r v = {a, b};
   return __builtin_bit_cast(int, __builtin_convertvector(v, f16x2r));
 }
+// z - (float)h.lo / z - (float)h.hi for a packed f16 pair h: one v_fma_mix_f32 each (f16 source 0, fp32 constant and addend)
+__device__ __forceinline__ float residual_lo(int h, float z) {
+  float o;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(h), "v"(z));
+  return o;
+}
+__device__ __forceinline__ float residual_hi(int h, float z) {
+  float o;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(h), "v"(z));
+  return o;
+}
+
 __device__ __forceinline__ TileH split_tile(const f32x4& t) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  // the value rounded to f16 (pk_rn16), then what is left (v_fma_mix_f32 /
-  // v_cvt_f32_f16 + v_sub).  Kept in scalars: with the halves read back out of the int2 vector hipcc
-  // (ROCm 7.2) subtracts the first pair from both (seen in the ISA, caught by the parity tests).
+  // the value rounded to f16 (pk_rn16), then what is left: one v_fma_mix_f32 per value on the packed halves (hipcc's own
+  // rendering of t - (float)half was v_cvt_f32_f16 + v_sub_f32: two instructions per value, 224 per k = 128 row)
   const int h01 = pk_rn16(t[0], t[1]), h23 = pk_rn16(t[2], t[3]);
-  const h2 a = __builtin_bit_cast(h2, h01), b = __builtin_bit_cast(h2, h23);
-  const int l01 = pk_rn16(t[0] - (float)a[0], t[1] - (float)a[1]);
-  const int l23 = pk_rn16(t[2] - (float)b[0], t[3] - (float)b[1]);
+  const int l01 = pk_rn16(residual_lo(h01, t[0]), residual_hi(h01, t[1]));
+  const int l23 = pk_rn16(residual_lo(h23, t[2]), residual_hi(h23, t[3]));
   TileH o;
   o.h[0] = h01;
   o.h[1] = h23;
@@ -321,14 +330,103 @@ __device__ __forceinline__ f32x4 tile_ptq_h(const TileH& P, const TileH& Q, f32x
   return C;
 }
 
+// Two block rows at once: C += P0^T Q0 + P1^T Q1 as three v_mfma_f32_16x16x32_f16 -- the contraction runs over the 32 rows of
+// both tiles (each lane supplies its four rows of tile 0 and its four rows of tile 1 to A and to B alike; the order inside the
+// contraction does not matter as long as both operands use the same one).  Same 16 cycles as the 16-row instruction.
+typedef int i32x4h __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));
+struct TileH2 {
+  i32x4h h, l;
+};
+__device__ __forceinline__ TileH2 pair_tiles(const TileH& a, const TileH& b) {
+  TileH2 o;
+  o.h = i32x4h{a.h[0], a.h[1], b.h[0], b.h[1]};
+  o.l = i32x4h{a.l[0], a.l[1], b.l[0], b.l[1]};
+  return o;
+}
+__device__ __forceinline__ f32x4 mfma32h(const i32x4h& a, const i32x4h& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8h, a), __builtin_bit_cast(f16x8h, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 tile_ptq_h2(const TileH2& P, const TileH2& Q, f32x4 C) {
+  C = mfma32h(P.h, Q.h, C);
+  C = mfma32h(P.h, Q.l, C);
+  C = mfma32h(P.l, Q.h, C);
+  return C;
+}
+
 // K3b: blocked right-looking Cholesky W = U^T U on the upper tiles.  On return the off-diagonal
 // tiles hold U_ij and the diagonal tiles hold U_ii^{-1}.  TRSM and SYRK run on the matrix cores.
 // SPLIT: the SYRK products on the f16 matrix pipe (the caller has scaled the system, row_scale).
 #ifndef MALS_SYRK_RESPLIT_MINT
 #define MALS_SYRK_RESPLIT_MINT 8
 #endif
-template <int T, bool SPLIT = false, bool RESPLIT = (T >= MALS_SYRK_RESPLIT_MINT)>
+// MALS_SYRK_PAIRS_MINT: from this T on (even T only) the rank-16 updates of TWO consecutive block rows are applied to the
+// trailing tiles together, as one K = 32 product per tile (tile_ptq_h2): block row kb is factored and applied to block row
+// kb + 1 alone (K = 16), block row kb + 1 is factored, then every tile below gets both rows' updates in three
+// v_mfma_f32_16x16x32_f16 instead of six v_mfma_f32_16x16x16_f16 -- T = 8: 150 matrix instructions instead of 252 for the
+// updates of a row, the same number of split_tile.  PAIRS is set by the LDS-staged k = 128 kernel only: measured there -1.3 % on
+// the user-half rows kernel of c5rank (the matrix pipe is a third busy: an f16 matrix instruction less is worth ~3.5 issue cycles,
+// not its 16 pipe cycles); in the register-staged T = 8 kernels the two operand pairs cost 28 more spilled dwords.
+#ifndef MALS_SYRK_PAIRS_MINT
+#define MALS_SYRK_PAIRS_MINT 8
+#endif
+template <int T>
+__device__ __forceinline__ void cholesky_factor_row(f32x4 (&acc)[tri(T)], int kb, int lane, float& minpiv) {
+  const f32x4 Uinv = factor_diag(acc[tidx(T, kb, kb)], lane, minpiv);
+  acc[tidx(T, kb, kb)] = Uinv;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {  // U_kj = Uinv^T A_kj
+    if (j > kb) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      acc[tidx(T, kb, j)] = tile_ptq(Uinv, acc[tidx(T, kb, j)], zero);
+    }
+  }
+}
+template <int T>
+__device__ __forceinline__ void cholesky_tiles_pairs(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
+  static_assert(T % 2 == 0, "block rows are taken two at a time");
+#pragma unroll
+  for (int kb = 0; kb < T; kb += 2) {
+    cholesky_factor_row<T>(acc, kb, lane, minpiv);
+    {  // block row kb -> block row kb + 1 only
+      const int i = kb + 1;
+      const TileH qi = split_tile(acc[tidx(T, kb, i)]);
+      const TileH np = negate_tile(qi);
+      acc[tidx(T, i, i)] = tile_ptq_h(np, qi, acc[tidx(T, i, i)]);
+#pragma unroll
+      for (int j = 0; j < T; ++j) {
+        if (j > i) {
+          const TileH qj = split_tile(acc[tidx(T, kb, j)]);
+          acc[tidx(T, i, j)] = tile_ptq_h(np, qj, acc[tidx(T, i, j)]);
+        }
+      }
+    }
+    cholesky_factor_row<T>(acc, kb + 1, lane, minpiv);
+#pragma unroll
+    for (int i = 0; i < T; ++i) {   // both block rows -> everything below them
+      if (i >= kb + 2) {
+        const TileH2 qi = pair_tiles(split_tile(acc[tidx(T, kb, i)]), split_tile(acc[tidx(T, kb + 1, i)]));
+        TileH2 np;
+        np.h = qi.h ^ (int)0x80008000;
+        np.l = qi.l ^ (int)0x80008000;
+        acc[tidx(T, i, i)] = tile_ptq_h2(np, qi, acc[tidx(T, i, i)]);
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+          if (j > i) {
+            const TileH2 qj = pair_tiles(split_tile(acc[tidx(T, kb, j)]), split_tile(acc[tidx(T, kb + 1, j)]));
+            acc[tidx(T, i, j)] = tile_ptq_h2(np, qj, acc[tidx(T, i, j)]);
+          }
+        }
+      }
+    }
+  }
+}
+template <int T, bool SPLIT = false, bool RESPLIT = (T >= MALS_SYRK_RESPLIT_MINT), bool PAIRS = false>
 __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
+  if constexpr (PAIRS && SPLIT && RESPLIT && T % 2 == 0 && T >= MALS_SYRK_PAIRS_MINT) {
+    cholesky_tiles_pairs<T>(acc, lane, minpiv);
+    return;
+  }
 #pragma unroll
   for (int kb = 0; kb < T; ++kb) {
 #ifdef MALS_DOUBLE_DIAG   // ablation by duplication (exp builds): what one more factor_diag per tile costs in place
@@ -1996,15 +2094,12 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
     ZOp<4> zh[T], zl[T];
 #pragma unroll
     for (int v = 0; v < T; ++v) {
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
       const float z0 = raw[v][0] * sc, z1 = raw[v][1] * sc, z2 = raw[v][2] * sc, z3 = raw[v][3] * sc;
       const int h01 = pk_rn16(z0, z1), h23 = pk_rn16(z2, z3);
-      const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
-      const f32x2 r01 = {z0 - (float)a[0], z1 - (float)a[1]}, r23 = {z2 - (float)b[0], z3 - (float)b[1]};
       zh[v].r[0] = h01;
       zh[v].r[1] = h23;
-      zl[v].r[0] = __builtin_bit_cast(int, __builtin_convertvector(r01, f16x2));  // v_cvt_pk_f16_f32: round to nearest
-      zl[v].r[1] = __builtin_bit_cast(int, __builtin_convertvector(r23, f16x2));
+      zl[v].r[0] = pk_rn16(residual_lo(h01, z0), residual_hi(h01, z1));
+      zl[v].r[1] = pk_rn16(residual_lo(h23, z2), residual_hi(h23, z3));
     }
     // the raw registers are free: the step after the next (T <= 6: two buffers) or the next one (T = 7, 8: one buffer, the
     // accumulators leave no room for a second) is requested now and lands during the 3 tri(T) matrix instructions below

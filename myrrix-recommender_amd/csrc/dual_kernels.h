@@ -247,13 +247,10 @@ __global__ __launch_bounds__(256, 2) void rotate_rows_split_kernel(RotateSplitPa
         for (int u = 0; u < 2; ++u) {
           const f32x4 z = raw[h][u] * sa;
           const int h01 = pk_rn16(z[0], z[1]), h23 = pk_rn16(z[2], z[3]);
-          const f16x2 a = __builtin_bit_cast(f16x2, h01), b = __builtin_bit_cast(f16x2, h23);
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          const f32x2 r01 = {z[0] - (float)a[0], z[1] - (float)a[1]}, r23 = {z[2] - (float)b[0], z[3] - (float)b[1]};
           ah[h].r[2 * u] = h01;
           ah[h].r[2 * u + 1] = h23;
-          al[h].r[2 * u] = __builtin_bit_cast(int, __builtin_convertvector(r01, f16x2));      // v_cvt_pk_f16_f32: round to nearest
-          al[h].r[2 * u + 1] = __builtin_bit_cast(int, __builtin_convertvector(r23, f16x2));
+          al[h].r[2 * u] = pk_rn16(residual_lo(h01, z[0]), residual_hi(h01, z[1]));
+          al[h].r[2 * u + 1] = pk_rn16(residual_lo(h23, z[2]), residual_hi(h23, z[3]));
         }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -327,18 +324,6 @@ __global__ void zero_rows_kernel(const WorkItem* __restrict__ items, int64_t n, 
       for (int c = lane; c < k; c += 64) o[c] = 0.f;
     }
   }
-}
-
-// z - (float)h.lo / z - (float)h.hi for a packed f16 pair h: one v_fma_mix_f32 each (f16 source 0, fp32 constant and addend)
-__device__ __forceinline__ float residual_lo(int h, float z) {
-  float o;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(h), "v"(z));
-  return o;
-}
-__device__ __forceinline__ float residual_hi(int h, float z) {
-  float o;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(o) : "v"(h), "v"(z));
-  return o;
 }
 
 template <int TN>

@@ -254,6 +254,12 @@ __global__ __launch_bounds__(64, 2) void als_lds_kernel_h(SolveParams p) {
       float bpart[T];
 #pragma unroll
       for (int v = 0; v < T; ++v) bpart[v] = 0.f;
+#ifdef MALS_PROFILING   // per-phase cycle stamps of 64 rows of the first 64 waves (MALS_DEBUG_TRACE=<first traced row>)
+      const int64_t trow = it / n_waves - p.trace_start;
+      const bool tr = MODE == 0 && p.trace && wave < 64 && trow >= 0 && trow < 64;
+      unsigned long long t0 = 0, t1 = 0, t2 = 0;
+      if (tr) t0 = __builtin_readcyclecounter();
+#endif
       // the row's first super-step and the next row's first chunk were requested before the previous row's epilogue
       wait_vm<0>();
       const int n_ss = (cur.len + 31) >> 5;
@@ -277,6 +283,9 @@ __global__ __launch_bounds__(64, 2) void als_lds_kernel_h(SolveParams p) {
         const unsigned src = last ? (nxt.len > 0 ? b_nrow : b_cur) : (odd ? b_next : b_cur + 128);
         ldsk_super_step(lds, ring, w, cb, ldsk_cols_addr(src, lane), L, acc, bpart);
       }
+#ifdef MALS_PROFILING
+      if (tr) t1 = __builtin_readcyclecounter();
+#endif
       float bcol[T];
 #pragma unroll
       for (int v = 0; v < T; ++v) bcol[v] = reduce_groups(bpart[v], lane);
@@ -311,10 +320,22 @@ __global__ __launch_bounds__(64, 2) void als_lds_kernel_h(SolveParams p) {
         float minpiv = 3.0e38f, wmax;
         float xcol[T];
         const float inv_s2row = row_scale<T>(acc, bcol, lane, wmax);
-        cholesky_tiles<T, true, LDSK_RESPLIT>(acc, lane, minpiv);
+        cholesky_tiles<T, true, LDSK_RESPLIT, true>(acc, lane, minpiv);
         minpiv *= inv_s2row;
+#ifdef MALS_PROFILING
+        if (tr) t2 = __builtin_readcyclecounter();
+#endif
         solve_tiles<T>(acc, bcol, xcol, lane);
         store_row<T, true>(p, xcol, minpiv, fmaxf(rmax, p.gramian_weight * wmax), cur.id, lane);
+#ifdef MALS_PROFILING
+        if (tr) {
+          const unsigned long long t3 = __builtin_readcyclecounter();
+          if (lane == 0) {
+            unsigned long long* o = p.trace + (trow * 64 + wave) * 6;
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = (unsigned long long)cur.len; o[5] = wall_clock64();
+          }
+        }
+#endif
       } else {
         float* s = p.scratch + (int64_t)cur.id * ((tri(T) * 4 + T) * 64);
 #pragma unroll
