@@ -186,7 +186,7 @@ __device__ __forceinline__ f32x4 tile_neg_ptq(const f32x4& P, const f32x4& Q, f3
 // row, and e[r] = L^-1[c][4g+r] = Uinv[4g+r][c] is already the acc layout of Uinv: no transposition.
 // (ds_bpermute is the scarce resource: tools/ubench/bperm_rate.hip measures one per 2.5 ns per CU,
 // shared by all waves, and it heads the dependency chain of every step.)
-// minpiv tracks the smallest pivot (a pivot <= singularity threshold flags a non-PD system).
+// minpiv watches the smallest pivot (a pivot <= singularity threshold flags a non-PD system), per lane: see the end of factor_diag.
 // Pivot order: step t eliminates index p = 4*(t&3) + (t>>2), i.e. register t>>2 of lane group t&3 --
 // register by register instead of 0..15.  Any symmetric pivot order factors an SPD tile (U is then a
 // row permutation of a triangle, which neither the TRSM, the SYRK nor the solves care about: they only
@@ -199,7 +199,6 @@ __device__ __forceinline__ void diag_step(f32x4& D, f32x4& E, int lane, int pos,
   constexpr int gm = T_ & 3, rm = T_ >> 2, P = 4 * gm + rm;
   constexpr int gn = (T_ + 1) & 3, rn = ((T_ + 1) >> 2) & 3, PN = 4 * gn + rn;  // the next step's pivot
   const int c = lane & 15;
-  minpiv = fminf(minpiv, piv);
   const float rinv = __builtin_amdgcn_rcpf(piv);
   float nl = -(num * rinv);        // num = D[c][p] (from lane (gm, c)), piv = D[p][p]: fetched a step ahead
   nl = pos > T_ ? nl : 0.f;        // finished rows (and row p itself) stay put: D[p][p] keeps the pivot
@@ -259,7 +258,12 @@ __device__ __forceinline__ f32x4 factor_diag(f32x4 D, int lane, float& minpiv) {
   diag_step<14>(D, E, lane, pos, minpiv, piv, num);
   diag_step<15>(D, E, lane, pos, minpiv, piv, num);
   // row c is scaled by 1/sqrt(its pivot), which lane (c>>2, c) still holds as D[c][c]
-  const float s = __builtin_amdgcn_rsqf(spread_to_col(select4(c & 3, D[0], D[1], D[2], D[3]), lane));
+  // (its pivot also enters the smallest-pivot watch here, per LANE -- lane (g,c) watches pivot c of every tile; cholesky_tiles
+  // takes the minimum over the 16 lanes of a row once per system.  Until round 4 every step folded its pivot into a uniform
+  // minimum: a v_min3 and a register copy of the scalar operands per two steps, 16 vector instructions per tile.)
+  const float pvc = spread_to_col(select4(c & 3, D[0], D[1], D[2], D[3]), lane);
+  minpiv = fminf(minpiv, pvc == pvc ? pvc : 0.f);   // (a pivot <= 0 poisons the rows after it: a NaN on the diagonal is a failed pivot, and v_min would drop it)
+  const float s = __builtin_amdgcn_rsqf(pvc);
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[r] *= s;
   return E;
@@ -382,6 +386,15 @@ __device__ __forceinline__ void cholesky_factor_row(f32x4 (&acc)[tri(T)], int kb
     }
   }
 }
+// smallest pivot of the system out of factor_diag's per-lane watch: minimum over the 16 lanes of a row (every lane group holds
+// the same 16 values), uniform afterwards
+__device__ __forceinline__ float min_row16(float x) {
+  x = fminf(x, row_ror<8>(x));
+  x = fminf(x, row_ror<4>(x));
+  x = fminf(x, row_ror<2>(x));
+  x = fminf(x, row_ror<1>(x));
+  return x;
+}
 template <int T>
 __device__ __forceinline__ void cholesky_tiles_pairs(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
   static_assert(T % 2 == 0, "block rows are taken two at a time");
@@ -425,6 +438,7 @@ template <int T, bool SPLIT = false, bool RESPLIT = (T >= MALS_SYRK_RESPLIT_MINT
 __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, float& minpiv) {
   if constexpr (PAIRS && SPLIT && RESPLIT && T % 2 == 0 && T >= MALS_SYRK_PAIRS_MINT) {
     cholesky_tiles_pairs<T>(acc, lane, minpiv);
+    minpiv = min_row16(minpiv);
     return;
   }
 #pragma unroll
@@ -479,6 +493,7 @@ __device__ __forceinline__ void cholesky_tiles(f32x4 (&acc)[tri(T)], int lane, f
       }
     }
   }
+  minpiv = min_row16(minpiv);
 }
 
 // vector layout conversions: "col layout" = lane (g,c) holds v[c]; "row layout" = lanes of group g

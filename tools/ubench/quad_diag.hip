@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void k(const float* in, float* out, float* out
     }
     for (int r = 0; r < 4; ++r) D[r] = D0[r] + 1e-30f * (U[r] + a0[r] + a1[r] + a2[r] + a3[r]);
   }
-  if (QUAD) minpiv = fminf(fminf(minpiv, row_ror<8>(minpiv)), fminf(row_ror<4>(minpiv), row_ror<12>(minpiv))),
-            minpiv = fminf(fminf(minpiv, row_ror<1>(minpiv)), fminf(row_ror<2>(minpiv), row_ror<3>(minpiv)));
+  minpiv = fminf(fminf(minpiv, row_ror<8>(minpiv)), fminf(row_ror<4>(minpiv), row_ror<12>(minpiv))),
+  minpiv = fminf(fminf(minpiv, row_ror<1>(minpiv)), fminf(row_ror<2>(minpiv), row_ror<3>(minpiv)));
   for (int r = 0; r < 4; ++r) out[w * 256 + (4 * g + r) * 16 + c] = U[r];
   if (lane == 0) out_piv[w] = minpiv;
 }
