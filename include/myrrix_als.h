@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MALS_ABI_VERSION 3
+#define MALS_ABI_VERSION 4
 
 typedef struct mals_handle_s* mals_handle;
 
@@ -329,8 +329,8 @@ int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_
  *   then entries with |value| < zero_threshold (model.decay.zeroThreshold, IFR:58-59) are dropped,
  *   which may leave existing rows empty (IFR:200-211 removes entries, not rows).
  * Dense indices are assigned in ascending id order; CSR columns ascend within a row.  Side X = R by
- * user, side Y = R^T by item.  Text parsing, tag hashing and file ordering stay with the caller.
- * At most 2^31 records per ingest. */
+ * user, side Y = R^T by item.  Records come from the caller (mals_ingest_append) or from the text of the
+ * input files (mals_ingest_append_text / _read_file / _read_dir, below).  At most 2^31 records per ingest. */
 typedef struct mals_ingest_s* mals_ingest;
 int mals_ingest_create(int32_t device, float zero_threshold, mals_ingest* out);
 int mals_ingest_destroy(mals_ingest g);
@@ -351,6 +351,69 @@ int mals_ingest_install(mals_ingest g, mals_handle h);
  * workspace (52 bytes per record, kept for later finishes; hipMalloc of tens of GB is slow), algorithmic
  * bytes read+written by all passes, radix passes run */
 int mals_ingest_stats(mals_ingest g, double* finish_ms, double* workspace_ms, double* bytes_moved, int32_t* radix_passes);
+
+/* ---- the TEXT half of the same row: bytes of the input files -> records, on the device -----------------
+ * Replaces the line loop of InputFilesReader.readInputFiles (IFR = online-local/src/net/myrrix/online/generation/
+ * InputFilesReader.java:88-192) over FileLineIterable (common/src/net/myrrix/common/iterator/FileLineIterator.java):
+ *   lines      java.io.BufferedReader.readLine: '\n', '\r' or "\r\n" ends a line; bytes after the last terminator
+ *              of a file are its last line
+ *   IFR:92-98  one line counter and one bad-line counter over all files; the line FOLLOWING the 101st bad line
+ *              fails the whole read with "Too many bad lines; aborting" (MALS_IO_ERROR, like the IOException)
+ *   IFR:101    empty lines and lines starting with '#' are skipped
+ *   IFR:51,105 Splitter.on(',').trimResults(): only the first three tokens are looked at; guava whitespace
+ *              (ASCII and non-ASCII) is trimmed from each
+ *   IFR:114-130 user and item tokens: Long.parseLong, or -- token starting with '"' -- a tag:
+ *              OneWayMigrator.toLongID(token.substring(1, token.length()-1)) = first 8 bytes of the MD5 of the
+ *              UTF-8 bytes, big-endian; a token that is a lone '"' makes the reference throw an unchecked
+ *              StringIndexOutOfBoundsException out of readInputFiles: MALS_INVALID_ARG here
+ *   IFR:132-137 value token: absent -> 1.0f; empty -> NaN = "remove this entry"; else LangUtils.parseFloat
+ *              (Float.parseFloat's grammar, correctly rounded; NaN / infinite / overflowing values rejected)
+ *   IFR:139-157 fewer than two tokens, or two tags -> bad line; an unparseable token -> bad line, except on line 1
+ *              of the whole input, which is taken for a header and ignored
+ *   IFR:159-165 tag in the user column -> its id joins itemTagIDs; in the item column -> userTagIDs
+ *   IFR:173-191 knownItemIDs (MALS_INGEST_OPT_KNOWN_ITEMS): per user the items whose last line was not a remove
+ * The parsed records join those of mals_ingest_append in stream order and go through the same mals_ingest_finish.
+ * Everything after the bytes reach HBM runs on the device (csrc/ingest_text_kernels.h, csrc/text_parse.h); the
+ * host lists and inflates files (zlib) and keeps the two sequential counters.  Behaviour of the JDK / guava /
+ * mahout pieces this restates is listed, with what is pinned and what is not, at the top of csrc/text_parse.h.
+ *
+ * mals_ingest_append_text: `bytes` continue the current file (any split, also inside a line or between '\r' and
+ * '\n'); end_of_file != 0 closes the file: its unterminated last line, if any, is a line.  MALS_MEM_DEVICE: the
+ * bytes are already in HBM. */
+enum { MALS_INGEST_OPT_KNOWN_ITEMS = 1, MALS_INGEST_OPT_TEXT_BLOCK_BYTES = 2 };
+enum { MALS_ITEM_TAG_IDS = 0, MALS_USER_TAG_IDS = 1 };
+int mals_ingest_set_option(mals_ingest g, int32_t option, int64_t value);
+int mals_ingest_append_text(mals_ingest g, const void* bytes, int64_t n_bytes, int mem_kind, int32_t end_of_file);
+/* One input file, by name like FileLineIterator.getFileInputStream (FLI:92-102): "*.gz" is inflated (all members, like
+ * GZIPInputStream); "*.zip" yields NO lines -- the reference wraps it in a ZipInputStream on which getNextEntry()
+ * is never called, and such a stream reads as empty; anything else is read as it is. */
+int mals_ingest_read_file(mals_ingest g, const char* path);
+/* IFR:71-86: the files of input_dir matching .+\.csv(\.(zip|gz))? in ascending last-modified order (equal
+ * timestamps: by name; the reference leaves that order to File.listFiles()).  A missing directory reads nothing. */
+int mals_ingest_read_dir(mals_ingest g, const char* input_dir, int32_t* n_files_read);
+typedef struct mals_ingest_text_info_t {
+  int32_t struct_size; /* sizeof(mals_ingest_text_info_t) */
+  int32_t reserved;
+  int64_t lines;             /* IFR:99 `lines` */
+  int64_t bad_lines;         /* IFR:93 `badLines` */
+  int64_t header_lines;      /* 0 or 1 */
+  int64_t skipped_lines;     /* empty or comment */
+  int64_t full_parser_lines; /* lines the fast (ASCII, numeric) parser handed to the full one */
+  int64_t text_bytes;
+  int64_t records;           /* records held (text and mals_ingest_append) */
+  double parse_ms;           /* HIP-event milliseconds of the text kernels so far */
+  int64_t n_item_tag_ids;    /* after mals_ingest_finish; -1 before */
+  int64_t n_user_tag_ids;
+  int64_t n_known_items;     /* entries of knownItemIDs; -1 if not requested / not finished */
+} mals_ingest_text_info_t;
+int mals_ingest_text_info(mals_ingest g, mals_ingest_text_info_t* out);
+/* after mals_ingest_finish: ascending ids of itemTagIDs / userTagIDs */
+int mals_ingest_get_tag_ids(mals_ingest g, int32_t which, int64_t* host_ids_out);
+/* after mals_ingest_finish with MALS_INGEST_OPT_KNOWN_ITEMS: knownItemIDs as a CSR over the dense user indices
+ * (n_users + 1 offsets) holding dense item indices, ascending within a user.  Its users are exactly the rows of
+ * side X and its items rows of side Y; it differs from R's pattern by the entries removeSmall pruned (IFR:194-211). */
+int mals_ingest_get_known_items(mals_ingest g, int64_t* host_ptr, int32_t* host_item_idx);
+int mals_ingest_device_known_items(mals_ingest g, const int64_t** ptr, const int32_t** item_idx, int64_t* n_known);
 
 /* ---- model.bin.gz, the file through which the factors leave and re-enter
  * the unmodified Java server.  Replaces GenerationSerializer.writeGeneration / readGeneration

@@ -14,8 +14,10 @@ FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
 SOLVE_AUTO, SOLVE_DIRECT, SOLVE_DUAL = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 GROUP_RCCL, GROUP_PEER_COPY = 0, 1
+INGEST_OPT_KNOWN_ITEMS, INGEST_OPT_TEXT_BLOCK_BYTES = 1, 2
+ITEM_TAG_IDS, USER_TAG_IDS = 0, 1
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
                 COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM",
@@ -68,6 +70,13 @@ class IterationInfo(ctypes.Structure):   # mals_iteration_info
                 ("seconds", ctypes.c_double), ("x_rows", ctypes.c_int64), ("y_rows", ctypes.c_int64),
                 ("entries_gathered", ctypes.c_int64), ("algorithmic_bytes", ctypes.c_double), ("devices", ctypes.c_int32),
                 ("reserved", ctypes.c_int32)]
+
+
+class IngestTextInfo(ctypes.Structure):   # mals_ingest_text_info_t
+    _fields_ = [("struct_size", ctypes.c_int32), ("reserved", ctypes.c_int32), ("lines", ctypes.c_int64), ("bad_lines", ctypes.c_int64),
+                ("header_lines", ctypes.c_int64), ("skipped_lines", ctypes.c_int64), ("full_parser_lines", ctypes.c_int64),
+                ("text_bytes", ctypes.c_int64), ("records", ctypes.c_int64), ("parse_ms", ctypes.c_double),
+                ("n_item_tag_ids", ctypes.c_int64), ("n_user_tag_ids", ctypes.c_int64), ("n_known_items", ctypes.c_int64)]
 
 
 ITERATION_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(IterationInfo))
@@ -148,6 +157,14 @@ SYMBOLS = {
     "mals_ingest_install": (ctypes.c_int, [_H, _H]),
     "mals_ingest_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I32)]),
+    "mals_ingest_set_option": (ctypes.c_int, [_H, _I32, _I64]),
+    "mals_ingest_append_text": (ctypes.c_int, [_H, _P, _I64, ctypes.c_int, _I32]),
+    "mals_ingest_read_file": (ctypes.c_int, [_H, ctypes.c_char_p]),
+    "mals_ingest_read_dir": (ctypes.c_int, [_H, ctypes.c_char_p, ctypes.POINTER(_I32)]),
+    "mals_ingest_text_info": (ctypes.c_int, [_H, ctypes.POINTER(IngestTextInfo)]),
+    "mals_ingest_get_tag_ids": (ctypes.c_int, [_H, _I32, _P]),
+    "mals_ingest_get_known_items": (ctypes.c_int, [_H, _P, _P]),
+    "mals_ingest_device_known_items": (ctypes.c_int, [_H, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(_I64)]),
     "mals_plan_shards": (ctypes.c_int, [_P, _I64, _I32, ctypes.c_double, _I32, _P]),
     "mals_group_set_alternate_streams": (ctypes.c_int, [_H, _I32]),
     "mals_group_create": (ctypes.c_int, [ctypes.POINTER(Config), _P, _I32, _I32, ctypes.POINTER(_H)]),

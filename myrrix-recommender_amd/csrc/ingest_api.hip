@@ -3,6 +3,7 @@
 // (ingest_kernels.h); the host only sequences kernels and reads back three counters.
 #include "../../include/myrrix_als.h"
 #include "ingest_kernels.h"
+#include "ingest_text_kernels.h"
 
 #include <hip/hip_runtime.h>
 
@@ -45,6 +46,40 @@ struct mals_ingest_s {
   double last_finish_ms = 0.0;
   double bytes_moved = 0.0;  // algorithmic bytes of the last finish (reads + writes of every pass)
   int radix_passes = 0;
+  // ---- text -> records (ingest_text_host.h) ----
+  size_t text_block_bytes = (size_t)256 << 20;
+  uint8_t* d_text = nullptr;   // [carried tail][new bytes][padding]
+  size_t text_cap = 0;
+  uint8_t* d_carry = nullptr;  // the unterminated tail of the previous block
+  size_t carry_cap = 0, carry_len = 0;
+  bool carry_ends_cr = false;
+  void* h_pinned = nullptr;    // staging buffer of mals_ingest_read_file
+  size_t pinned_cap = 0;
+  unsigned* t_block_counts = nullptr;
+  size_t t_block_counts_cap = 0;
+  unsigned* t_tile_sums = nullptr;
+  size_t t_tile_sums_cap = 0;
+  size_t t_line_cap = 0;       // per-line arrays of one block
+  unsigned *t_starts = nullptr, *t_flag = nullptr, *t_flag_scan = nullptr, *t_defer = nullptr;
+  uint8_t* t_status = nullptr;
+  int64_t *t_user = nullptr, *t_item = nullptr;
+  uint32_t* t_value = nullptr;
+  mals::TextCounters* t_counters = nullptr;  // + two tag cursors
+  int64_t* d_tags[2] = {nullptr, nullptr};   // [0]: itemTagIDs (tags seen in the user column), [1]: userTagIDs; with repeats
+  size_t tag_cap[2] = {0, 0}, n_tags_raw[2] = {0, 0};
+  int64_t lines = 0, bad_lines = 0, header_lines = 0, skipped_lines = 0, slow_lines = 0, text_bytes = 0;
+  bool abort_armed = false;    // badLines > 100: the next line throws (IFR:96-98)
+  bool text_failed = false;
+  int text_fail_code = 0;
+  std::string text_fail_msg;
+  double parse_ms = 0.0;
+  // results of the last finish that come from the text path's extras
+  int64_t* tag_ids[2] = {nullptr, nullptr};  // ascending, unique
+  int64_t n_tag_ids[2] = {0, 0};
+  bool want_known = false;
+  int64_t n_known = 0;
+  int64_t* known_ptr = nullptr;  // knownItemIDs as a CSR over the dense user / item indices
+  int32_t* known_idx = nullptr;
 };
 
 namespace {
@@ -145,7 +180,12 @@ void free_results(mals_ingest g) {
     dfree(g->ptr[sd]);
     dfree(g->col[sd]);
     dfree(g->val[sd]);
+    dfree(g->tag_ids[sd]);
+    g->n_tag_ids[sd] = 0;
   }
+  dfree(g->known_ptr);
+  dfree(g->known_idx);
+  g->n_known = 0;
   g->finished = false;
   g->n_users = g->n_items = g->nnz = 0;
 }
@@ -177,6 +217,10 @@ int mals_ingest_destroy(mals_ingest g) {
   dfree(g->d_item);
   dfree(g->d_value);
   for (int b = 0; b < mals_ingest_s::N_WS; ++b) dfree(g->ws[b]);
+  dfree(g->d_text); dfree(g->d_carry); dfree(g->t_block_counts); dfree(g->t_tile_sums); dfree(g->t_starts); dfree(g->t_flag);
+  dfree(g->t_flag_scan); dfree(g->t_defer); dfree(g->t_status); dfree(g->t_user); dfree(g->t_item); dfree(g->t_value);
+  dfree(g->t_counters); dfree(g->d_tags[0]); dfree(g->d_tags[1]);
+  if (g->h_pinned) (void)hipHostFree(g->h_pinned);
   delete g;
   return MALS_OK;
 }
@@ -247,10 +291,15 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
     if (int rc = alloc_results(g, 0, 0, 0)) return rc;
     ICHK(g, hipMemsetAsync(g->ptr[0], 0, sizeof(int64_t), g->stream));
     ICHK(g, hipMemsetAsync(g->ptr[1], 0, sizeof(int64_t), g->stream));
+    if (g->want_known) {
+      ICHK(g, hipMalloc(&g->known_ptr, sizeof(int64_t)));
+      ICHK(g, hipMalloc(&g->known_idx, sizeof(int32_t)));
+      ICHK(g, hipMemsetAsync(g->known_ptr, 0, sizeof(int64_t), g->stream));
+    }
     return MALS_OK;
   }
   struct Tmp {  // small per-finish device temporaries (sized by the number of distinct ids)
-    unsigned *head = nullptr, *scan = nullptr, *ri = nullptr, *keep = nullptr;  // arena
+    unsigned *head = nullptr, *scan = nullptr, *ri = nullptr, *keep = nullptr, *present = nullptr;  // arena
     float* pair_val = nullptr;                                                   // arena
     int32_t* coo_row = nullptr;                                                  // arena
     unsigned *alive_u = nullptr, *alive_i = nullptr, *new_u = nullptr, *new_i = nullptr;
@@ -295,6 +344,7 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
     t.keep = (unsigned*)s.pay64[0];
     t.pair_val = (float*)((char*)s.pay64[0] + k4);
     t.coo_row = (int32_t*)s.pay64[1];
+    t.present = g->want_known ? (unsigned*)((char*)s.pay64[1] + k4) : nullptr;  // coo_row needs 4 bytes per entry at most
   }
   ICHK(g, hipEventRecord(e0, g->stream));  // the pipeline proper starts here
   // 1. records sorted by item id (stable: stream order inside an item); dense item rank of every position
@@ -337,9 +387,9 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
   ICHK(g, hipMemsetAsync(t.alive_u, 0, sizeof(unsigned) * (size_t)n_u_all, g->stream));
   ICHK(g, hipMemsetAsync(t.alive_i, 0, sizeof(unsigned) * (size_t)n_i_all, g->stream));
   hipLaunchKernelGGL(replay_pairs_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], sorted_val, n, g->zero_threshold,
-                     t.keep, t.pair_val, t.alive_u, t.alive_i);
+                     t.keep, t.pair_val, t.alive_u, t.alive_i, t.present);
   ICHK(g, hipGetLastError());
-  g->bytes_moved += (8.0 + 4.0 + 8.0) * (double)n;
+  g->bytes_moved += (8.0 + 4.0 + 8.0 + (t.present ? 4.0 : 0.0)) * (double)n;
   // 5. ids that still own an entry, renumbered densely (ascending id)
   if (int rc = scan_u32(g, s, t.alive_u, t.new_u, n_u_all, &n_users)) return rc;
   if (int rc = scan_u32(g, s, t.alive_i, t.new_i, n_i_all, &n_items)) return rc;
@@ -356,6 +406,22 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
                      (int64_t)n_users, g->ptr[0]);
   ICHK(g, hipGetLastError());
   g->bytes_moved += 16.0 * (double)n + 16.0 * (double)nnz + 8.0 * (double)n_users;
+  // 6b. knownItemIDs (IFR:173-191): the pairs present at the end of the stream, pruned from R or not, as a CSR over
+  //    the same dense indices (its users are exactly the rows of RbyRow, its items rows of RbyColumn)
+  if (g->want_known) {
+    unsigned n_known = 0;
+    if (int rc = scan_u32(g, s, t.present, t.scan, n, &n_known)) return rc;
+    g->n_known = n_known;
+    ICHK(g, hipMalloc(&g->known_ptr, sizeof(int64_t) * ((size_t)n_users + 1)));
+    ICHK(g, hipMalloc(&g->known_idx, sizeof(int32_t) * std::max<size_t>(n_known, 1)));
+    int32_t* known_row = (int32_t*)t.ri;
+    hipLaunchKernelGGL(compact_known_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[r], t.present, t.scan, n, t.new_u, t.new_i,
+                       known_row, g->known_idx);
+    hipLaunchKernelGGL(row_ptr_from_sorted_kernel, dim3(blocks_for((int64_t)n_known + 1)), dim3(256), 0, g->stream, known_row,
+                       (int64_t)n_known, (int64_t)n_users, g->known_ptr);
+    ICHK(g, hipGetLastError());
+    g->bytes_moved += (4.0 + 12.0 + 8.0) * (double)n + 12.0 * (double)n_known + 8.0 * (double)n_users;
+  }
   // 7. the transposed matrix: the entries are sorted by (user, item); a STABLE sort on the item half of
   //    the key alone leaves the users ascending inside every item, so the four low digits are not sorted
   if (nnz > 0) {
@@ -374,6 +440,23 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
                      (int64_t)n_items, g->ptr[1]);
   ICHK(g, hipGetLastError());
   g->bytes_moved += 4.0 * (double)nnz + 8.0 * (double)n_items;
+  // 8. tag id sets (IFR:159-165): sorted, unique
+  for (int which = 0; which < 2; ++which) {
+    const int64_t nt = (int64_t)g->n_tags_raw[which];
+    if (nt == 0) continue;  // nt <= n: every tag comes from a record
+    hipLaunchKernelGGL(ids_to_keys_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, g->d_tags[which], nt, s.keys[0], s.pay[0]);
+    ICHK(g, hipGetLastError());
+    int rt = 0;
+    if (int rc = radix_sort(g, s, s.pay, nt, &rt)) return rc;
+    hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, s.keys[rt], nt, t.head);
+    ICHK(g, hipGetLastError());
+    unsigned n_unique = 0;
+    if (int rc = scan_u32(g, s, t.head, t.scan, nt, &n_unique)) return rc;
+    ICHK(g, hipMalloc(&g->tag_ids[which], sizeof(int64_t) * (size_t)n_unique));
+    g->n_tag_ids[which] = n_unique;
+    hipLaunchKernelGGL(unique_ids_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, s.keys[rt], t.head, t.scan, nt, g->tag_ids[which]);
+    ICHK(g, hipGetLastError());
+  }
   ICHK(g, hipStreamSynchronize(g->stream));
   return MALS_OK;
 }
@@ -382,6 +465,8 @@ extern "C" {
 
 int mals_ingest_finish(mals_ingest g) {
   if (!g) return MALS_INVALID_ARG;
+  if (g->text_failed) return fail(g, g->text_fail_code, g->text_fail_msg);
+  if (g->carry_len) return fail(g, MALS_INVALID_ARG, "text pending: the last mals_ingest_append_text of a file must say end_of_file");
   ICHK(g, hipSetDevice(g->device));
   free_results(g);
   g->bytes_moved = 0.0;
@@ -470,3 +555,5 @@ int mals_ingest_stats(mals_ingest g, double* finish_ms, double* workspace_ms, do
 }
 
 }  // extern "C"
+
+#include "ingest_text_host.h"

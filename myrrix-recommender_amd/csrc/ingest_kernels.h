@@ -323,9 +323,11 @@ __global__ void pair_from_sorted_kernel(const uint64_t* __restrict__ ukeys, cons
 __global__ void replay_pairs_kernel(const uint64_t* __restrict__ keys, const float* __restrict__ values,  // both in sorted order
                                     int64_t n, float zero_threshold,
                                     unsigned* __restrict__ keep, float* __restrict__ pair_val,
-                                    unsigned* __restrict__ user_alive, unsigned* __restrict__ item_alive) {
+                                    unsigned* __restrict__ user_alive, unsigned* __restrict__ item_alive,
+                                    unsigned* __restrict__ present_out) {  // present_out (may be null): knownItemIDs, IFR:173-191
   MALS_GRID_STRIDE(i, n) {
     keep[i] = 0;
+    if (present_out) present_out[i] = 0;
     const uint64_t k = keys[i];
     if (i != 0 && keys[i - 1] == k) continue;  // not the head of its run
     bool present = false;
@@ -345,6 +347,7 @@ __global__ void replay_pairs_kernel(const uint64_t* __restrict__ keys, const flo
       user_alive[(unsigned)(k >> 32)] = 1u;
       item_alive[(unsigned)(k & 0xffffffffu)] = 1u;
       pair_val[i] = v;
+      if (present_out) present_out[i] = 1u;
       keep[i] = (fabsf(v) < zero_threshold) ? 0u : 1u;  // removeSmall, IFR:200-211 (NaN sums are kept, like there)
     }
   }

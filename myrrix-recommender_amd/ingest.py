@@ -1,10 +1,11 @@
 """Ingest -> CSR on the device: plumbing over mals_ingest_* and the
 host mirror of the reference entry point.
 
-`Ingest` is one mals_ingest object.  `readInputRecords` mirrors the part of
-InputFilesReader.readInputFiles (online-local/.../generation/InputFilesReader.java:64-211) that
-follows line parsing: it takes the parsed records in file order and returns what the reference
-leaves in RbyRow / RbyColumn -- as id tables + two CSR matrices."""
+`Ingest` is one mals_ingest object.  `readInputFiles` mirrors InputFilesReader.readInputFiles
+(online-local/.../generation/InputFilesReader.java:64-211): a directory of *.csv / *.csv.gz files in,
+what the reference leaves in RbyRow / RbyColumn, itemTagIDs, userTagIDs and knownItemIDs out -- as id
+tables + CSR matrices; `readInputRecords` is its second half alone, for callers that parse lines
+themselves."""
 import ctypes
 
 import numpy as np
@@ -62,6 +63,49 @@ class Ingest:
             self._chk(self._L.mals_ingest_append(self._g, len(u), u.ctypes.data_as(ctypes.c_void_p),
                                                  i.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p), MEM_HOST))
 
+    def set_option(self, option, value):
+        self._chk(self._L.mals_ingest_set_option(self._g, int(option), int(value)))
+
+    def append_text(self, data, end_of_file=True):
+        """Bytes of an input file (bytes-like, or a torch uint8 CUDA tensor already in HBM).  A file may arrive in any
+        number of pieces, split anywhere; the last piece says end_of_file."""
+        if _is_torch(data):
+            assert data.is_cuda and str(data.dtype) == "torch.uint8"
+            d = data.contiguous()
+            self._chk(self._L.mals_ingest_append_text(self._g, ctypes.c_void_p(d.data_ptr()), int(d.numel()), MEM_DEVICE, int(end_of_file)))
+        else:
+            b = bytes(data)
+            self._chk(self._L.mals_ingest_append_text(self._g, ctypes.c_char_p(b) if b else None, len(b), MEM_HOST, int(end_of_file)))
+
+    def read_file(self, path):
+        self._chk(self._L.mals_ingest_read_file(self._g, str(path).encode()))
+
+    def read_dir(self, path):
+        n = ctypes.c_int32()
+        self._chk(self._L.mals_ingest_read_dir(self._g, str(path).encode(), ctypes.byref(n)))
+        return n.value
+
+    def text_info(self):
+        info = _lib.IngestTextInfo()
+        info.struct_size = ctypes.sizeof(info)
+        self._chk(self._L.mals_ingest_text_info(self._g, ctypes.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_ if k not in ("struct_size", "reserved")}
+
+    def tag_ids(self, which):
+        n = self.text_info()["n_item_tag_ids" if which == _lib.ITEM_TAG_IDS else "n_user_tag_ids"]
+        out = np.empty(max(n, 0), dtype=np.int64)
+        self._chk(self._L.mals_ingest_get_tag_ids(self._g, which, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def known_items(self):
+        """knownItemIDs as (row_ptr over the dense users, dense item indices)."""
+        c = self.counts()
+        n = self.text_info()["n_known_items"]
+        ptr = np.empty(c["users"] + 1, dtype=np.int64)
+        idx = np.empty(max(n, 0), dtype=np.int32)
+        self._chk(self._L.mals_ingest_get_known_items(self._g, ptr.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p)))
+        return ptr, idx
+
     def finish(self):
         self._chk(self._L.mals_ingest_finish(self._g))
 
@@ -109,4 +153,27 @@ def readInputRecords(user_ids, item_ids, values, device=0, zero_threshold=None):
         return g.ids(SIDE_X), g.ids(SIDE_Y), g.csr(SIDE_X), g.csr(SIDE_Y)
 
 
-__all__ = ["Ingest", "readInputRecords"]
+def readInputFiles(inputDir, device=0, zero_threshold=None, known_items=True):
+    """InputFilesReader.readInputFiles(knownItemIDs, rbyRow, rbyColumn, itemTagIDs, userTagIDs, inputDir) (IFR:64-192):
+    returns a dict with the id tables, both CSR matrices, the two tag id sets and knownItemIDs (None when the caller
+    runs with model.noKnownItems, IFR:173)."""
+    import logging
+    from .factorizer import System
+    log = logging.getLogger("net.myrrix.online.generation.InputFilesReader")
+    if zero_threshold is None:
+        zero_threshold = float(System.getProperty("model.decay.zeroThreshold", "0.0001"))  # IFR:58-59
+    with Ingest(device, zero_threshold) as g:
+        if known_items:
+            g.set_option(_lib.INGEST_OPT_KNOWN_ITEMS, 1)
+        n_files = g.read_dir(inputDir)
+        if n_files == 0:
+            log.info("No input files in %s", inputDir)
+        log.info("Pruning near-zero entries")
+        g.finish()
+        info = g.text_info()
+        return {"user_ids": g.ids(SIDE_X), "item_ids": g.ids(SIDE_Y), "RbyRow": g.csr(SIDE_X), "RbyColumn": g.csr(SIDE_Y),
+                "itemTagIDs": g.tag_ids(_lib.ITEM_TAG_IDS), "userTagIDs": g.tag_ids(_lib.USER_TAG_IDS),
+                "knownItemIDs": g.known_items() if known_items else None, "info": info}
+
+
+__all__ = ["Ingest", "readInputRecords", "readInputFiles"]
