@@ -380,7 +380,10 @@ int mals_ingest_stats(mals_ingest g, double* finish_ms, double* workspace_ms, do
  * mals_ingest_append_text: `bytes` continue the current file (any split, also inside a line or between '\r' and
  * '\n'); end_of_file != 0 closes the file: its unterminated last line, if any, is a line.  MALS_MEM_DEVICE: the
  * bytes are already in HBM. */
-enum { MALS_INGEST_OPT_KNOWN_ITEMS = 1, MALS_INGEST_OPT_TEXT_BLOCK_BYTES = 2 };
+/* KNOWN_ITEMS: also build knownItemIDs (off by default); TEXT_BLOCK_BYTES: bytes handed to the device at a time
+ * (default 256 MiB); RESERVE_RECORDS: allocate the record arrays for this many records now (they grow by copying
+ * otherwise) */
+enum { MALS_INGEST_OPT_KNOWN_ITEMS = 1, MALS_INGEST_OPT_TEXT_BLOCK_BYTES = 2, MALS_INGEST_OPT_RESERVE_RECORDS = 3 };
 enum { MALS_ITEM_TAG_IDS = 0, MALS_USER_TAG_IDS = 1 };
 int mals_ingest_set_option(mals_ingest g, int32_t option, int64_t value);
 int mals_ingest_append_text(mals_ingest g, const void* bytes, int64_t n_bytes, int mem_kind, int32_t end_of_file);
@@ -402,6 +405,8 @@ typedef struct mals_ingest_text_info_t {
   int64_t text_bytes;
   int64_t records;           /* records held (text and mals_ingest_append) */
   double parse_ms;           /* HIP-event milliseconds of the text kernels so far */
+  double stage_ms;           /* ... of bringing the blocks in front of them: host-to-device copies (PCIe) for
+                                MALS_MEM_HOST bytes, a device-to-device copy for MALS_MEM_DEVICE */
   int64_t n_item_tag_ids;    /* after mals_ingest_finish; -1 before */
   int64_t n_user_tag_ids;
   int64_t n_known_items;     /* entries of knownItemIDs; -1 if not requested / not finished */

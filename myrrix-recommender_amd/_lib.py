@@ -16,7 +16,7 @@ GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
 SOLVE_AUTO, SOLVE_DIRECT, SOLVE_DUAL = 0, 1, 2
 ABI_VERSION = 4
 GROUP_RCCL, GROUP_PEER_COPY = 0, 1
-INGEST_OPT_KNOWN_ITEMS, INGEST_OPT_TEXT_BLOCK_BYTES = 1, 2
+INGEST_OPT_KNOWN_ITEMS, INGEST_OPT_TEXT_BLOCK_BYTES, INGEST_OPT_RESERVE_RECORDS = 1, 2, 3
 ITEM_TAG_IDS, USER_TAG_IDS = 0, 1
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
@@ -75,7 +75,7 @@ class IterationInfo(ctypes.Structure):   # mals_iteration_info
 class IngestTextInfo(ctypes.Structure):   # mals_ingest_text_info_t
     _fields_ = [("struct_size", ctypes.c_int32), ("reserved", ctypes.c_int32), ("lines", ctypes.c_int64), ("bad_lines", ctypes.c_int64),
                 ("header_lines", ctypes.c_int64), ("skipped_lines", ctypes.c_int64), ("full_parser_lines", ctypes.c_int64),
-                ("text_bytes", ctypes.c_int64), ("records", ctypes.c_int64), ("parse_ms", ctypes.c_double),
+                ("text_bytes", ctypes.c_int64), ("records", ctypes.c_int64), ("parse_ms", ctypes.c_double), ("stage_ms", ctypes.c_double),
                 ("n_item_tag_ids", ctypes.c_int64), ("n_user_tag_ids", ctypes.c_int64), ("n_known_items", ctypes.c_int64)]
 
 

@@ -72,7 +72,8 @@ struct mals_ingest_s {
   bool text_failed = false;
   int text_fail_code = 0;
   std::string text_fail_msg;
-  double parse_ms = 0.0;
+  double parse_ms = 0.0, stage_ms = 0.0;
+  hipEvent_t t_ev[2] = {nullptr, nullptr};
   // results of the last finish that come from the text path's extras
   int64_t* tag_ids[2] = {nullptr, nullptr};  // ascending, unique
   int64_t n_tag_ids[2] = {0, 0};
@@ -221,6 +222,8 @@ int mals_ingest_destroy(mals_ingest g) {
   dfree(g->t_flag_scan); dfree(g->t_defer); dfree(g->t_status); dfree(g->t_user); dfree(g->t_item); dfree(g->t_value);
   dfree(g->t_counters); dfree(g->d_tags[0]); dfree(g->d_tags[1]);
   if (g->h_pinned) (void)hipHostFree(g->h_pinned);
+  if (g->t_ev[0]) (void)hipEventDestroy(g->t_ev[0]);
+  if (g->t_ev[1]) (void)hipEventDestroy(g->t_ev[1]);
   delete g;
   return MALS_OK;
 }

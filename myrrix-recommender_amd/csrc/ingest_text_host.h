@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr size_t TEXT_PAD = 64;  // readable bytes behind the text (16-byte and 8-byte aligned window loads)
+constexpr size_t TEXT_PAD = 128;  // readable bytes behind the text (16-byte and 8-byte aligned window loads)
 
 struct TextScratch {
   unsigned* block_counts = nullptr;  // line starts per LT_BLOCK_BYTES, then their exclusive scan
@@ -72,6 +72,8 @@ int ensure_record_capacity(mals_ingest g, int64_t extra) {
 int process_text_region(mals_ingest g, size_t region) {
   if (region == 0) return MALS_OK;
   if (region >= 0xffffff00ull) return fail(g, MALS_INVALID_ARG, "text block too large");
+  // HIP-event time of the kernels only: allocations (which cost milliseconds to seconds, depending on the box) sit
+  // between the timed segments
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ICHK(g, hipEventCreate(&e0));
   ICHK(g, hipEventCreate(&e1));
@@ -82,6 +84,14 @@ int process_text_region(mals_ingest g, size_t region) {
       (void)hipEventDestroy(b);
     }
   } ev{e0, e1};
+  auto seg_end = [&]() -> int {
+    ICHK(g, hipEventRecord(e1, g->stream));
+    ICHK(g, hipEventSynchronize(e1));
+    float ms = 0.f;
+    ICHK(g, hipEventElapsedTime(&ms, e0, e1));
+    g->parse_ms += ms;
+    return MALS_OK;
+  };
   ICHK(g, hipEventRecord(e0, g->stream));
   // 1. line starts
   const int64_t n_blk = ((int64_t)region + LT_BLOCK_BYTES - 1) / LT_BLOCK_BYTES;
@@ -95,6 +105,7 @@ int process_text_region(mals_ingest g, size_t region) {
   ICHK(g, hipGetLastError());
   unsigned n_lines = 0;
   if (int rc = scan_u32(g, s, g->t_block_counts, g->t_block_counts, n_blk, &n_lines)) return rc;
+  if (int rc = seg_end()) return rc;
   if (n_lines == 0) return fail(g, MALS_HIP_ERROR, "internal: a non-empty text region without a line");
   // sequential rule IFR:96-98: the line that follows the 101st bad line throws
   if (g->abort_armed) return text_fail(g, MALS_IO_ERROR, "Too many bad lines; aborting");
@@ -106,12 +117,11 @@ int process_text_region(mals_ingest g, size_t region) {
     g->t_line_cap = 0;
     const size_t cap = L + L / 4;
     ICHK(g, hipMalloc(&g->t_starts, sizeof(unsigned) * cap));
-    ICHK(g, hipMalloc(&g->t_status, cap));
+    ICHK(g, hipMalloc(&g->t_status, cap + 8));
     ICHK(g, hipMalloc(&g->t_user, sizeof(int64_t) * cap));
     ICHK(g, hipMalloc(&g->t_item, sizeof(int64_t) * cap));
     ICHK(g, hipMalloc(&g->t_value, sizeof(uint32_t) * cap));
     ICHK(g, hipMalloc(&g->t_flag, sizeof(unsigned) * cap));
-    ICHK(g, hipMalloc(&g->t_flag_scan, sizeof(unsigned) * cap));
     ICHK(g, hipMalloc(&g->t_defer, sizeof(unsigned) * cap));
     g->t_line_cap = cap;
   }
@@ -122,6 +132,7 @@ int process_text_region(mals_ingest g, size_t region) {
     s.total = g->t_tile_sums + std::max(lt, tiles);
   }
   if (!g->t_counters) ICHK(g, hipMalloc(&g->t_counters, sizeof(TextCounters) + 2 * sizeof(unsigned)));
+  ICHK(g, hipEventRecord(e0, g->stream));
   ICHK(g, hipMemsetAsync(g->t_counters, 0, sizeof(TextCounters) + 2 * sizeof(unsigned), g->stream));
   hipLaunchKernelGGL(line_starts_kernel, dim3((unsigned)n_blk), dim3(256), 0, g->stream, g->d_text, (int64_t)region, g->t_block_counts,
                      g->t_starts);
@@ -133,11 +144,16 @@ int process_text_region(mals_ingest g, size_t region) {
   hipLaunchKernelGGL(parse_deferred_kernel, dim3((unsigned)std::min<size_t>((L + 63) / 64, 4096)), dim3(64), 0, g->stream, g->d_text,
                      g->t_starts, (int64_t)L, (unsigned)region, first, g->t_status, g->t_user, g->t_item, g->t_value, g->t_defer,
                      g->t_counters);
-  hipLaunchKernelGGL(line_summary_kernel, dim3(lgrid), dim3(256), 0, g->stream, g->t_status, (int64_t)L, g->t_flag, g->t_counters);
+  const int64_t ct = ((int64_t)L + CT_TILE - 1) / CT_TILE;  // t_flag: records per tile, then their exclusive scan
+  hipLaunchKernelGGL(line_summary_kernel, dim3((unsigned)ct), dim3(256), 0, g->stream, g->t_status, (int64_t)L, g->t_flag, g->t_counters);
+  unsigned n_records = 0;
+  if (int rc = scan_u32(g, s, g->t_flag, g->t_flag, ct, nullptr)) return rc;
+  ICHK(g, hipMemcpyAsync(&n_records, s.total, sizeof(unsigned), hipMemcpyDeviceToHost, g->stream));
   ICHK(g, hipGetLastError());
   TextCounters c;
   ICHK(g, hipMemcpyAsync(&c, g->t_counters, sizeof(c), hipMemcpyDeviceToHost, g->stream));
-  ICHK(g, hipStreamSynchronize(g->stream));
+  if (int rc = seg_end()) return rc;
+  c.records = n_records;
   // 4. the sequential part of the contract
   if (c.fatal || g->bad_lines + (int64_t)c.bad > 100) {
     std::vector<uint8_t> st(L);
@@ -164,10 +180,11 @@ int process_text_region(mals_ingest g, size_t region) {
     if (g->n + (int64_t)c.records >= (int64_t)0x7fffff00) return text_fail(g, MALS_INVALID_ARG, "at most 2^31 records per ingest");
     if (g->finished) free_results(g);
     if (int rc = ensure_record_capacity(g, c.records)) return rc;
-    if (int rc = scan_u32(g, s, g->t_flag, g->t_flag_scan, (int64_t)L, nullptr)) return rc;
-    hipLaunchKernelGGL(compact_records_kernel, dim3(blocks_for((int64_t)L)), dim3(256), 0, g->stream, g->t_flag, g->t_flag_scan, (int64_t)L,
-                       g->t_user, g->t_item, g->t_value, g->d_user + g->n, g->d_item + g->n, g->d_value + g->n);
+    ICHK(g, hipEventRecord(e0, g->stream));
+    hipLaunchKernelGGL(compact_records_kernel, dim3((unsigned)ct), dim3(256), 0, g->stream, g->t_status, g->t_flag, (int64_t)L, g->t_user,
+                       g->t_item, g->t_value, g->d_user + g->n, g->d_item + g->n, g->d_value + g->n);
     ICHK(g, hipGetLastError());
+    if (int rc = seg_end()) return rc;
     g->n += c.records;
   }
   if (c.user_tags || c.item_tags) {
@@ -180,11 +197,6 @@ int process_text_region(mals_ingest g, size_t region) {
     g->n_tags_raw[0] += c.user_tags;
     g->n_tags_raw[1] += c.item_tags;
   }
-  ICHK(g, hipEventRecord(e1, g->stream));
-  ICHK(g, hipEventSynchronize(e1));
-  float ms = 0.f;
-  ICHK(g, hipEventElapsedTime(&ms, e0, e1));
-  g->parse_ms += ms;
   g->text_bytes += (int64_t)region;
   return MALS_OK;
 }
@@ -214,11 +226,17 @@ int append_text_impl(mals_ingest g, const uint8_t* bytes, int64_t n_bytes, int m
       ICHK(g, hipMalloc(&g->d_text, cap));
       g->text_cap = cap;
     }
+    if (!g->t_ev[0]) {
+      ICHK(g, hipEventCreate(&g->t_ev[0]));
+      ICHK(g, hipEventCreate(&g->t_ev[1]));
+    }
+    ICHK(g, hipEventRecord(g->t_ev[0], g->stream));
     if (g->carry_len) ICHK(g, hipMemcpyAsync(g->d_text, g->d_carry, g->carry_len, hipMemcpyDeviceToDevice, g->stream));
     if (m)
       ICHK(g, hipMemcpyAsync(g->d_text + g->carry_len, bytes + off, m, mem_kind == MALS_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
                              g->stream));
     ICHK(g, hipMemsetAsync(g->d_text + total, 0, TEXT_PAD, g->stream));
+    ICHK(g, hipEventRecord(g->t_ev[1], g->stream));
     // where the complete lines end
     size_t region;
     uint8_t last_byte = 0;
@@ -248,6 +266,12 @@ int append_text_impl(mals_ingest g, const uint8_t* bytes, int64_t n_bytes, int m
       else region = (g->carry_ends_cr && m) ? g->carry_len : 0;  // the carried '\r' turned out to be a terminator of its own
     }
     if (int rc = process_text_region(g, region)) return rc;
+    {
+      float ms = 0.f;
+      ICHK(g, hipEventSynchronize(g->t_ev[1]));
+      ICHK(g, hipEventElapsedTime(&ms, g->t_ev[0], g->t_ev[1]));
+      g->stage_ms += ms;  // bringing the block in front of the kernels: PCIe for host bytes, a device copy otherwise
+    }
     // the tail waits for the next block
     const size_t rest = total - region;
     if (rest) {
@@ -297,6 +321,11 @@ int mals_ingest_set_option(mals_ingest g, int32_t option, int64_t value) {
     case MALS_INGEST_OPT_KNOWN_ITEMS:
       g->want_known = value != 0;
       return MALS_OK;
+    case MALS_INGEST_OPT_RESERVE_RECORDS: {
+      if (value < 0 || value >= (int64_t)0x7fffff00) return fail(g, MALS_INVALID_ARG, "at most 2^31 records per ingest");
+      ICHK(g, hipSetDevice(g->device));
+      return ensure_record_capacity(g, std::max<int64_t>(0, value - g->n));
+    }
     case MALS_INGEST_OPT_TEXT_BLOCK_BYTES:
       if (value < 1 || value > (int64_t)1 << 31) return fail(g, MALS_INVALID_ARG, "text block: 1 byte .. 2 GiB");
       g->text_block_bytes = (size_t)value;
@@ -422,6 +451,7 @@ int mals_ingest_text_info(mals_ingest g, mals_ingest_text_info_t* out) {
   out->text_bytes = g->text_bytes;
   out->records = g->n;
   out->parse_ms = g->parse_ms;
+  out->stage_ms = g->stage_ms;
   out->n_item_tag_ids = g->finished ? g->n_tag_ids[0] : -1;
   out->n_user_tag_ids = g->finished ? g->n_tag_ids[1] : -1;
   out->n_known_items = (g->finished && g->known_ptr) ? g->n_known : -1;
