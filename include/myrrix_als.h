@@ -302,18 +302,29 @@ int mals_reconstruction_error(mals_handle h, double* sum_out, int64_t* count_out
  * ServerRecommender.recommend(userID, howMany, considerKnownItems, null) (online/src/net/myrrix/online/
  * ServerRecommender.java:382-441) -> multithreadedTopN (:443-508) -> RecommendIterator (RecommendIterator.
  * java:62-109) -> TopN (common/src/net/myrrix/common/TopN.java:49-128), for a batch of model users given by
- * their dense indices: score of item i = (float) dot(Y_i, X_u) with SimpleVectorMath.dot (fp32 products,
- * fp64 sum); the user's known items (the entries of its row of R on this handle) are skipped unless
- * consider_known_items; the how_many best come back best first, equal scores in ascending item index
- * (the reference leaves ties in hash order).  item_idx_out / score_out: n_queries x how_many, padded with
- * -1 / -inf; n_out (may be NULL): results per query.  Rescorers, candidate filters and tags stay with
- * the caller.  Y is streamed once per 64 queries. */
+ * their dense indices.  The score of item i IS the reference's: (float)(sum_j dot(Y_i, f_j) / n) over the
+ * query's n vectors with SimpleVectorMath.dot (every product rounded to fp32, fp64 sum in feature order,
+ * RecommendIterator.java:93-104) -- bit-identical; the user's known items (the entries of its row of R on this
+ * handle) are skipped unless consider_known_items; the how_many best come back best first, equal scores in
+ * ascending item index (the reference leaves ties in hash order).  item_idx_out / score_out: n_queries x
+ * how_many, padded with -1 / -inf; n_out (may be NULL): results per query.  Rescorers, candidate filters and
+ * tags stay with the caller (tag items: pass them as exclusions).  On large item sets a split-bf16 MFMA pass
+ * with a proven error margin only narrows the items down to a few hundred candidates per query, whose scores
+ * are then computed exactly (csrc/topn_kernels.h); Y is streamed once per up to 256 queries. */
 int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, int32_t how_many, int32_t consider_known_items,
                    int64_t* item_idx_out, float* score_out, int32_t* n_out);
 /* The same for caller-supplied query vectors (n_queries x features, host) -- anonymous users / fold-in
  * (SR:561-606) -- with optional per-query lists of item indices to skip (CSR: exclude_ptr has
  * n_queries+1 entries; both NULL = none). */
 int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_queries, int32_t how_many,
+                           const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
+                           int32_t* n_out);
+/* ... and for queries of SEVERAL vectors each -- recommendToMany (ServerRecommender.java:366-441: the feature
+ * vectors of all the users asked for; the caller passes the intersection of their known items, :398-425, as the
+ * exclusion list): query q owns vectors[vector_ptr[q] .. vector_ptr[q+1]) (rows of `vectors`, features floats
+ * each; at least one: RecommendIterator.java:52), its score is the mean of the dots, divided last
+ * (RecommendIterator.java:93-104).  vector_ptr NULL = one vector per query. */
+int mals_recommend_to_many(mals_handle h, const float* vectors, const int64_t* vector_ptr, int32_t n_queries, int32_t how_many,
                            const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
                            int32_t* n_out);
 

@@ -356,6 +356,29 @@ class ALSCore:
                                                  cnt.ctypes.data_as(ctypes.c_void_p)))
         return idx, sc, cnt
 
+    def recommend_to_many(self, queries, how_many, exclude=None):
+        """recommendToMany (ServerRecommender.java:366-441): queries = list of (n_j x features) arrays, one per query; the
+        score of an item is the mean of its dots with the query's vectors (RecommendIterator.java:93-104)."""
+        qs = [np.ascontiguousarray(np.atleast_2d(_host(q, np.float32))) for q in queries]
+        assert all(q.shape[1] == self.features for q in qs)
+        vptr = np.zeros(len(qs) + 1, dtype=np.int64)
+        vptr[1:] = np.cumsum([len(q) for q in qs])
+        flatv = np.ascontiguousarray(np.concatenate(qs, axis=0)) if qs else np.zeros((0, self.features), np.float32)
+        idx = np.empty((len(qs), how_many), dtype=np.int64)
+        sc = np.empty((len(qs), how_many), dtype=np.float32)
+        cnt = np.empty(len(qs), dtype=np.int32)
+        ep = ei = None
+        if exclude is not None:
+            ptr = np.zeros(len(qs) + 1, dtype=np.int64)
+            ptr[1:] = np.cumsum([len(e) for e in exclude])
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(e, np.int64) for e in exclude]) if ptr[-1] else np.zeros(0, np.int64))
+            ep, ei = ptr.ctypes.data_as(ctypes.c_void_p), flat.ctypes.data_as(ctypes.c_void_p)
+            self._keep[("excl",)] = (ptr, flat)
+        self._chk(self._L.mals_recommend_to_many(self._h, flatv.ctypes.data_as(ctypes.c_void_p), vptr.ctypes.data_as(ctypes.c_void_p),
+                                                 len(qs), int(how_many), ep, ei, idx.ctypes.data_as(ctypes.c_void_p),
+                                                 sc.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
+        return idx, sc, cnt
+
     def reconstruction_error(self):
         """ReconstructionEvaluator's sum and count over the local user rows (mean = sum / count)."""
         sm, cnt = ctypes.c_double(0.0), ctypes.c_int64(0)

@@ -197,16 +197,7 @@ struct mals_handle_s {
   mals_stats stats;
   std::vector<PendingEvent> pending;
   unsigned long long* d_trace = nullptr;  // MALS_DEBUG_TRACE
-  // top-N workspace (grow-only): score rows, selection output, state, histograms
-  float* tn_scores = nullptr;
-  uint32_t* tn_out = nullptr;
-  void* tn_state = nullptr;
-  unsigned* tn_hist = nullptr;
-  size_t tn_scores_cap = 0, tn_out_cap = 0;
-  uint32_t* tn_host = nullptr;  // pinned staging for the selection results
-  size_t tn_host_words = 0;
-  float* tn_q = nullptr;       // query vectors of one pass
-  int64_t* tn_qidx = nullptr;  // [2][TOPN_MAX_QUERIES]: user indices, local rows
+  void* tn_ws = nullptr;  // top-N workspace (topn_host.h), grow-only
   double* d_sd = nullptr;       // mals_sample_dots: estimates, indices
   int64_t* d_sd_idx = nullptr;
   size_t sd_cap = 0, sd_idx_cap = 0;
@@ -1236,227 +1227,7 @@ int launch_reconstruction(mals_handle h, SideState& s, SideState& o, unsigned gr
 
 
 namespace {
-template <int T, int MODE>
-int launch_topn_scores_T(mals_handle h, const float* Y, int64_t n_items, const float* dQ, int nq, int tile_stride, int64_t n_out,
-                         float* d_scores, TopnState* d_st, int cap, uint32_t* d_cand) {
-  const int64_t tiles = (n_items + 16 * (int64_t)tile_stride - 1) / (16 * (int64_t)tile_stride);
-  int per_cu = 16;
-  if (const char* e = std::getenv("MALS_TOPN_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e));  // tuning override
-  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + 3) / 4, (int64_t)h->n_cu * per_cu));
-#define MALS_TOPN_LAUNCH(NT)                                                                                                 \
-  hipLaunchKernelGGL((topn_scores_kernel<T, MODE, NT>), dim3(grid), dim3(256), 0, h->stream, Y, n_items, h->cfg.features, dQ, nq, \
-                     tile_stride, n_out, d_scores, d_st, cap, d_cand)
-  switch ((nq + 15) / 16) {
-    case 1: MALS_TOPN_LAUNCH(1); break;
-    case 2: MALS_TOPN_LAUNCH(2); break;
-    case 3: MALS_TOPN_LAUNCH(3); break;
-    default: MALS_TOPN_LAUNCH(4); break;
-  }
-#undef MALS_TOPN_LAUNCH
-  HIPCHK(h, hipGetLastError());
-  return MALS_OK;
-}
-template <int MODE>
-int launch_topn_scores(mals_handle h, const float* Y, int64_t n_items, const float* dQ, int nq, int tile_stride, int64_t n_out,
-                       float* d_scores, TopnState* d_st, int cap, uint32_t* d_cand) {
-  switch (h->T) {
-    case 1: return launch_topn_scores_T<1, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
-    case 2: return launch_topn_scores_T<2, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
-    case 3: return launch_topn_scores_T<3, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
-    case 4: return launch_topn_scores_T<4, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
-    case 5: return launch_topn_scores_T<5, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
-    case 6: return launch_topn_scores_T<6, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
-    case 7: return launch_topn_scores_T<7, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
-    case 8: return launch_topn_scores_T<8, MODE>(h, Y, n_items, dQ, nq, tile_stride, n_out, d_scores, d_st, cap, d_cand);
-  }
-  return fail(h, MALS_INVALID_ARG, "unsupported feature count");
-}
-
-struct TopnCand {
-  uint32_t key;
-  int64_t idx;
-};
-void topn_emit(std::vector<TopnCand>& cand, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
-  // best score first; equal scores in ascending item index (the reference's order among ties is its hash order)
-  std::sort(cand.begin(), cand.end(), [](const TopnCand& a, const TopnCand& b) { return a.key != b.key ? a.key > b.key : a.idx < b.idx; });
-  const int n = (int)std::min<size_t>(cand.size(), (size_t)how_many);
-  if (n_out) *n_out = n;
-  for (int j = 0; j < how_many; ++j) {
-    if (j < n) {
-      const uint32_t kk = cand[(size_t)j].key;
-      const uint32_t bits = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;
-      float f;
-      std::memcpy(&f, &bits, 4);
-      item_idx_out[j] = cand[(size_t)j].idx;
-      score_out[j] = f;
-    } else {
-      item_idx_out[j] = -1;
-      score_out[j] = -std::numeric_limits<float>::infinity();
-    }
-  }
-}
-
-// radix select of the how_many-th best score of every query over score rows of length n_row
-int topn_select_threshold(mals_handle h, const float* d_scores, int64_t n_row, int nq, int how_many, TopnState* d_st, unsigned* d_hist,
-                          unsigned* slabs_out) {
-  hipLaunchKernelGGL(topn_init_kernel, dim3((unsigned)((nq * 256 + 255) / 256)), dim3(256), 0, h->stream, d_st, d_hist, nq, how_many);
-  // slabs per query: enough workgroups to fill the chip whatever the batch size
-  const unsigned slabs = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_row + 4095) / 4096, (int64_t)(h->n_cu * 8 + nq - 1) / nq));
-  for (int pass = 0; pass < 4; ++pass) {
-    hipLaunchKernelGGL(topn_hist_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_row, pass, d_st, d_hist);
-    hipLaunchKernelGGL(topn_pick_kernel, dim3((unsigned)nq), dim3(256), 0, h->stream, d_st, d_hist, pass);
-  }
-  HIPCHK(h, hipGetLastError());
-  *slabs_out = slabs;
-  return MALS_OK;
-}
-
-int topn_workspace(mals_handle h, int64_t n_items, int how_many, int cap_ties) {
-  const size_t per_q = 2 * ((size_t)how_many + (size_t)cap_ties);
-  if (h->tn_scores_cap < (size_t)TOPN_MAX_QUERIES * (size_t)n_items) {
-    free_dev(h->tn_scores);
-    h->tn_scores_cap = 0;
-    HIPCHK(h, hipMalloc(&h->tn_scores, sizeof(float) * (size_t)TOPN_MAX_QUERIES * (size_t)n_items));
-    h->tn_scores_cap = (size_t)TOPN_MAX_QUERIES * (size_t)n_items;
-  }
-  if (h->tn_out_cap < (size_t)TOPN_MAX_QUERIES * per_q) {
-    free_dev(h->tn_out);
-    h->tn_out_cap = 0;
-    HIPCHK(h, hipMalloc(&h->tn_out, sizeof(uint32_t) * (size_t)TOPN_MAX_QUERIES * per_q));
-    h->tn_out_cap = (size_t)TOPN_MAX_QUERIES * per_q;
-  }
-  const size_t host_words = (size_t)TOPN_MAX_QUERIES * (per_q + 4);
-  if (h->tn_host_words < host_words) {
-    if (h->tn_host) (void)hipHostFree(h->tn_host);
-    h->tn_host = nullptr;
-    h->tn_host_words = 0;
-    HIPCHK(h, hipHostMalloc(&h->tn_host, sizeof(uint32_t) * host_words));
-    h->tn_host_words = host_words;
-  }
-  if (!h->tn_state) HIPCHK(h, hipMalloc(&h->tn_state, sizeof(TopnState) * TOPN_MAX_QUERIES));
-  if (!h->tn_hist) HIPCHK(h, hipMalloc(&h->tn_hist, sizeof(unsigned) * 256 * TOPN_MAX_QUERIES));
-  return MALS_OK;
-}
-
-// Exact path: every score is materialised (one row per query), the N-th best found by radix select
-// over the full rows, everything above it and the ties handed back.
-int topn_batch_full(mals_handle h, const float* dQ, const int64_t* d_query_row, const int64_t* d_excl_ptr, const int64_t* d_excl_idx,
-                    int nq, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
-  SideState& y = h->side[MALS_SIDE_Y];
-  SideState& x = h->side[MALS_SIDE_X];
-  const int64_t n_items = y.n_total;
-  const int cap_ties = 1024;
-  if (int rc = topn_workspace(h, n_items, how_many, cap_ties)) return rc;
-  float* d_scores = h->tn_scores;
-  uint32_t* d_out = h->tn_out;
-  TopnState* d_st = (TopnState*)h->tn_state;
-  const size_t per_q = 2 * ((size_t)how_many + cap_ties);
-  const size_t out_words = (size_t)nq * per_q;
-  if (int rc = launch_topn_scores<0>(h, y.F, n_items, dQ, nq, 1, n_items, d_scores, d_st, 0, nullptr)) return rc;
-  if (d_query_row) hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, nq, 1, n_items, d_scores);
-  if (d_excl_ptr) hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, d_excl_ptr, d_excl_idx, nq, n_items, 1, n_items, d_scores);
-  unsigned slabs = 1;
-  if (int rc = topn_select_threshold(h, d_scores, n_items, nq, how_many, d_st, h->tn_hist, &slabs)) return rc;
-  hipLaunchKernelGGL(topn_collect_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, d_scores, n_items, d_st, how_many, cap_ties, d_out);
-  HIPCHK(h, hipGetLastError());
-  uint32_t* out = h->tn_host;
-  TopnState* st = reinterpret_cast<TopnState*>(h->tn_host + (size_t)TOPN_MAX_QUERIES * per_q);
-  HIPCHK(h, hipMemcpyAsync(out, d_out, sizeof(uint32_t) * out_words, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(st, d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  std::vector<float> row;
-  std::vector<TopnCand> cand;
-  for (int q = 0; q < nq; ++q) {
-    const uint32_t* o = &out[(size_t)q * per_q];
-    const uint32_t above = st[(size_t)q].above, ties_total = st[(size_t)q].ties;
-    const uint32_t ties_stored = std::min<uint32_t>(ties_total, (uint32_t)cap_ties);
-    const uint32_t need_ties = above < (uint32_t)how_many ? (uint32_t)how_many - above : 0;
-    cand.clear();
-    if (above > (uint32_t)how_many || (ties_stored < ties_total && need_ties > 0)) {
-      // more ties at the N-th score than the selection buffer holds (e.g. a block of identical items): which of
-      // them have the lowest indices is not known from an unordered subset -- resolve this query on the host
-      row.resize((size_t)n_items);
-      HIPCHK(h, hipMemcpy(row.data(), d_scores + (size_t)q * (size_t)n_items, sizeof(float) * (size_t)n_items, hipMemcpyDeviceToHost));
-      const uint32_t ninf = score_key(-std::numeric_limits<float>::infinity());
-      for (int64_t i = 0; i < n_items; ++i) {
-        const uint32_t kk = score_key(row[(size_t)i]);
-        if (kk > ninf && kk >= st[(size_t)q].prefix) cand.push_back({kk, i});
-      }
-    } else {
-      for (uint32_t p = 0; p < above; ++p) cand.push_back({o[2 * p + 1], (int64_t)o[2 * p]});
-      for (uint32_t p = 0; p < ties_stored; ++p) cand.push_back({o[2 * (how_many + p) + 1], (int64_t)o[2 * (how_many + p)]});
-    }
-    topn_emit(cand, how_many, item_idx_out + (size_t)q * how_many, score_out + (size_t)q * how_many, n_out ? n_out + q : nullptr);
-  }
-  return MALS_OK;
-}
-
-// Filter path (large catalogues): score rows are never materialised.  A 1/16 sample of the items
-// (every 16th 16-item tile) is scored and radix-selected exactly like above: its N-th best score is a
-// lower bound of the true N-th best.  One pass over all of Y then appends only the (item, score)
-// pairs that reach that bound -- about 16 N of them -- and the host sorts those.  Every item scoring
-// at least the true N-th best is in the list, so the result (ties included) is exact.  *done = false
-// when a candidate list overflowed or the sample was too thin: the caller takes the full path.
-int topn_batch_filter(mals_handle h, const float* dQ, const int64_t* d_query_row, const int64_t* d_excl_ptr, const int64_t* d_excl_idx,
-                      int nq, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out, bool* done) {
-  *done = false;
-  SideState& y = h->side[MALS_SIDE_Y];
-  SideState& x = h->side[MALS_SIDE_X];
-  const int64_t n_items = y.n_total;
-  const int stride = 16;
-  const int64_t n_sample = ((n_items + 16 * stride - 1) / (16 * stride)) * 16;
-  const int cap = 48 * how_many + 2048;  // expected ~16 N candidates; the buffer is (how_many + cap_ties) pairs per query
-  if (int rc = topn_workspace(h, n_items, how_many, cap - how_many)) return rc;
-  float* d_scores = h->tn_scores;
-  uint32_t* d_cand = h->tn_out;
-  TopnState* d_st = (TopnState*)h->tn_state;
-  if (int rc = launch_topn_scores<0>(h, y.F, n_items, dQ, nq, stride, n_sample, d_scores, d_st, 0, nullptr)) return rc;
-  if (d_query_row) hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, nq, stride, n_sample, d_scores);
-  if (d_excl_ptr) hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, d_excl_ptr, d_excl_idx, nq, n_items, stride, n_sample, d_scores);
-  unsigned slabs = 1;
-  if (int rc = topn_select_threshold(h, d_scores, n_sample, nq, how_many, d_st, h->tn_hist, &slabs)) return rc;
-  // st[q].prefix now is the sample's N-th best key (st[q].above still 0: it becomes the candidate counter)
-  if (int rc = launch_topn_scores<1>(h, y.F, n_items, dQ, nq, 1, n_items, nullptr, d_st, cap, d_cand)) return rc;
-  if (d_query_row || d_excl_ptr)
-    hipLaunchKernelGGL(topn_strike_kernel, dim3(16, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, d_query_row, d_excl_ptr, d_excl_idx, nq,
-                       d_st, cap, d_cand);
-  HIPCHK(h, hipGetLastError());
-  uint32_t* out = h->tn_host;
-  TopnState* st = reinterpret_cast<TopnState*>(h->tn_host + (size_t)TOPN_MAX_QUERIES * 2 * (size_t)cap);
-  HIPCHK(h, hipMemcpyAsync(st, d_st, sizeof(TopnState) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(out, d_cand, sizeof(uint32_t) * (size_t)nq * 2 * (size_t)cap, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  const uint32_t ninf = score_key(-std::numeric_limits<float>::infinity());
-  for (int q = 0; q < nq; ++q)
-    if (st[(size_t)q].above > (uint32_t)cap || st[(size_t)q].prefix <= ninf || st[(size_t)q].remaining > 0x7fffffffu) return MALS_OK;  // overflow / thin sample
-  std::vector<TopnCand> cand;
-  for (int q = 0; q < nq; ++q) {
-    cand.clear();
-    const uint32_t* o = &out[(size_t)q * 2 * (size_t)cap];
-    int valid = 0;
-    for (uint32_t p = 0; p < st[(size_t)q].above; ++p)
-      if (o[2 * p + 1] > ninf) {
-        cand.push_back({o[2 * p + 1], (int64_t)o[2 * p]});
-        ++valid;
-      }
-    if (valid < how_many) return MALS_OK;  // cannot happen with a valid bound; be safe and let the full path answer
-    topn_emit(cand, how_many, item_idx_out + (size_t)q * how_many, score_out + (size_t)q * how_many, n_out ? n_out + q : nullptr);
-  }
-  *done = true;
-  return MALS_OK;
-}
-
-int topn_batch(mals_handle h, const float* dQ, const int64_t* d_query_row, const int64_t* d_excl_ptr, const int64_t* d_excl_idx,
-               int nq, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
-  const int64_t n_items = h->side[MALS_SIDE_Y].n_total;
-  // the sample must hold comfortably more than how_many candidates for its N-th best to be a useful bound
-  if (n_items >= 65536 && n_items / 16 >= 64 * (int64_t)how_many && !std::getenv("MALS_TOPN_FULL")) {
-    bool done = false;
-    if (int rc = topn_batch_filter(h, dQ, d_query_row, d_excl_ptr, d_excl_idx, nq, how_many, item_idx_out, score_out, n_out, &done)) return rc;
-    if (done) return MALS_OK;
-  }
-  return topn_batch_full(h, dQ, d_query_row, d_excl_ptr, d_excl_idx, nq, how_many, item_idx_out, score_out, n_out);
-}
+#include "topn_host.h"
 }  // namespace
 
 // ================================================================================================
@@ -1652,13 +1423,7 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_rows);
   free_dev(h->d_sd);
   free_dev(h->d_sd_idx);
-  free_dev(h->tn_scores);
-  free_dev(h->tn_out);
-  free_dev(h->tn_state);
-  free_dev(h->tn_hist);
-  free_dev(h->tn_q);
-  free_dev(h->tn_qidx);
-  if (h->tn_host) (void)hipHostFree(h->tn_host);
+  topn_free(h);
   delete h;
   return MALS_OK;
 }
@@ -2655,66 +2420,53 @@ int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, in
       return fail(h, MALS_INVALID_ARG, "known items of this user are not on this handle (row outside the local shard)");
   }
   if (int rc = use_device(h)) return rc;
-  const int k = h->cfg.features;
-  for (int q0 = 0; q0 < n_queries; q0 += TOPN_MAX_QUERIES) {
-    const int nq = std::min(TOPN_MAX_QUERIES, n_queries - q0);
-    if (!h->tn_q) HIPCHK(h, hipMalloc(&h->tn_q, sizeof(float) * TOPN_MAX_QUERIES * 128));
-    if (!h->tn_qidx) HIPCHK(h, hipMalloc(&h->tn_qidx, sizeof(int64_t) * 2 * TOPN_MAX_QUERIES));
-    float* dQ = h->tn_q;
-    int64_t *d_idx = h->tn_qidx, *d_row = h->tn_qidx + TOPN_MAX_QUERIES;
-    std::vector<int64_t> rows((size_t)nq);
-    for (int q = 0; q < nq; ++q) rows[(size_t)q] = consider_known_items ? -1 : user_idx[q0 + q] - x.row_offset;
-    hipError_t e = hipMemcpyAsync(d_idx, user_idx + q0, sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_row, rows.data(), sizeof(int64_t) * (size_t)nq, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nq * k + 255) / 256)), dim3(256), 0, h->stream, x.F, d_idx, nq, k, dQ);
-      e = hipGetLastError();
-    }
-    int rc = e == hipSuccess ? MALS_OK : fail(h, MALS_HIP_ERROR, hipGetErrorString(e));
-    if (rc == MALS_OK)
-      rc = topn_batch(h, dQ, d_row, nullptr, nullptr, nq, how_many, item_idx_out + (size_t)q0 * how_many, score_out + (size_t)q0 * how_many,
-                      n_out ? n_out + q0 : nullptr);
-    if (rc != MALS_OK) return rc;
-  }
-  return MALS_OK;
+  TopnRequest rq;
+  rq.n_queries = n_queries;
+  rq.how_many = how_many;
+  rq.user_idx = user_idx;
+  rq.skip_known = !consider_known_items;
+  rq.item_idx_out = item_idx_out;
+  rq.score_out = score_out;
+  rq.n_out = n_out;
+  return topn_run(h, rq);
 }
 
-int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_queries, int32_t how_many,
+int mals_recommend_to_many(mals_handle h, const float* vectors, const int64_t* vector_ptr, int32_t n_queries, int32_t how_many,
                            const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
                            int32_t* n_out) {
   if (!h) return MALS_INVALID_ARG;
   SideState& y = h->side[MALS_SIDE_Y];
   if (!y.F || y.n_total == 0) return fail(h, MALS_INVALID_ARG, "item factor replica not available");
-  if (n_queries < 0 || how_many <= 0 || how_many > 4096 || (n_queries > 0 && (!query_vectors || !item_idx_out || !score_out)))
+  if (n_queries < 0 || how_many <= 0 || how_many > 4096 || (n_queries > 0 && (!vectors || !item_idx_out || !score_out)))
     return fail(h, MALS_INVALID_ARG, "bad recommend arguments (how_many in 1..4096)");
   if ((exclude_ptr == nullptr) != (exclude_idx == nullptr) && exclude_ptr && exclude_ptr[n_queries] > 0)
     return fail(h, MALS_INVALID_ARG, "exclude_ptr and exclude_idx go together");
-  if (int rc = use_device(h)) return rc;
-  const int k = h->cfg.features;
-  for (int q0 = 0; q0 < n_queries; q0 += TOPN_MAX_QUERIES) {
-    const int nq = std::min(TOPN_MAX_QUERIES, n_queries - q0);
-    if (!h->tn_q) HIPCHK(h, hipMalloc(&h->tn_q, sizeof(float) * TOPN_MAX_QUERIES * 128));
-    float* dQ = h->tn_q;
-    int64_t *d_ptr = nullptr, *d_ex = nullptr;
-    hipError_t e = hipMemcpyAsync(dQ, query_vectors + (size_t)q0 * k, sizeof(float) * (size_t)nq * k, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess && exclude_ptr) {
-      std::vector<int64_t> ptr((size_t)nq + 1);
-      for (int q = 0; q <= nq; ++q) ptr[(size_t)q] = exclude_ptr[q0 + q] - exclude_ptr[q0];
-      const int64_t n_ex = ptr[(size_t)nq];
-      e = hipMalloc(&d_ptr, sizeof(int64_t) * ((size_t)nq + 1));
-      if (e == hipSuccess) e = hipMalloc(&d_ex, sizeof(int64_t) * (size_t)std::max<int64_t>(n_ex, 1));
-      if (e == hipSuccess) e = hipMemcpy(d_ptr, ptr.data(), sizeof(int64_t) * ((size_t)nq + 1), hipMemcpyHostToDevice);
-      if (e == hipSuccess && n_ex) e = hipMemcpy(d_ex, exclude_idx + exclude_ptr[q0], sizeof(int64_t) * (size_t)n_ex, hipMemcpyHostToDevice);
+  if (vector_ptr) {
+    if (vector_ptr[0] != 0) return fail(h, MALS_INVALID_ARG, "vector_ptr[0] must be 0");
+    for (int q = 0; q < n_queries; ++q) {
+      const int64_t n = vector_ptr[q + 1] - vector_ptr[q];
+      if (n < 1) return fail(h, MALS_INVALID_ARG, "features must not be empty");  // RecommendIterator.java:52
+      if (n > (1 << 20)) return fail(h, MALS_INVALID_ARG, "too many vectors in one query");
     }
-    int rc = e == hipSuccess ? MALS_OK : fail(h, MALS_HIP_ERROR, hipGetErrorString(e));
-    if (rc == MALS_OK)
-      rc = topn_batch(h, dQ, nullptr, d_ptr, d_ex, nq, how_many, item_idx_out + (size_t)q0 * how_many, score_out + (size_t)q0 * how_many,
-                      n_out ? n_out + q0 : nullptr);
-    if (d_ptr) (void)hipFree(d_ptr);
-    if (d_ex) (void)hipFree(d_ex);
-    if (rc != MALS_OK) return rc;
   }
-  return MALS_OK;
+  if (int rc = use_device(h)) return rc;
+  TopnRequest rq;
+  rq.n_queries = n_queries;
+  rq.how_many = how_many;
+  rq.vectors = vectors;
+  rq.vec_ptr = vector_ptr;
+  rq.excl_ptr = exclude_ptr;
+  rq.excl_idx = exclude_idx;
+  rq.item_idx_out = item_idx_out;
+  rq.score_out = score_out;
+  rq.n_out = n_out;
+  return topn_run(h, rq);
+}
+
+int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_queries, int32_t how_many,
+                           const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
+                           int32_t* n_out) {
+  return mals_recommend_to_many(h, query_vectors, nullptr, n_queries, how_many, exclude_ptr, exclude_idx, item_idx_out, score_out, n_out);
 }
 
 int mals_symmetric_eigen(const double* A, int32_t n, double* evals_out, double* V_out) {

@@ -1,23 +1,48 @@
 // topn_kernels.h -- hand-written gfx950 kernels of top-N scoring: what
-// ServerRecommender.multithreadedTopN (online/src/net/myrrix/online/ServerRecommender.java:443-508)
-// does with RecommendIterator (RecommendIterator.java:62-109) and TopN (common/.../TopN.java:49-128):
-// score every item against the query vector, skip the user's known items, keep the N best.
+// ServerRecommender.multithreadedTopN (online/src/net/myrrix/online/ServerRecommender.java:443-508) does with
+// RecommendIterator (online/.../RecommendIterator.java:62-109) and TopN (common/src/net/myrrix/common/TopN.java:
+// 49-128): score every item against the query's vector(s), skip the known items, keep the N best.
 //
-//   scores   fp64 matrix cores, 16 items x 16 queries x 4 features per instruction; all queries of
-//            the batch are scored per item read, so Y is streamed once per batch: HBM-bound
-//            (n_items * 4k bytes).  fp64 accumulation like the reference's dot
-//            (SimpleVectorMath.java:34-41), cast to fp32 at the end.
-//   mask     known items of each query's user -> -inf (RecommendIterator.java:75-82).
-//   select   4-pass radix select (8-bit digits of an order-preserving integer image of the score,
-//            grid-wide histograms per query) finds the N-th largest score exactly, then everything
-//            above it plus the ties are handed back; no sort of the whole row.
+// The score of item i for a query with vectors f_1..f_n IS the reference's (RecommendIterator.java:93-104):
+//     (float)( (dot(Y_i, f_1) + ... + dot(Y_i, f_n)) / n ),   dot = SimpleVectorMath.dot (SVM:34-41): every product
+//     rounded to fp32, summed in fp64 in feature order
+// computed by topn_exact_* below with exactly those operations, so scores and -- with ties in ascending item index --
+// indices are bit-identical to the oracle's.  What makes that affordable on a million items is a FILTER in front:
+//   1. sample     every `stride`-th 16-item tile is scored approximately against all queries of the pass on
+//                 v_mfma_f32_16x16x32_bf16 (item rows split into two bf16 halves, query vectors one bf16), fp32
+//                 accumulate.  |approx - exact| <= 2^-8 |x| |y_i| (bound below), so lb_i = approx - margin_i is a
+//                 LOWER bound of the exact score.  Known items are masked out.
+//   2. threshold  per query tau = (a lower estimate of) the N-th largest lb of the sample: at least N unmasked items
+//                 score >= tau exactly, hence the exact N-th best score is >= tau.
+//   3. filter     ALL items streamed once per pass (Y is read once for up to 256 queries: HBM-bound, n_items * 4k
+//                 bytes), same approximate score; item i is a candidate of query q iff approx + margin_i >= tau_q --
+//                 a superset of {i: exact score >= tau_q}, which contains the exact top N with all its ties.
+//   4. rescore    exact reference arithmetic on the candidates only (a few hundred per query), known items struck.
+//   5. final      per query the N largest (score key, ~index) pairs: the N best, ties by ascending index.
+// Nothing approximate reaches the output; if a query's candidates overflow their buffer, or its sample holds fewer than
+// N unmasked items, the pass is answered by the dense path: exact scores of every item (topn_exact_dense_kernel), known
+// items masked, 4-pass radix select of the N-th best, everything above it plus the ties sorted on the host.
+//
+// Error bound of the approximate score.  The item rows enter split, y = hi + lo + r with hi = bf16(y), lo = bf16(y - hi),
+// |r| <= 2^-18 |y|; the query vector enters as one bf16, x = xh + e, |e| <= 2^-9 |x|.  approx = sum (hi + lo) xh on
+// v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulate): |approx - sum x y| <= (2^-9 + 2^-18) sum |x_f y_f| plus the
+// accumulation of <= 128 terms (2^-17 of it); the reference's own roundings (fp32 products, final cast) are <= 2^-23 of
+// it.  In total < 2^-8.9 sum |x_f y_f| <= 2^-8.9 |x|_2 |y_i|_2 (Cauchy-Schwarz); the kernels use 2^-8, round both
+// factors of the margin UP to bf16, and add an absolute floor for the subnormal range.  For a query of n vectors the
+// filter vector is their mean and |x| is the mean of their norms (an upper bound of the norm of the mean, and of the
+// per-vector error sum).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mals {
 
-constexpr int TOPN_MAX_QUERIES = 64;  // queries scored per item read (x vectors staged in LDS)
+constexpr int TOPN_MAX_QUERIES = 64;      // dense path: queries per pass
+constexpr int TOPN_FILTER_QUERIES = 256;  // filter path: queries scored per read of Y
+constexpr int TOPN_FILTER_MAX_N = 64;     // largest how_many the filter path takes (the candidates of a query sit in LDS)
+constexpr float TOPN_MARGIN = 0.00390625f;  // 2^-8
+constexpr float TOPN_MARGIN_FLOOR = 1e-30f;
+constexpr int TOPN_COUNT_STRIDE = 32;  // candidate counters one per 128-byte line: atomics on one LINE serialise in L2 (97 us per pass when packed)
 
 // fp32 -> uint32 with the same order (NaN sorts above +inf; the scores here are finite or -inf)
 __device__ __host__ __forceinline__ uint32_t score_key(float f) {
@@ -25,109 +50,276 @@ __device__ __host__ __forceinline__ uint32_t score_key(float f) {
   __builtin_memcpy(&u, &f, 4);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __host__ __forceinline__ float key_score(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
 
-// Scores on the fp64 matrix cores: D[item][query] += A[item][feature] * B[feature][query] with
-// v_mfma_f64_16x16x4_f64 -- 16 items x 16 queries x 4 features per instruction, operands widened
-// from fp32 (their product is exact in fp64), fp64 accumulation, one cast to fp32 at the end.  The
-// reference rounds each product to fp32 before it widens (SimpleVectorMath.java:37); the difference
-// is below half an fp32 ulp of the score, so a score can differ from the reference's in its last bit
-// (tests compare at 2 ulp).  A wave owns 16 consecutive items and all query tiles; the queries sit
-// in LDS as doubles in operand order.  Y is read once per batch: HBM-bound (n_items * 4k bytes).
-typedef double f64x4_t __attribute__((ext_vector_type(4)));
-struct TopnState {
-  uint32_t prefix;     // digits decided so far (in place, high bits); after 4 passes the N-th best key
-  uint32_t remaining;  // rank of the N-th score inside the candidates that match the prefix
-  uint32_t above;      // collected: scores strictly above the N-th (filter path: all candidates)
-  uint32_t ties;       // collected: scores equal to the N-th (all of them counted, cap_ties stored)
-};
-__device__ __forceinline__ uint32_t topn_threshold(const TopnState* st, int q) { return st[q].prefix; }
-__device__ __forceinline__ unsigned topn_append(TopnState* st, int q) { return atomicAdd(&st[q].above, 1u); }
-__device__ __forceinline__ unsigned topn_count(const TopnState* st, int q) { return st[q].above; }
-
-// MODE 0: dense score rows for the 16-item tiles whose index is a multiple of tile_stride
-//         (1 = every item; 16 = the 1/16 sample that yields the filter thresholds), row length n_out;
-// MODE 1: filter -- only (item, score) pairs whose score reaches the query's threshold key are
-//         appended to the query's candidate list (st[q].above counts them, also past the capacity).
-// NT = query tiles of 16 (compile time: the MFMA block below is straight-line code; a wave-uniform
-// runtime test per MFMA made the fully unrolled kernel 2x slower).
-template <int T, int MODE, int NT>
-__global__ __launch_bounds__(256) void topn_scores_kernel(const float* __restrict__ Y, int64_t n_items, int k,
-                                                          const float* __restrict__ Q, int n_queries, int tile_stride,
-                                                          int64_t n_out, float* __restrict__ scores,  // MODE 0: [n_queries][n_out]
-                                                          TopnState* __restrict__ st, int cap, uint32_t* __restrict__ cand) {
-  constexpr int KP = 16 * T;                                  // padded feature count
-  __shared__ double sq[NT * KP * 16];                          // [query tile][feature][query in tile]
-  constexpr int n_tiles = NT;
-  for (int i = threadIdx.x; i < n_tiles * KP * 16; i += 256) {
-    const int j = i & 15, f = (i >> 4) % KP, qt = i / (16 * KP);
-    const int q = 16 * qt + j;
-    sq[i] = (q < n_queries && f < k) ? (double)Q[(int64_t)q * k + f] : 0.0;
+// ---- the reference's arithmetic ----------------------------------------------------------------------------------
+// SimpleVectorMath.dot (SVM:34-41)
+__device__ __forceinline__ double topn_ref_dot(const float* __restrict__ y, const float* __restrict__ x, int k) {
+  double d = 0.0;
+  for (int f = 0; f < k; ++f) d += (double)__fmul_rn(y[f], x[f]);
+  return d;
+}
+// RecommendIterator.java:93-104 for the vectors [v0, v1) of `vecs`
+__device__ __forceinline__ float topn_ref_score(const float* __restrict__ y, const float* __restrict__ vecs, int v0, int v1, int k) {
+  double sum = 0.0;
+  int count = 0;
+  for (int v = v0; v < v1; ++v) {
+    sum += topn_ref_dot(y, vecs + (int64_t)v * k, k);
+    ++count;
   }
-  __shared__ uint32_t sthr[TOPN_MAX_QUERIES];
-  if (MODE == 1 && threadIdx.x < TOPN_MAX_QUERIES) sthr[threadIdx.x] = threadIdx.x < n_queries ? topn_threshold(st, threadIdx.x) : 0xffffffffu;
+  return (float)(sum / (double)count);
+}
+
+// per query: the filter vector (mean of its vectors, fp32) and the norm that scales the margin (mean of their norms,
+// rounded up).  One workgroup of 128 threads per query.
+__global__ __launch_bounds__(128) void topn_prepare_kernel(const float* __restrict__ vecs, const int32_t* __restrict__ vptr, int k,
+                                                           float* __restrict__ xbar, float* __restrict__ mnorm) {
+  const int q = blockIdx.x, v0 = vptr[q], v1 = vptr[q + 1], n = v1 - v0;
+  const int f = threadIdx.x;
+  double mean = 0.0;
+  if (f < k) {
+    for (int v = v0; v < v1; ++v) mean += (double)vecs[(int64_t)v * k + f];
+    xbar[(int64_t)q * k + f] = n ? (float)(mean / n) : 0.f;
+  }
+  __shared__ double red[128];
+  double norms = 0.0;
+  for (int v = v0; v < v1; ++v) {
+    const double x = f < k ? (double)vecs[(int64_t)v * k + f] : 0.0;
+    red[f] = x * x;
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+      if (f < s) red[f] += red[f + s];
+      __syncthreads();
+    }
+    norms += sqrt(red[0]);
+    __syncthreads();
+  }
+  if (f == 0) mnorm[q] = n ? (float)(norms / n * 1.000001) : 0.f;
+}
+
+// ---- approximate scores on the bf16 matrix pipe -----------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+
+// position of an item in a score row that holds every tile_stride-th 16-item tile (-1: not in it)
+__device__ __forceinline__ int64_t topn_row_slot(int64_t item, int tile_stride) {
+  const int64_t tile = item >> 4;
+  return tile % tile_stride ? -1 : (tile / tile_stride) * 16 + (item & 15);
+}
+
+// bf16 >= v (v finite): the margin operands are rounded toward +infinity, so that what the matrix pipe adds is never
+// less than the bound asks for
+__device__ __forceinline__ __bf16 bf16_up(float v) {
+  uint32_t u = __float_as_uint(v);
+  if (!(u & 0x80000000u)) u += 0xffffu;  // positive: up = away from zero; negative: truncation is already up
+  const uint16_t h = (uint16_t)(u >> 16);
+  return __builtin_bit_cast(__bf16, h);
+}
+
+// The queries of a pass as MFMA B operands in the order the filter kernel's LDS wants them: per query tile t, S + 1
+// entries of 64 lanes x 8 bf16:
+//   entry s < S : lane (g, c) = bf16(xbar[query 16 t + c][features 8 S g + 8 s + 0..7])
+//   entry S     : the "margin step": lane (0, c) = {2^-8 |x_q| rounded up, floor, 0 (-tau hi), 0 (-tau lo), 0...}; the
+//                 filter kernel fills the tau slots once the thresholds are known.  Its A operand is {|y_i|, 1, 1, 1, 0..}
+//                 so one more MFMA adds margin_i - tau_q to every accumulator.
+// Built once per pass (grid = NT workgroups of 64 lanes); every filter workgroup copies it with 16-byte loads.
+__global__ __launch_bounds__(64) void topn_image_kernel(const float* __restrict__ xbar, const float* __restrict__ mnorm, int n_queries, int k,
+                                                        int S, bf16x8* __restrict__ img) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int g = lane >> 4, q = 16 * t + (lane & 15);
+  for (int s = 0; s < S; ++s) {
+    bf16x8 hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int f = 8 * S * g + 8 * s + j;
+      hi[j] = (__bf16)((q < n_queries && f < k) ? xbar[(int64_t)q * k + f] : 0.f);
+    }
+    img[(t * (S + 1) + s) * 64 + lane] = hi;
+  }
+  bf16x8 m;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = (__bf16)0.f;
+  if (g == 0) {
+    if (q < n_queries) {
+      m[0] = bf16_up(TOPN_MARGIN * mnorm[q]);
+      m[1] = bf16_up(TOPN_MARGIN_FLOOR);
+    } else {
+      m[2] = (__bf16)(-1e30f);  // a padding query never has a candidate
+    }
+  }
+  img[(t * (S + 1) + S) * 64 + lane] = m;
+}
+
+// S = contraction steps of 32 features (features padded to 32 S); NT = query tiles of 16 per workgroup; the workgroup's
+// query tiles are [NT blockIdx.y, NT blockIdx.y + NT).
+// MODE 0: sample -- lower bounds (approx - margin) of every tile_stride-th tile into lb[q][slot], row length n_out;
+// MODE 1: filter -- (item i, query q) is a hit iff approx + margin_i - tau_q >= 0.  Hits go to a list PRIVATE to the
+//         wave (wave_hits[wave][..], wave_count[wave] counts them, also past wave_cap): positions come from a ballot, not
+//         from an atomic -- a returning atomic in this loop waits on the same counter as the prefetched rows, and with
+//         240 queries nearly every tile has a hit (measured: 284 us per pass with atomics).  topn_scatter_kernel
+//         sorts the hits into per-query candidate lists afterwards.
+// A wave owns U 16-item tiles at a time (U = 2 in MODE 1: every B operand fetched from LDS serves both): lane (g, c)
+// reads the contiguous quarter [8 S g, 8 S (g + 1)) of item c's row (the order of the features inside the contraction
+// is free); MFMA step s contracts features 8 S g + 8 s + j.  The item rows are split (hi + lo, 16 bits), the queries are
+// not (8 bits): |approx - exact| <= 2^-9 sum |x y|, the margin uses 2^-8.  The grid is persistent (as many workgroups as
+// fit the chip at once): the LDS image is loaded once per workgroup.
+template <int S, int NT, int MODE, bool ALIGNED>
+__global__ __launch_bounds__(256) void topn_filter_kernel(const float* __restrict__ Y, int64_t n_items, int k,
+                                                          const bf16x8* __restrict__ img, int n_queries,
+                                                          int tile_stride, int64_t n_out, float* __restrict__ lb,
+                                                          const float* __restrict__ tau, int wave_cap, unsigned* __restrict__ wave_count,
+                                                          uint2* __restrict__ wave_hits) {
+  constexpr int CH = 8 * S;  // features per lane
+  constexpr int U = MODE == 1 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  bf16x8* bq = reinterpret_cast<bf16x8*>(smem);  // [NT][S + 1][64 lanes]
+  const int t_base = NT * blockIdx.y;
+  for (int i = threadIdx.x; i < NT * (S + 1) * 64; i += 256) bq[i] = img[(int64_t)t_base * (S + 1) * 64 + i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, kk = lane >> 4, c = lane & 15;
+  if (MODE == 1) {  // -tau_q = hi + lo (lo rounded up) into slots 2, 3 of the margin entries
+    for (int i = threadIdx.x; i < NT * 16; i += 256) {
+      const int q = 16 * t_base + i;
+      if (q < n_queries) {
+        const float tq = tau[q];
+        float v = -tq;
+        if (!(tq > -__builtin_huge_valf())) v = 1e30f;  // no threshold: everything is a candidate (the pass falls back)
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = bf16_up(v - (float)hi);
+        bf16x8 m = bq[((i >> 4) * (S + 1) + S) * 64 + (i & 15)];
+        m[2] = hi;
+        m[3] = lo;
+        bq[((i >> 4) * (S + 1) + S) * 64 + (i & 15)] = m;
+      }
+    }
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-  const int64_t step = (int64_t)tile_stride * 16;             // items between processed tiles
-  // The order of the features inside the contraction is free (it only moves fp64 rounding), so lane
-  // (kk, c) takes the CONTIGUOUS quarter [kk*4T, (kk+1)*4T) of item c's row: at k = 64 exactly one
-  // 64-byte line per lane, read with T 16-byte loads.  MFMA step s contracts feature kk*4T + s.
-  constexpr int CH = 4 * T;
+  const int64_t step = (int64_t)tile_stride * 16;  // items between consecutive processed tiles
+  // ALIGNED (k == 32 S): four-float loads.  Otherwise one load per feature, the index clamped into the row: the padding
+  // features meet zeros in the query operand, so what they hold does not matter -- and nothing here may branch on or
+  // touch a loaded value (a wait for the loads would turn the prefetch into a plain load).
   auto load_rows16 = [&](int64_t i0, float (&yv)[CH]) {
     const int64_t item = i0 + c;
-    const bool ok = item < n_items;
-    const float* y = Y + (ok ? item : 0) * k + kk * CH;
-    if (k == KP) {
-      const float4* y4 = reinterpret_cast<const float4*>(y);
+    const float* row = Y + (item < n_items ? item : 0) * k;  // rows past the end read row 0; dropped in the epilogue
+    if (ALIGNED) {
+      const float4* y4 = reinterpret_cast<const float4*>(row + g * CH);
 #pragma unroll
-      for (int v = 0; v < T; ++v) {
+      for (int v = 0; v < CH / 4; ++v) {
         const float4 t4 = y4[v];
         yv[4 * v] = t4.x; yv[4 * v + 1] = t4.y; yv[4 * v + 2] = t4.z; yv[4 * v + 3] = t4.w;
       }
     } else {
 #pragma unroll
-      for (int s = 0; s < CH; ++s) yv[s] = kk * CH + s < k ? y[s] : 0.f;
-    }
-  };
-  float ynext[CH];
-  if (wave * step < n_items) load_rows16(wave * step, ynext);
-  for (int64_t i0 = wave * step; i0 < n_items; i0 += n_waves * step) {
-    const bool ok = i0 + c < n_items;
-    float yv[CH];
-#pragma unroll
-    for (int s = 0; s < CH; ++s) yv[s] = ynext[s];
-    if (i0 + n_waves * step < n_items) load_rows16(i0 + n_waves * step, ynext);  // next tile's rows fly during the MFMAs
-    f64x4_t acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f64x4_t{0., 0., 0., 0.};
-#pragma unroll
-    for (int s = 0; s < CH; ++s) {
-      const double a = ok ? (double)yv[s] : 0.0;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const double b = sq[(t * KP + kk * CH + s) * 16 + c];  // lane (kk, c) = feature kk*4T+s, query c
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      for (int s = 0; s < CH; ++s) {
+        const int f = g * CH + s;
+        yv[s] = row[f < k ? f : k - 1];
       }
     }
-    // D layout: lane (g = lane>>4, c) reg r = D[row = g + 4r][col = c]: item i0+g+4r, query 16t+c
+  };
+  // wave w takes tile groups w, w + n_waves, ...; group j = tiles U j .. U j + U - 1 (of the processed tiles)
+  const int64_t n_proc = (n_items + step - 1) / step;       // processed tiles
+  const int64_t n_groups = (n_proc + U - 1) / U;
+  unsigned n_hits = 0;  // wave-uniform
+  uint2* my_hits = MODE == 1 ? wave_hits + wave * (int64_t)wave_cap : nullptr;
+  float ynext[U][CH];
+  if (wave < n_groups)
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_rows16((wave * U + u) * step, ynext[u]);
+  for (int64_t grp = wave; grp < n_groups; grp += n_waves) {
+    float yv[U][CH];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int s = 0; s < CH; ++s) yv[u][s] = ynext[u][s];
+    if (grp + n_waves < n_groups)
+#pragma unroll
+      for (int u = 0; u < U; ++u) load_rows16(((grp + n_waves) * U + u) * step, ynext[u]);  // the next rows fly during the MFMAs
+    bf16x8 ah[U][S], al[U][S], am[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // |y_c| of the tile's 16 items: this lane's quarter, then the other three
+      float nsq = 0.f;
+#pragma unroll
+      for (int s = 0; s < CH; ++s)
+        if (ALIGNED || g * CH + s < k) nsq = __builtin_fmaf(yv[u][s], yv[u][s], nsq);
+      nsq += __shfl_xor(nsq, 16);
+      nsq += __shfl_xor(nsq, 32);
+      const float ny = __builtin_sqrtf(nsq) * 1.0000005f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) am[u][j] = (__bf16)0.f;
+      if (g == 0) {
+        const float sgn = MODE == 0 ? -1.f : 1.f;  // the sample wants approx - margin
+        am[u][0] = MODE == 0 ? (__bf16)(-(float)bf16_up(ny)) : bf16_up(ny);
+        am[u][1] = (__bf16)sgn;
+        am[u][2] = (__bf16)1.f;
+        am[u][3] = (__bf16)1.f;
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = yv[u][8 * s + j];
+          const __bf16 h = (__bf16)v;
+          ah[u][s][j] = h;
+          al[u][s][j] = (__bf16)(v - (float)h);
+        }
+    }
+    f32x4t acc[U][NT];
+    bf16x8 b = bq[lane];  // the operand of step (t = 0, s = 0); the next one is fetched while this one is multiplied
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int q = 16 * t + c;
-      if (q < n_queries) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int64_t it = i0 + kk + 4 * r;
-          if (it >= n_items) continue;
-          const float sc = (float)acc[t][r];                  // RecommendIterator.java:104
-          if (MODE == 0) {
-            scores[(int64_t)q * n_out + (i0 / step) * 16 + kk + 4 * r] = sc;
+      for (int u = 0; u < U; ++u) acc[u][t] = f32x4t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s <= S; ++s) {
+        const int nxt = t * (S + 1) + s + 1;
+        const bf16x8 bn = bq[(nxt < NT * (S + 1) ? nxt : 0) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (s < S) {
+            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][s], b, acc[u][t], 0, 0, 0);
+            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u][s], b, acc[u][t], 0, 0, 0);
           } else {
-            const uint32_t key = score_key(sc);
-            if (key >= sthr[q]) {
-              const unsigned p = topn_append(st, q);
-              if ((int)p < cap) {
-                cand[((int64_t)q * cap + p) * 2] = (uint32_t)it;
-                cand[((int64_t)q * cap + p) * 2 + 1] = key;
+            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[u], b, acc[u][t], 0, 0, 0);
+          }
+        }
+        b = bn;
+      }
+    }
+    // D layout: lane (g, c) register r = D[row 4 g + r][col c]: item 4 g + r of the tile, query 16 (t_base + t) + c
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i0 = (grp * U + u) * step;
+      if (i0 >= n_items) continue;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int q = 16 * (t_base + t) + c;
+        if (MODE == 0) {
+          if (q < n_queries) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (i0 + 4 * g + r < n_items) lb[(int64_t)q * n_out + (grp * U + u) * 16 + 4 * g + r] = acc[u][t][r];
+          }
+        } else {
+          // a candidate is an accumulator that is not negative: one test per wave and query tile, the rare hits inside
+          const uint32_t all_neg = __float_as_uint(acc[u][t][0]) & __float_as_uint(acc[u][t][1]) & __float_as_uint(acc[u][t][2]) &
+                                   __float_as_uint(acc[u][t][3]);
+          if (__ballot(!(all_neg >> 31))) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int64_t it = i0 + 4 * g + r;
+              const bool hit = !(acc[u][t][r] < 0.f) && it < n_items && q < n_queries;  // a NaN (overflow of the approximation) is a hit too
+              const uint64_t hm = __ballot(hit);
+              if (hm) {
+                const unsigned at = n_hits + (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
+                if (hit && at < (unsigned)wave_cap) my_hits[at] = make_uint2((uint32_t)it, (uint32_t)q);
+                n_hits += (unsigned)__popcll(hm);
               }
             }
           }
@@ -135,14 +327,29 @@ __global__ __launch_bounds__(256) void topn_scores_kernel(const float* __restric
       }
     }
   }
+  if (MODE == 1 && lane == 0) wave_count[wave] = n_hits;
+}
+
+// the waves' hit lists -> per-query candidate lists (count[q] counts them, also past cap).  One thread per hit slot;
+// here a returning atomic costs nothing else its latency.
+__global__ __launch_bounds__(256) void topn_scatter_kernel(const unsigned* __restrict__ wave_count, const uint2* __restrict__ wave_hits,
+                                                           int wave_cap, int n_waves, int cap, unsigned* __restrict__ count,
+                                                           uint32_t* __restrict__ cand, unsigned* __restrict__ overflow) {
+  const int w = blockIdx.x;
+  if (w >= n_waves) return;
+  const unsigned n = wave_count[w];
+  if (n > (unsigned)wave_cap) {
+    if (threadIdx.x == 0) atomicAdd(overflow, 1u);
+    return;
+  }
+  for (unsigned i = threadIdx.x; i < n; i += 256) {
+    const uint2 hq = wave_hits[(int64_t)w * wave_cap + i];
+    const unsigned p = atomicAdd(&count[(size_t)hq.y * TOPN_COUNT_STRIDE], 1u);
+    if ((int)p < cap) cand[(int64_t)hq.y * cap + p] = hq.x;
+  }
 }
 
 // known items of the query's user are never recommended (RecommendIterator.java:75-82)
-// position of an item in a score row that holds every tile_stride-th 16-item tile (-1: not in it)
-__device__ __forceinline__ int64_t topn_row_slot(int64_t item, int tile_stride) {
-  const int64_t tile = item >> 4;
-  return tile % tile_stride ? -1 : (tile / tile_stride) * 16 + (item & 15);
-}
 __global__ void topn_mask_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                  const int64_t* __restrict__ query_row, int n_queries, int tile_stride, int64_t n_out,
                                  float* __restrict__ scores) {
@@ -168,38 +375,198 @@ __global__ void topn_exclude_kernel(const int64_t* __restrict__ excl_ptr, const 
     if (slot >= 0) scores[(int64_t)q * n_out + slot] = -__builtin_huge_valf();
   }
 }
-// Filter path: candidates that are known / excluded items are struck out (key 0 never qualifies).
-// One workgroup row per query; a query has a few hundred candidates, so every list entry is compared
-// against all of them.
-__global__ __launch_bounds__(256) void topn_strike_kernel(const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
-                                                          const int64_t* __restrict__ query_row,
-                                                          const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx,
-                                                          int n_queries, const TopnState* __restrict__ st, int cap,
-                                                          uint32_t* __restrict__ cand) {
+
+// tau[q] = a value that at least how_many entries of row q reach: the how_many-th largest of the 1024 per-thread
+// maxima of the row (thread t owns entries t, t + 1024, ...).  Those maxima are distinct entries, so the claim holds;
+// it is the exact how_many-th largest unless two of the best how_many share a thread, and a lower tau only lets a
+// few more candidates through.  -inf if fewer than how_many threads hold a finite entry (the dense path answers).
+__global__ __launch_bounds__(1024) void topn_threshold_kernel(const float* __restrict__ rows, int64_t n_row, int how_many,
+                                                              float* __restrict__ tau) {
+  __shared__ unsigned h[256], sfx[256];
+  __shared__ uint32_t s_prefix, s_rem;
+  const int q = blockIdx.x;
+  const float* row = rows + (int64_t)q * n_row;
+  const uint32_t ninf_key = score_key(-__builtin_huge_valf());
+  float best = -__builtin_huge_valf();
+  for (int64_t i = threadIdx.x; i < n_row; i += 1024) best = fmaxf(best, row[i]);   // NaN lower bounds are dropped by fmaxf
+  const uint32_t key = score_key(best);
+  if (threadIdx.x == 0) {
+    s_prefix = 0;
+    s_rem = (uint32_t)how_many;
+  }
+  const int lane = threadIdx.x & 63;
+  for (int pass = 0; pass < 4; ++pass) {
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+    const uint32_t prefix = s_prefix;
+    const bool cnd = key > ninf_key && (key & mask) == prefix;
+    const int digit = (int)((key >> shift) & 255);
+    uint64_t peers = __ballot(cnd);
+    if (peers) {
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool one = (digit >> bit) & 1;
+        const uint64_t m = __ballot(one);
+        peers &= one ? m : ~m;
+      }
+      if (cnd && (peers & ((1ull << lane) - 1)) == 0) atomicAdd(&h[digit], (unsigned)__popcll(peers));
+    }
+    __syncthreads();
+    // the digit d with  sum_{j > d} h[j] < rem <= sum_{j >= d} h[j]: suffix sums by 256 threads (a serial walk over the
+    // bins by one thread cost 10 us per pass)
+    if (threadIdx.x < 256) sfx[threadIdx.x] = h[threadIdx.x];
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      unsigned v = 0;
+      if (threadIdx.x < 256 && threadIdx.x + off < 256) v = sfx[threadIdx.x + off];
+      __syncthreads();
+      if (threadIdx.x < 256) sfx[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const unsigned rem = s_rem;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+      const unsigned ge = sfx[threadIdx.x], gt = threadIdx.x < 255 ? sfx[threadIdx.x + 1] : 0u;
+      if (rem < 0x80000000u && gt < rem && rem <= ge) {
+        s_prefix = prefix | ((uint32_t)threadIdx.x << shift);
+        s_rem = rem - gt;
+      }
+      if (threadIdx.x == 0 && (rem >= 0x80000000u || ge < rem)) s_rem = 0x80000000u;  // fewer candidates than asked for
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) tau[q] = (s_rem >= 0x80000000u || s_prefix <= ninf_key) ? -__builtin_huge_valf() : key_score(s_prefix);
+}
+
+// ---- exact rescoring of the candidates --------------------------------------------------------------------------------
+// pairs[q][p] = (score key << 32) | ~item for p < min(count[q], cap), 0 for a candidate that is a known / excluded item
+// of the query (RecommendIterator.java:75-82).  One thread per candidate.
+__global__ __launch_bounds__(256) void topn_rescore_kernel(const float* __restrict__ Y, int k, const float* __restrict__ vecs,
+                                                           const int32_t* __restrict__ vptr, const unsigned* __restrict__ count, int cap,
+                                                           const uint32_t* __restrict__ cand, const int64_t* __restrict__ row_ptr,
+                                                           const int32_t* __restrict__ col, const int64_t* __restrict__ query_row,
+                                                           const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx,
+                                                           uint64_t* __restrict__ pairs) {
   const int q = blockIdx.y;
-  if (q >= n_queries) return;
-  int64_t b = 0, e = 0;
-  const int64_t* list64 = nullptr;
-  const int32_t* list32 = nullptr;
+  const unsigned cq = count[(size_t)q * TOPN_COUNT_STRIDE];
+  const unsigned n = cq < (unsigned)cap ? cq : (unsigned)cap;
+  int64_t kb = 0, ke = 0, eb = 0, ee = 0;
   if (query_row) {
     const int64_t r = query_row[q];
-    if (r >= 0) { b = row_ptr[r]; e = row_ptr[r + 1]; list32 = col; }
-  } else if (excl_ptr) {
-    b = excl_ptr[q]; e = excl_ptr[q + 1]; list64 = excl_idx;
+    if (r >= 0) {
+      kb = row_ptr[r];
+      ke = row_ptr[r + 1];
+    }
   }
-  const unsigned n_c = topn_count(st, q) < (unsigned)cap ? topn_count(st, q) : (unsigned)cap;
-  uint32_t* cq = cand + (int64_t)q * cap * 2;
-  for (int64_t i = b + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t it = list32 ? (int64_t)list32[i] : list64[i];
-    for (unsigned p = 0; p < n_c; ++p)
-      if ((int64_t)cq[2 * p] == it) cq[2 * p + 1] = 0u;
+  if (excl_ptr) {
+    eb = excl_ptr[q];
+    ee = excl_ptr[q + 1];
+  }
+  for (unsigned p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
+    const uint32_t it = cand[(int64_t)q * cap + p];
+    bool struck = false;
+    for (int64_t i = kb; i < ke; ++i) struck |= (uint32_t)col[i] == it;           // the same list for the whole workgroup
+    for (int64_t i = eb; i < ee; ++i) struck |= excl_idx[i] == (int64_t)it;
+    uint64_t out = 0;
+    if (!struck) {
+      const float sc = topn_ref_score(Y + (int64_t)it * k, vecs, vptr[q], vptr[q + 1], k);
+      out = ((uint64_t)score_key(sc) << 32) | (uint64_t)(0xffffffffu - it);
+    }
+    pairs[(int64_t)q * cap + p] = out;
+  }
+}
+// The N best of every query: how_many rounds of "largest remaining pair" over the query's candidates in LDS (a few
+// hundred pairs, N <= 64: cheaper than sorting them).  Pairs are unique (the item is part of them), larger = better
+// score, then lower index.  out_pairs[q][j], j < how_many: the j-th best (0 = none).
+__global__ __launch_bounds__(256) void topn_final_kernel(const uint64_t* __restrict__ pairs, const unsigned* __restrict__ count, int cap,
+                                                         int how_many, uint64_t* __restrict__ out_pairs, unsigned* __restrict__ count_out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+  __shared__ uint64_t wbest[4];
+  __shared__ int wwhere[4];
+  const int q = blockIdx.x;
+  const unsigned cq = count[(size_t)q * TOPN_COUNT_STRIDE];
+  if (threadIdx.x == 0) count_out[q] = cq;
+  const int n = (int)(cq < (unsigned)cap ? cq : (unsigned)cap);
+  for (int i = threadIdx.x; i < n; i += 256) a[i] = pairs[(int64_t)q * cap + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int j = 0; j < how_many; ++j) {
+    uint64_t best = 0;
+    int where = -1;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const uint64_t v = a[i];
+      if (v > best) {
+        best = v;
+        where = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint64_t ob = __shfl_down(best, off);
+      const int ow = __shfl_down(where, off);
+      if (ob > best) {
+        best = ob;
+        where = ow;
+      }
+    }
+    if (lane == 0) {
+      wbest[w] = best;
+      wwhere[w] = where;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint64_t b = wbest[0];
+      int wh = wwhere[0];
+      for (int x = 1; x < 4; ++x)
+        if (wbest[x] > b) {
+          b = wbest[x];
+          wh = wwhere[x];
+        }
+      out_pairs[(int64_t)q * how_many + j] = b;
+      if (wh >= 0) a[wh] = 0;
+    }
+    __syncthreads();
   }
 }
 
-// Selection state per query: {prefix, remaining} + a 256-bin histogram.  The N-th largest score is
+// ---- the dense path: exact scores of every item -----------------------------------------------------------------------
+// scores[q][i] for a 64-item tile per workgroup: the tile's rows are staged in LDS (coalesced), wave w takes the queries
+// w, w + 4, ...: lane = item, the query's vectors are read with wave-uniform addresses.
+__global__ __launch_bounds__(256) void topn_exact_dense_kernel(const float* __restrict__ Y, int64_t n_items, int k,
+                                                               const float* __restrict__ vecs, const int32_t* __restrict__ vptr,
+                                                               int n_queries, float* __restrict__ scores) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  float* ys = reinterpret_cast<float*>(smem);  // [64][k + 1]
+  const int pitch = k + 1;
+  for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < n_items; i0 += (int64_t)gridDim.x * 64) {
+    const int rows = (int)(n_items - i0 < 64 ? n_items - i0 : 64);
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * k; e += 256) ys[(e / k) * pitch + (e % k)] = Y[i0 * k + e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < rows) {
+      const float* y = ys + lane * pitch;
+      for (int q = w; q < n_queries; q += 4) {
+        const int v0 = __builtin_amdgcn_readfirstlane(vptr[q]), v1 = __builtin_amdgcn_readfirstlane(vptr[q + 1]);
+        scores[(int64_t)q * n_items + i0 + lane] = topn_ref_score(y, vecs, v0, v1, k);
+      }
+    }
+  }
+}
+
+// Selection state per query (dense path): {prefix, remaining} + a 256-bin histogram.  The N-th largest score is
 // found by a 4-pass radix select, most significant digit first; every pass is one grid-wide scan of
 // the score rows (grid = slabs x queries) into the per-query histogram, followed by a one-thread-per-
 // query pick of the digit in which the N-th score lies.  -inf scores (masked items) never qualify.
+struct TopnState {
+  uint32_t prefix;     // digits decided so far (in place, high bits); after 4 passes the N-th best key
+  uint32_t remaining;  // rank of the N-th score inside the candidates that match the prefix
+  uint32_t above;      // collected: scores strictly above the N-th
+  uint32_t ties;       // collected: scores equal to the N-th (all of them counted, cap_ties stored)
+};
 
 __global__ void topn_init_kernel(TopnState* __restrict__ st, unsigned* __restrict__ hist, int n_queries, int how_many) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -15,10 +15,16 @@ import heapq
 import numpy as np
 
 
+def _seq_sum(p):
+    """double dot = 0.0; dot += p[0]; dot += p[1]; ... (SVM:36-39): starts from +0.0, so a sum of negative zeros is +0.0"""
+    z = np.zeros((len(p), 1), np.float64)
+    return np.cumsum(np.concatenate([z, p.astype(np.float64)], axis=1), axis=1)[:, -1]
+
+
 def scores(Y, x):
     """(float) dot(Y_i, x) for every item: fp32 products, sequential fp64 sum, cast to fp32."""
     p = (np.asarray(Y, np.float32) * np.asarray(x, np.float32)[None, :]).astype(np.float32)
-    d = np.cumsum(p.astype(np.float64), axis=1)[:, -1] if p.shape[1] else np.zeros(len(p))
+    d = _seq_sum(p)
     return d.astype(np.float32)
 
 
@@ -37,9 +43,22 @@ def select_top_n(items, n):
     return [(it, v) for v, _, it in sorted(heap, key=lambda t: (-t[0], t[2]))]
 
 
+def scores_to_many(Y, vectors):
+    """RecommendIterator.java:93-104 for a query of several vectors: (float)((dot_1 + ... + dot_n) / n), the dots
+    added in fp64 in the order of the vectors."""
+    vectors = np.asarray(vectors, np.float32)
+    total = np.zeros(len(Y), np.float64)
+    for x in vectors:
+        p = (np.asarray(Y, np.float32) * x[None, :]).astype(np.float32)
+        total = total + _seq_sum(p)
+    return (total / float(len(vectors))).astype(np.float32)
+
+
 def recommend(Y, x, how_many, known=None):
-    """Returns (item indices, scores), best first, ties by ascending index."""
-    s = scores(Y, x)
+    """Returns (item indices, scores), best first, ties by ascending index.  x: one vector, or an array of several
+    (recommendToMany)."""
+    x = np.asarray(x, np.float32)
+    s = scores(Y, x) if x.ndim == 1 else scores_to_many(Y, x)
     ok = np.ones(len(s), bool)
     if known is not None and len(known):
         ok[np.asarray(known, np.int64)] = False
