@@ -1981,10 +1981,17 @@ __global__ __launch_bounds__(256) void gramian_finalize_kernel(const double* __r
 // ill-conditioned (state[0], set by the solving kernels) and the matrix is not there yet (state[1]).  Those rows'
 // answers move by more than 1e-4 with the rounding of these products (cond(W) ~ 1e7; sweep case 2550), and parity is
 // with the reference's arithmetic.  Per-workgroup partial sums, combined in workgroup order by the last to arrive.
+// state[3] = "run": the go / no-go of the NEXT gramian_ref_kernel launch, decided once.  With the chunks of a half-
+// iteration on two alternating streams the other stream's solving kernels may set state[0] while this launch's
+// workgroups are still being dispatched: were every workgroup to read state[0] itself, some would return and some
+// compute, the arrival ticket would never reach gridDim - 1 and stay non-zero, and the next launch would sum stale
+// partials.  One thread latches the decision in front of the launch (same stream), every workgroup reads the latch.
+__global__ void gramian_ref_latch_kernel(int* state) { state[3] = (state[0] != 0 && state[1] == 0) ? 1 : 0; }
+
 template <int T>
 __global__ __launch_bounds__(256) void gramian_ref_kernel(const float* __restrict__ M, int64_t n_rows, int k, int* state,
                                                           double* __restrict__ part, double* __restrict__ Gref) {
-  if (state[0] == 0 || state[1] != 0) return;
+  if (state[3] == 0) return;
   constexpr int KP = 16 * T, NE = T * T;   // KP^2 / 256 entries per thread
   __shared__ float srow[8][KP];
   __shared__ int s_last;

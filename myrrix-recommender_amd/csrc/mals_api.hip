@@ -811,6 +811,7 @@ int launch_refine(mals_handle h, const RefineParams& q) {
 template <int T>
 int launch_gramian_ref_T(mals_handle h, const SideState& o) {
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((o.n_total + 63) / 64, (int64_t)h->n_cu * 2));
+  hipLaunchKernelGGL(gramian_ref_latch_kernel, dim3(1), dim3(1), 0, h->stream, h->d_gref_state);
   hipLaunchKernelGGL((gramian_ref_kernel<T>), dim3(grid), dim3(256), 0, h->stream, o.F, o.n_total, h->cfg.features, h->d_gref_state,
                      h->d_gref_part, h->d_Gref);
   HIPCHK(h, hipGetLastError());
@@ -1086,7 +1087,10 @@ int prepare_dual_device(mals_handle h, int side) {
     h->d_lam = reinterpret_cast<float*>(h->d_eig + (reinterpret_cast<char*>(e.lam) - h->eig_stage));
     h->d_Bs = reinterpret_cast<int32_t*>(h->d_eig + (reinterpret_cast<char*>(e.Bs) - h->eig_stage));
   }
-  if (!h->d_zbound) HIPCHK(h, hipMalloc(&h->d_zbound, 2 * sizeof(unsigned)));  // {z bound of the dual kernels, x' bound of the un-rotation}
+  // {z bound of the dual kernels, x' bound of the un-rotation of the even chunks, of the odd chunks}: a chunk's un-rotation
+  // picks its operand scale from the bound its OWN dual kernels left -- with the chunks on two alternating streams a
+  // shared slot made the scale (hence the f16 split of small components) depend on how far the other stream had got
+  if (!h->d_zbound) HIPCHK(h, hipMalloc(&h->d_zbound, 3 * sizeof(unsigned)));
   const size_t need = (size_t)o.n_total * KP;
   if (h->Mr_cap < need) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1098,7 +1102,7 @@ int prepare_dual_device(mals_handle h, int side) {
   // pinned source, rewritten no earlier than the next half-iteration's prepare_dual_host (which waits for this stream)
   HIPCHK(h, hipMemcpyAsync(h->d_eig, h->eig_stage, h->eig_stage_bytes, hipMemcpyHostToDevice, h->stream));
   h->Bs_stride = e.nBs;
-  HIPCHK(h, hipMemsetAsync(h->d_zbound, 0, 2 * sizeof(unsigned), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_zbound, 0, 3 * sizeof(unsigned), h->stream));
   RotateParams rp;
   rp.src = o.F;
   rp.dst = h->d_Mr;
@@ -1148,7 +1152,8 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
   dp.alpha = (float)h->cfg.alpha;
   dp.lambda_alpha = (float)(h->cfg.lambda * h->cfg.alpha);
   dp.sqrt_w_max = (float)std::sqrt(std::fabs(h->cfg.alpha) * (double)s.max_abs_val);
-  dp.xbound = h->d_zbound + 1;
+  dp.xbound = h->d_zbound + 1 + (chunk & 1);
+  HIPCHK(h, hipMemsetAsync(dp.xbound, 0, sizeof(unsigned), h->stream));  // same stream as the chunk two back, whose un-rotation is done
   dp.any_marked = h->d_gref_state;
   dp.refine_flag = h->refine_limit > 0.f ? s.refine : nullptr;
   dp.refine_limit = h->refine_limit;
@@ -1185,7 +1190,7 @@ int launch_dual_chunk(mals_handle h, int side, int chunk) {
     sp.src = rp.src; sp.dst = rp.dst; sp.items = rp.items; sp.dmax = nullptr; sp.zbound = nullptr; sp.n_rows = rp.n_rows; sp.k = k;
     sp.src_stride = k; sp.dst_stride = k; sp.dst_cols = k;
     sp.Bs = reinterpret_cast<const i32x4*>(h->d_Bs + h->Bs_stride);
-    sp.bound_bits = h->d_zbound + 1;
+    sp.bound_bits = dp.xbound;
     sp.bound_host = 0.f;
     if (int rc = launch_rotate_split<true>(h, sp)) return rc;
   } else if (int rc = launch_rotate<true, false>(h, rp)) {
@@ -1828,8 +1833,8 @@ static int solve_chunks(mals_handle h, int side, int chunk_begin, int chunk_end,
       h->pad_done.assign(s.chunks.size(), 0);
       h->tl[0] = now_us();
       h->tl[1] = h->tl[2] = 0.0;
-      // nothing marked yet, no reference-rounded Gramian yet (gramian_ref_kernel)
-      HIPCHK(h, hipMemsetAsync(h->d_gref_state, 0, 2 * sizeof(int), h->stream));
+      // nothing marked yet, no reference-rounded Gramian yet, no arrival counted (gramian_ref_kernel)
+      HIPCHK(h, hipMemsetAsync(h->d_gref_state, 0, 3 * sizeof(int), h->stream));
     }
     for (int c = chunk_begin; c < chunk_end; ++c) h->pad_done[(size_t)c] = 1;
     if (k % 16 != 0) {

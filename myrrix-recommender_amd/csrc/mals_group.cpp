@@ -1015,15 +1015,30 @@ int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max
   for (;;) {
     const auto t_it = std::chrono::steady_clock::now();
     mals_stats st0;
+    // the callback is sampled ONCE per iteration (one installed while an iteration runs starts with the next one)
+    const mals_iteration_fn iter_fn = g->iter_fn;
+    void* const iter_user = g->iter_user;
     std::vector<std::pair<int64_t, int64_t>> before;   // (rows_solved, nnz_gathered) of every local member
-    if (g->iter_fn)
+    auto rows_now = [&]() {
+      int64_t r = 0;
+      for (Member& mb : g->m) {
+        (void)mals_get_stats(mb.h, &st0);
+        r += st0.rows_solved;
+      }
+      return r;
+    };
+    int64_t rows_before = 0, rows_after_x = 0;
+    if (iter_fn) {
       for (Member& mb : g->m) {
         (void)mals_get_stats(mb.h, &st0);
         before.emplace_back(st0.rows_solved, st0.nnz_gathered);
+        rows_before += st0.rows_solved;
       }
+    }
     // a cancellation is local knowledge: agree on it before entering a collective
     if (int rc = agree_status(g, g->cancelled.load() ? MALS_CANCELLED : MALS_OK, "cancelled")) return rc;
     if (int rc = mals_group_half_iteration(g, MALS_SIDE_X)) return rc;  // ALS:228
+    if (iter_fn) rows_after_x = rows_now();  // what THIS process's members solved in the X half, exactly
     if (int rc = agree_status(g, g->cancelled.load() ? MALS_CANCELLED : MALS_OK, "cancelled")) return rc;
     if (int rc = mals_group_half_iteration(g, MALS_SIDE_Y)) return rc;  // ALS:229
     // ALS:231-238: the sample dots (SimpleVectorMath.dot) on the device from a complete replica (every replica
@@ -1044,7 +1059,7 @@ int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max
     ++it;
     if (iterations_out) *iterations_out = it;
     if (convergence_out) *convergence_out = mean;
-    if (g->iter_fn) {   // what the reference logs per iteration (ALS:241-246, 351-358)
+    if (iter_fn && before.size() == g->m.size()) {   // what the reference logs per iteration (ALS:241-246, 351-358)
       mals_iteration_info info;
       std::memset(&info, 0, sizeof(info));
       info.struct_size = (int32_t)sizeof(info);
@@ -1057,12 +1072,11 @@ int mals_group_factorize(mals_group g, double convergence_threshold, int32_t max
         rows += st0.rows_solved - before[i].first;
         info.entries_gathered += st0.nnz_gathered - before[i].second;
       }
-      const int64_t x_all = g->n_rows[MALS_SIDE_X], y_all = g->n_rows[MALS_SIDE_Y];
-      info.x_rows = g->single_process ? x_all : rows * x_all / std::max<int64_t>(1, x_all + y_all);
+      info.x_rows = rows_after_x - rows_before;
       info.y_rows = rows - info.x_rows;
       info.algorithmic_bytes = (double)(info.entries_gathered + rows) * (4.0 * g->cfg.features + 8.0);
       info.devices = (int32_t)g->m.size();
-      g->iter_fn(g->iter_user, &info);
+      iter_fn(iter_user, &info);
     }
     if (max_iterations > 0 && it >= max_iterations) break;              // ALS:242-245
     if (!std::isfinite(mean)) break;                                    // ALS:248-251

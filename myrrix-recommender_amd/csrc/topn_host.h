@@ -3,19 +3,22 @@
 #pragma once
 
 struct TopnWorkspace {
-  // inputs of one pass
-  float* d_vecs = nullptr;      // [n_vecs][k]
-  int32_t* d_vptr = nullptr;    // [nq + 1]
-  int64_t* d_rows = nullptr;    // [nq]: local row of the query's user (known items), -1 = none
-  int64_t* d_uidx = nullptr;    // [n_vecs]: user indices to gather vectors from X
-  int64_t* d_excl_ptr = nullptr;
-  int64_t* d_excl_idx = nullptr;
-  size_t vecs_cap = 0, excl_cap = 0;
+  // inputs of one pass: ONE device block, the image of the pinned block of the pass's slot (one copy); the pointers
+  // below are views into it
+  uint8_t* d_in = nullptr;
+  size_t din_cap = 0;
+  const float* d_vecs = nullptr;      // [n_vecs][k] (caller's vectors) or X itself (model users: rows d_vrow)
+  const int64_t* d_vrow = nullptr;    // vector v = row d_vrow[v] of d_vecs; NULL: row v
+  const int32_t* d_vptr = nullptr;    // [nq + 1]
+  const int64_t* d_rows = nullptr;    // [nq]: local row of the query's user (known items), -1 = none
+  const int64_t* d_excl_ptr = nullptr;
+  const int64_t* d_excl_idx = nullptr;
   // filter path
-  float *d_xbar = nullptr, *d_mnorm = nullptr, *d_tau = nullptr, *d_lb = nullptr;
+  float *d_tau = nullptr, *d_lb = nullptr;
   unsigned* d_count = nullptr;
   uint32_t* d_cand = nullptr;
-  uint64_t *d_pairs = nullptr, *d_outp = nullptr;
+  uint64_t* d_pairs = nullptr;
+  uint8_t* d_outp = nullptr;    // the pass's results: [nq][how_many] pairs | counts | taus | overflow word
   void* d_img = nullptr;        // the pass's queries as split bf16 MFMA operands (topn_image_kernel)
   unsigned* d_wcount = nullptr; // hits per wave of the filter kernel, [n_waves] + one overflow word
   uint2* d_whits = nullptr;     // [n_waves][TOPN_WAVE_CAP] (item, query)
@@ -38,8 +41,8 @@ struct TopnWorkspace {
 void topn_free(mals_handle h) {
   TopnWorkspace* w = static_cast<TopnWorkspace*>(h->tn_ws);
   if (!w) return;
-  free_dev(w->d_vecs); free_dev(w->d_vptr); free_dev(w->d_rows); free_dev(w->d_uidx); free_dev(w->d_excl_ptr); free_dev(w->d_excl_idx);
-  free_dev(w->d_xbar); free_dev(w->d_mnorm); free_dev(w->d_tau); free_dev(w->d_lb); free_dev(w->d_count); free_dev(w->d_cand);
+  free_dev(w->d_in);
+  free_dev(w->d_tau); free_dev(w->d_lb); free_dev(w->d_count); free_dev(w->d_cand);
   free_dev(w->d_pairs); free_dev(w->d_outp); free_dev(w->d_img); free_dev(w->d_wcount); free_dev(w->d_whits); free_dev(w->d_scores); free_dev(w->d_sel); free_dev(w->d_state); free_dev(w->d_hist);
   for (int s = 0; s < 2; ++s) {
     if (w->h_stage[s]) (void)hipHostFree(w->h_stage[s]);
@@ -101,8 +104,8 @@ void topn_emit(std::vector<TopnCand>& cand, int how_many, int64_t* item_idx_out,
   }
 }
 
-// The pass's vectors, offsets, known-item rows and exclusion lists on the device.  Everything goes through the pinned
-// input block of `slot`, so the copies are asynchronous and the host never waits for the pass that is still running.
+// The pass's vectors, offsets, known-item rows and exclusion lists on the device: assembled in the pinned input block
+// of `slot` and sent with ONE asynchronous copy (the host never waits for the pass that is still running).
 int topn_upload_pass(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, TopnPass& ps, int slot) {
   const int k = h->cfg.features;
   SideState& x = h->side[MALS_SIDE_X];
@@ -115,10 +118,10 @@ int topn_upload_pass(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, Top
     ps.n_vecs = rq.vec_ptr[ps.q0 + ps.nq] - ps.v0;
   }
   const int64_t n_ex = (rq.excl_ptr && rq.excl_idx) ? rq.excl_ptr[ps.q0 + ps.nq] - rq.excl_ptr[ps.q0] : 0;
-  // layout of the pinned block
+  // layout of the block (8-byte aligned pieces)
   const size_t o_vptr = 0, o_rows = o_vptr + 8 * ((TOPN_FILTER_QUERIES + 2) / 2), o_uidx = o_rows + 8 * TOPN_FILTER_QUERIES,
                o_eptr = o_uidx + 8 * TOPN_FILTER_QUERIES, o_vecs = o_eptr + 8 * (TOPN_FILTER_QUERIES + 1),
-               o_eidx = o_vecs + ((own_vectors ? sizeof(float) * (size_t)ps.n_vecs * (size_t)k : 0) + 7) / 8 * 8,
+               o_eidx = o_vecs + ((own_vectors ? sizeof(float) * (size_t)ps.n_vecs * (size_t)k : 0) + 15) / 16 * 16,
                total = o_eidx + 8 * (size_t)n_ex;
   if (total > w->in_cap[slot]) {
     HIPCHK(h, hipStreamSynchronize(h->stream));  // an earlier pass may still be reading the old block
@@ -128,45 +131,36 @@ int topn_upload_pass(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, Top
     HIPCHK(h, hipHostMalloc(&w->h_in[slot], total + total / 2, hipHostMallocDefault));
     w->in_cap[slot] = total + total / 2;
   }
+  if (int rc = topn_grow(h, w->d_in, w->din_cap, total + total / 2)) return rc;
   uint8_t* in = w->h_in[slot];
   int32_t* vptr = reinterpret_cast<int32_t*>(in + o_vptr);
   for (int q = 0; q <= ps.nq; ++q) vptr[q] = (rq.user_idx || !rq.vec_ptr) ? q : (int32_t)(rq.vec_ptr[ps.q0 + q] - ps.v0);
-  if (int rc = topn_grow(h, w->d_vecs, w->vecs_cap, (size_t)std::max<int64_t>(ps.n_vecs, 1) * (size_t)k)) return rc;
-  if (!w->d_vptr) {
-    HIPCHK(h, hipMalloc(&w->d_vptr, sizeof(int32_t) * (TOPN_FILTER_QUERIES + 1)));
-    HIPCHK(h, hipMalloc(&w->d_rows, sizeof(int64_t) * TOPN_FILTER_QUERIES));
-    HIPCHK(h, hipMalloc(&w->d_uidx, sizeof(int64_t) * TOPN_FILTER_QUERIES));
-    HIPCHK(h, hipMalloc(&w->d_excl_ptr, sizeof(int64_t) * (TOPN_FILTER_QUERIES + 1)));
-  }
-  HIPCHK(h, hipMemcpyAsync(w->d_vptr, vptr, sizeof(int32_t) * ((size_t)ps.nq + 1), hipMemcpyHostToDevice, h->stream));
   ps.have_rows = ps.have_excl = false;
+  w->d_vptr = reinterpret_cast<const int32_t*>(w->d_in + o_vptr);
+  w->d_rows = reinterpret_cast<const int64_t*>(w->d_in + o_rows);
+  w->d_excl_ptr = reinterpret_cast<const int64_t*>(w->d_in + o_eptr);
+  w->d_excl_idx = reinterpret_cast<const int64_t*>(w->d_in + o_eidx);
   if (rq.user_idx) {
-    int64_t* uidx = reinterpret_cast<int64_t*>(in + o_uidx);
-    std::memcpy(uidx, rq.user_idx + ps.q0, sizeof(int64_t) * (size_t)ps.nq);
-    HIPCHK(h, hipMemcpyAsync(w->d_uidx, uidx, sizeof(int64_t) * (size_t)ps.nq, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((ps.nq * k + 255) / 256)), dim3(256), 0, h->stream, x.F, w->d_uidx, ps.nq, k, w->d_vecs);
-    HIPCHK(h, hipGetLastError());
+    std::memcpy(in + o_uidx, rq.user_idx + ps.q0, sizeof(int64_t) * (size_t)ps.nq);
+    w->d_vecs = x.F;
+    w->d_vrow = reinterpret_cast<const int64_t*>(w->d_in + o_uidx);
     if (rq.skip_known) {
       int64_t* rows = reinterpret_cast<int64_t*>(in + o_rows);
       for (int q = 0; q < ps.nq; ++q) rows[q] = rq.user_idx[ps.q0 + q] - x.row_offset;
-      HIPCHK(h, hipMemcpyAsync(w->d_rows, rows, sizeof(int64_t) * (size_t)ps.nq, hipMemcpyHostToDevice, h->stream));
       ps.have_rows = true;
     }
   } else {
-    float* vecs = reinterpret_cast<float*>(in + o_vecs);
-    std::memcpy(vecs, rq.vectors + ps.v0 * k, sizeof(float) * (size_t)ps.n_vecs * (size_t)k);
-    HIPCHK(h, hipMemcpyAsync(w->d_vecs, vecs, sizeof(float) * (size_t)ps.n_vecs * (size_t)k, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(in + o_vecs, rq.vectors + ps.v0 * k, sizeof(float) * (size_t)ps.n_vecs * (size_t)k);
+    w->d_vecs = reinterpret_cast<const float*>(w->d_in + o_vecs);
+    w->d_vrow = nullptr;
   }
   if (n_ex > 0) {
     int64_t* eptr = reinterpret_cast<int64_t*>(in + o_eptr);
-    int64_t* eidx = reinterpret_cast<int64_t*>(in + o_eidx);
     for (int q = 0; q <= ps.nq; ++q) eptr[q] = rq.excl_ptr[ps.q0 + q] - rq.excl_ptr[ps.q0];
-    std::memcpy(eidx, rq.excl_idx + rq.excl_ptr[ps.q0], sizeof(int64_t) * (size_t)n_ex);
-    if (int rc = topn_grow(h, w->d_excl_idx, w->excl_cap, (size_t)n_ex)) return rc;
-    HIPCHK(h, hipMemcpyAsync(w->d_excl_ptr, eptr, sizeof(int64_t) * ((size_t)ps.nq + 1), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(w->d_excl_idx, eidx, sizeof(int64_t) * (size_t)n_ex, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(in + o_eidx, rq.excl_idx + rq.excl_ptr[ps.q0], sizeof(int64_t) * (size_t)n_ex);
     ps.have_excl = true;
   }
+  HIPCHK(h, hipMemcpyAsync(w->d_in, in, total, hipMemcpyHostToDevice, h->stream));
   return MALS_OK;
 }
 
@@ -197,7 +191,7 @@ int topn_pass_dense(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, cons
   if (!w->d_hist) HIPCHK(h, hipMalloc(&w->d_hist, sizeof(unsigned) * 256 * TOPN_MAX_QUERIES));
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_items + 63) / 64, (int64_t)h->n_cu * 8));
   hipLaunchKernelGGL(topn_exact_dense_kernel, dim3(grid), dim3(256), sizeof(float) * 64 * (size_t)(k + 1), h->stream, y.F, n_items, k, w->d_vecs,
-                     w->d_vptr, nq, w->d_scores);
+                     w->d_vrow, w->d_vptr, nq, w->d_scores);
   if (ps.have_rows)
     hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, w->d_rows, nq, 1, n_items, w->d_scores);
   if (ps.have_excl)
@@ -323,7 +317,7 @@ TopnFilterPlan topn_plan(mals_handle h, int how_many) {
   const int64_t target = std::max<int64_t>(512 * (int64_t)how_many, 16384);  // sample items: expected candidates = how_many x stride
   p.tile_stride = (int)std::max<int64_t>(1, n_items / target);
   p.n_sample = ((n_items + 16 * (int64_t)p.tile_stride - 1) / (16 * (int64_t)p.tile_stride)) * 16;
-  p.stage_bytes = (size_t)TOPN_FILTER_QUERIES * ((size_t)how_many * 8 + 8) + 16;
+  p.stage_bytes = (size_t)TOPN_FILTER_QUERIES * ((size_t)how_many * 8 + 8) + 16;  // pairs | counts | taus | overflow word
   return p;
 }
 
@@ -334,50 +328,41 @@ int topn_pass_filter_enqueue(mals_handle h, TopnWorkspace* w, const TopnRequest&
   const int k = h->cfg.features, nq = ps.nq, how_many = rq.how_many;
   const int64_t n_items = y.n_total;
   const int nt = (nq + 15) / 16;
-  if (!w->d_xbar) {
-    HIPCHK(h, hipMalloc(&w->d_xbar, sizeof(float) * TOPN_FILTER_QUERIES * 128));
-    HIPCHK(h, hipMalloc(&w->d_mnorm, sizeof(float) * TOPN_FILTER_QUERIES));
+  if (!w->d_tau) {
     HIPCHK(h, hipMalloc(&w->d_tau, sizeof(float) * TOPN_FILTER_QUERIES));
-    HIPCHK(h, hipMalloc(&w->d_count, sizeof(unsigned) * TOPN_FILTER_QUERIES * (TOPN_COUNT_STRIDE + 1)));  // padded counters + their compact copy
+    HIPCHK(h, hipMalloc(&w->d_count, sizeof(unsigned) * (TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE + 1)));  // padded counters, then the overflow word
+    HIPCHK(h, hipMalloc(&w->d_img, (size_t)16 * 5 * 64 * 16));
   }
+  unsigned* d_overflow = w->d_count + (size_t)TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE;
   if (int rc = topn_grow(h, w->d_lb, w->lb_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.n_sample)) return rc;
-  if (int rc = topn_grow(h, w->d_cand, w->cand_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.cap)) return rc;
   if (int rc = topn_grow(h, w->d_pairs, w->pairs_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.cap)) return rc;
-  if (int rc = topn_grow(h, w->d_outp, w->outp_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)how_many)) return rc;
-  if (!w->d_img) HIPCHK(h, hipMalloc(&w->d_img, (size_t)16 * 5 * 64 * 16));
-  hipLaunchKernelGGL(topn_prepare_kernel, dim3((unsigned)nq), dim3(128), 0, h->stream, w->d_vecs, w->d_vptr, k, w->d_xbar, w->d_mnorm);
-  // the image covers every tile an instantiation may touch (16 tiles; the padding queries never produce a candidate)
-  hipLaunchKernelGGL(topn_image_kernel, dim3(16), dim3(64), 0, h->stream, w->d_xbar, w->d_mnorm, nq, k, p.S, static_cast<bf16x8*>(w->d_img));
-  HIPCHK(h, hipMemsetAsync(w->d_count, 0, sizeof(unsigned) * (size_t)nq * TOPN_COUNT_STRIDE, h->stream));
-  // 1. sample: lower bounds of every tile_stride-th tile, known items out
+  if (int rc = topn_grow(h, w->d_cand, w->cand_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.cap)) return rc;
+  if (int rc = topn_grow(h, w->d_outp, w->outp_cap, p.stage_bytes)) return rc;
+  const int64_t* d_rows = ps.have_rows ? w->d_rows : nullptr;
+  const int64_t* d_eptr = ps.have_excl ? w->d_excl_ptr : nullptr;
+  const int64_t* d_eidx = ps.have_excl ? w->d_excl_idx : nullptr;
+  // 0. the queries as matrix operands (every tile an instantiation may touch: padding queries never produce a hit)
+  hipLaunchKernelGGL(topn_prepare_kernel, dim3(16), dim3(256), 0, h->stream, w->d_vecs, w->d_vrow, w->d_vptr, nq, k, p.S,
+                     static_cast<bf16x8*>(w->d_img), w->d_count, d_overflow);
+  // 1. sample: lower bounds of every tile_stride-th tile; 2. threshold (known items out of the sample first)
   int n_fw = 0;
   if (int rc = topn_launch_filter_S<0>(h, p.S, nt, y.F, n_items, k, w, nq, p.tile_stride, p.n_sample, &n_fw)) return rc;
-  if (ps.have_rows)
-    hipLaunchKernelGGL(topn_mask_kernel, dim3(16, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, w->d_rows, nq, p.tile_stride, p.n_sample,
-                       w->d_lb);
-  if (ps.have_excl)
-    hipLaunchKernelGGL(topn_exclude_kernel, dim3(16, (unsigned)nq), dim3(256), 0, h->stream, w->d_excl_ptr, w->d_excl_idx, nq, n_items, p.tile_stride,
-                       p.n_sample, w->d_lb);
-  // 2. threshold, 3. filter, 4. exact scores of the candidates, known items struck, 5. the N best
-  hipLaunchKernelGGL(topn_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, h->stream, w->d_lb, p.n_sample, how_many, w->d_tau);
+  hipLaunchKernelGGL(topn_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, h->stream, w->d_lb, p.n_sample, how_many, x.row_ptr, x.col, d_rows, d_eptr,
+                     d_eidx, n_items, p.tile_stride, w->d_tau);
+  // 3. filter, 4. exact scores of the hits (known items dropped), 5. the N best
   if (int rc = topn_launch_filter_S<1>(h, p.S, nt, y.F, n_items, k, w, nq, 1, n_items, &n_fw)) return rc;
-  HIPCHK(h, hipMemsetAsync(w->d_wcount + n_fw, 0, sizeof(unsigned), h->stream));  // the overflow word
   hipLaunchKernelGGL(topn_scatter_kernel, dim3((unsigned)n_fw), dim3(256), 0, h->stream, w->d_wcount, w->d_whits, TOPN_WAVE_CAP, n_fw, p.cap,
-                     w->d_count, w->d_cand, w->d_wcount + n_fw);
-  hipLaunchKernelGGL(topn_rescore_kernel, dim3(4, (unsigned)nq), dim3(256), 0, h->stream, y.F, k, w->d_vecs, w->d_vptr, w->d_count, p.cap, w->d_cand,
-                     x.row_ptr, x.col, ps.have_rows ? w->d_rows : nullptr, ps.have_excl ? w->d_excl_ptr : nullptr,
-                     ps.have_excl ? w->d_excl_idx : nullptr, w->d_pairs);
+                     w->d_count, w->d_cand, d_overflow);
+  hipLaunchKernelGGL(topn_rescore_kernel, dim3(4, (unsigned)nq), dim3(256), 0, h->stream, y.F, k, w->d_vecs, w->d_vrow, w->d_vptr, w->d_count, p.cap,
+                     w->d_cand, x.row_ptr, x.col, d_rows, d_eptr, d_eidx, w->d_pairs);
+  uint8_t* o = w->d_outp;
+  const size_t o_cnt = sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many, o_tau = o_cnt + sizeof(unsigned) * TOPN_FILTER_QUERIES,
+               o_ovf = o_tau + sizeof(float) * TOPN_FILTER_QUERIES;
   hipLaunchKernelGGL(topn_final_kernel, dim3((unsigned)nq), dim3(256), sizeof(uint64_t) * (size_t)p.cap, h->stream, w->d_pairs, w->d_count, p.cap,
-                     how_many, w->d_outp, w->d_count + (size_t)TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE);
+                     how_many, reinterpret_cast<uint64_t*>(o), reinterpret_cast<unsigned*>(o + o_cnt), w->d_tau, reinterpret_cast<float*>(o + o_tau),
+                     d_overflow, reinterpret_cast<unsigned*>(o + o_ovf));
   HIPCHK(h, hipGetLastError());
-  uint8_t* st = w->h_stage[slot];
-  HIPCHK(h, hipMemcpyAsync(st, w->d_outp, sizeof(uint64_t) * (size_t)nq * (size_t)how_many, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(st + sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many, w->d_count + (size_t)TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE, sizeof(unsigned) * (size_t)nq,
-                           hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(st + sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many + sizeof(unsigned) * TOPN_FILTER_QUERIES, w->d_tau,
-                           sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipMemcpyAsync(st + sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many + (sizeof(unsigned) + sizeof(float)) * TOPN_FILTER_QUERIES,
-                           w->d_wcount + n_fw, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(w->h_stage[slot], o, p.stage_bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipEventRecord(w->ev[slot], h->stream));
   return MALS_OK;
 }

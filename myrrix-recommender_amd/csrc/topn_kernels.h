@@ -64,42 +64,16 @@ __device__ __forceinline__ double topn_ref_dot(const float* __restrict__ y, cons
   for (int f = 0; f < k; ++f) d += (double)__fmul_rn(y[f], x[f]);
   return d;
 }
-// RecommendIterator.java:93-104 for the vectors [v0, v1) of `vecs`
-__device__ __forceinline__ float topn_ref_score(const float* __restrict__ y, const float* __restrict__ vecs, int v0, int v1, int k) {
+// RecommendIterator.java:93-104 for the vectors [v0, v1) of the pass: vector v = row vrow[v] of vecs (vrow NULL: row v)
+__device__ __forceinline__ float topn_ref_score(const float* __restrict__ y, const float* __restrict__ vecs, const int64_t* __restrict__ vrow,
+                                                int v0, int v1, int k) {
   double sum = 0.0;
   int count = 0;
   for (int v = v0; v < v1; ++v) {
-    sum += topn_ref_dot(y, vecs + (int64_t)v * k, k);
+    sum += topn_ref_dot(y, vecs + (vrow ? vrow[v] : (int64_t)v) * k, k);
     ++count;
   }
   return (float)(sum / (double)count);
-}
-
-// per query: the filter vector (mean of its vectors, fp32) and the norm that scales the margin (mean of their norms,
-// rounded up).  One workgroup of 128 threads per query.
-__global__ __launch_bounds__(128) void topn_prepare_kernel(const float* __restrict__ vecs, const int32_t* __restrict__ vptr, int k,
-                                                           float* __restrict__ xbar, float* __restrict__ mnorm) {
-  const int q = blockIdx.x, v0 = vptr[q], v1 = vptr[q + 1], n = v1 - v0;
-  const int f = threadIdx.x;
-  double mean = 0.0;
-  if (f < k) {
-    for (int v = v0; v < v1; ++v) mean += (double)vecs[(int64_t)v * k + f];
-    xbar[(int64_t)q * k + f] = n ? (float)(mean / n) : 0.f;
-  }
-  __shared__ double red[128];
-  double norms = 0.0;
-  for (int v = v0; v < v1; ++v) {
-    const double x = f < k ? (double)vecs[(int64_t)v * k + f] : 0.0;
-    red[f] = x * x;
-    __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) {
-      if (f < s) red[f] += red[f + s];
-      __syncthreads();
-    }
-    norms += sqrt(red[0]);
-    __syncthreads();
-  }
-  if (f == 0) mnorm[q] = n ? (float)(norms / n * 1.000001) : 0.f;
 }
 
 // ---- approximate scores on the bf16 matrix pipe -----------------------------------------------------------------------
@@ -123,36 +97,68 @@ __device__ __forceinline__ __bf16 bf16_up(float v) {
 
 // The queries of a pass as MFMA B operands in the order the filter kernel's LDS wants them: per query tile t, S + 1
 // entries of 64 lanes x 8 bf16:
-//   entry s < S : lane (g, c) = bf16(xbar[query 16 t + c][features 8 S g + 8 s + 0..7])
-//   entry S     : the "margin step": lane (0, c) = {2^-8 |x_q| rounded up, floor, 0 (-tau hi), 0 (-tau lo), 0...}; the
-//                 filter kernel fills the tau slots once the thresholds are known.  Its A operand is {|y_i|, 1, 1, 1, 0..}
-//                 so one more MFMA adds margin_i - tau_q to every accumulator.
-// Built once per pass (grid = NT workgroups of 64 lanes); every filter workgroup copies it with 16-byte loads.
-__global__ __launch_bounds__(64) void topn_image_kernel(const float* __restrict__ xbar, const float* __restrict__ mnorm, int n_queries, int k,
-                                                        int S, bf16x8* __restrict__ img) {
-  const int t = blockIdx.x, lane = threadIdx.x;
-  const int g = lane >> 4, q = 16 * t + (lane & 15);
-  for (int s = 0; s < S; ++s) {
-    bf16x8 hi;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int f = 8 * S * g + 8 * s + j;
-      hi[j] = (__bf16)((q < n_queries && f < k) ? xbar[(int64_t)q * k + f] : 0.f);
-    }
-    img[(t * (S + 1) + s) * 64 + lane] = hi;
+//   entry s < S : lane (g, c) = bf16(xbar[query 16 t + c][features 8 S g + 8 s + 0..7]), xbar = the mean of the query's
+//                 vectors (fp32)
+//   entry S     : the "margin step": lane (0, c) = {2^-8 |x_q| rounded up, floor, 0 (-tau hi), 0 (-tau lo), 0...},
+//                 |x_q| = the mean of the norms of the query's vectors; the filter kernel fills the tau slots once the
+//                 thresholds are known.  Its A operand is {|y_i|, 1, 1, 1, 0..}, so one more MFMA adds margin_i - tau_q
+//                 to every accumulator.
+// One workgroup per query tile (16 queries), once per pass: gathers the vectors (row vrow[v] of vecs; vrow NULL: row
+// v), builds the tile's image, and clears the pass's counters.
+__global__ __launch_bounds__(256) void topn_prepare_kernel(const float* __restrict__ vecs, const int64_t* __restrict__ vrow,
+                                                           const int32_t* __restrict__ vptr, int n_queries, int k, int S,
+                                                           bf16x8* __restrict__ img, unsigned* __restrict__ count,
+                                                           unsigned* __restrict__ overflow) {
+  __shared__ float xb[16][129];
+  __shared__ float nrm[16];
+  const int t = blockIdx.x, qi = threadIdx.x >> 4, sub = threadIdx.x & 15;  // 16 threads per query
+  const int q = 16 * t + qi;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0u;
+  if (sub == 0 && q < n_queries) count[(size_t)q * TOPN_COUNT_STRIDE] = 0u;
+  int v0 = 0, v1 = 0;
+  if (q < n_queries) {
+    v0 = vptr[q];
+    v1 = vptr[q + 1];
   }
-  bf16x8 m;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) m[j] = (__bf16)0.f;
-  if (g == 0) {
-    if (q < n_queries) {
-      m[0] = bf16_up(TOPN_MARGIN * mnorm[q]);
-      m[1] = bf16_up(TOPN_MARGIN_FLOOR);
-    } else {
-      m[2] = (__bf16)(-1e30f);  // a padding query never has a candidate
-    }
+  const int n = v1 - v0;
+  for (int f = sub; f < 128; f += 16) {
+    double mean = 0.0;
+    if (f < k)
+      for (int v = v0; v < v1; ++v) mean += (double)vecs[(vrow ? vrow[v] : (int64_t)v) * k + f];
+    xb[qi][f] = n ? (float)(mean / n) : 0.f;
   }
-  img[(t * (S + 1) + S) * 64 + lane] = m;
+  double norms = 0.0;
+  for (int v = v0; v < v1; ++v) {
+    const float* x = vecs + (vrow ? vrow[v] : (int64_t)v) * k;
+    double ss = 0.0;
+    for (int f = sub; f < k; f += 16) ss += (double)x[f] * (double)x[f];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) ss += __shfl_xor(ss, off);  // the 16 lanes of this query
+    norms += sqrt(ss);
+  }
+  if (sub == 0) nrm[qi] = n ? (float)(norms / n * 1.000001) : 0.f;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    for (int s = 0; s < S; ++s) {
+      bf16x8 hi;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hi[j] = (__bf16)xb[c][8 * S * g + 8 * s + j];
+      img[(t * (S + 1) + s) * 64 + lane] = hi;
+    }
+    bf16x8 m;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = (__bf16)0.f;
+    if (g == 0) {
+      if (16 * t + c < n_queries) {
+        m[0] = bf16_up(TOPN_MARGIN * nrm[c]);
+        m[1] = bf16_up(TOPN_MARGIN_FLOOR);
+      } else {
+        m[2] = (__bf16)(-1e30f);  // a padding query never has a candidate
+      }
+    }
+    img[(t * (S + 1) + S) * 64 + lane] = m;
+  }
 }
 
 // S = contraction steps of 32 features (features padded to 32 S); NT = query tiles of 16 per workgroup; the workgroup's
@@ -380,13 +386,34 @@ __global__ void topn_exclude_kernel(const int64_t* __restrict__ excl_ptr, const 
 // maxima of the row (thread t owns entries t, t + 1024, ...).  Those maxima are distinct entries, so the claim holds;
 // it is the exact how_many-th largest unless two of the best how_many share a thread, and a lower tau only lets a
 // few more candidates through.  -inf if fewer than how_many threads hold a finite entry (the dense path answers).
-__global__ __launch_bounds__(1024) void topn_threshold_kernel(const float* __restrict__ rows, int64_t n_row, int how_many,
+// The known / excluded items of the query (RecommendIterator.java:75-82) are taken out of its row first, by this
+// workgroup (the row is its own).
+__global__ __launch_bounds__(1024) void topn_threshold_kernel(float* __restrict__ rows, int64_t n_row, int how_many,
+                                                              const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+                                                              const int64_t* __restrict__ query_row, const int64_t* __restrict__ excl_ptr,
+                                                              const int64_t* __restrict__ excl_idx, int64_t n_items, int tile_stride,
                                                               float* __restrict__ tau) {
   __shared__ unsigned h[256], sfx[256];
   __shared__ uint32_t s_prefix, s_rem;
   const int q = blockIdx.x;
-  const float* row = rows + (int64_t)q * n_row;
+  float* row = rows + (int64_t)q * n_row;
   const uint32_t ninf_key = score_key(-__builtin_huge_valf());
+  if (query_row) {
+    const int64_t r = query_row[q];
+    if (r >= 0)
+      for (int64_t i = row_ptr[r] + threadIdx.x; i < row_ptr[r + 1]; i += 1024) {
+        const int64_t slot = topn_row_slot(col[i], tile_stride);
+        if (slot >= 0) row[slot] = -__builtin_huge_valf();
+      }
+  }
+  if (excl_ptr)
+    for (int64_t i = excl_ptr[q] + threadIdx.x; i < excl_ptr[q + 1]; i += 1024) {
+      const int64_t it = excl_idx[i];
+      const int64_t slot = (it >= 0 && it < n_items) ? topn_row_slot(it, tile_stride) : -1;
+      if (slot >= 0) row[slot] = -__builtin_huge_valf();
+    }
+  __threadfence_block();
+  __syncthreads();
   float best = -__builtin_huge_valf();
   for (int64_t i = threadIdx.x; i < n_row; i += 1024) best = fmaxf(best, row[i]);   // NaN lower bounds are dropped by fmaxf
   const uint32_t key = score_key(best);
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(1024) void topn_threshold_kernel(const float* __res
 // pairs[q][p] = (score key << 32) | ~item for p < min(count[q], cap), 0 for a candidate that is a known / excluded item
 // of the query (RecommendIterator.java:75-82).  One thread per candidate.
 __global__ __launch_bounds__(256) void topn_rescore_kernel(const float* __restrict__ Y, int k, const float* __restrict__ vecs,
-                                                           const int32_t* __restrict__ vptr, const unsigned* __restrict__ count, int cap,
+                                                           const int64_t* __restrict__ vrow, const int32_t* __restrict__ vptr, const unsigned* __restrict__ count, int cap,
                                                            const uint32_t* __restrict__ cand, const int64_t* __restrict__ row_ptr,
                                                            const int32_t* __restrict__ col, const int64_t* __restrict__ query_row,
                                                            const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx,
@@ -471,7 +498,7 @@ __global__ __launch_bounds__(256) void topn_rescore_kernel(const float* __restri
     for (int64_t i = eb; i < ee; ++i) struck |= excl_idx[i] == (int64_t)it;
     uint64_t out = 0;
     if (!struck) {
-      const float sc = topn_ref_score(Y + (int64_t)it * k, vecs, vptr[q], vptr[q + 1], k);
+      const float sc = topn_ref_score(Y + (int64_t)it * k, vecs, vrow, vptr[q], vptr[q + 1], k);
       out = ((uint64_t)score_key(sc) << 32) | (uint64_t)(0xffffffffu - it);
     }
     pairs[(int64_t)q * cap + p] = out;
@@ -480,15 +507,23 @@ __global__ __launch_bounds__(256) void topn_rescore_kernel(const float* __restri
 // The N best of every query: how_many rounds of "largest remaining pair" over the query's candidates in LDS (a few
 // hundred pairs, N <= 64: cheaper than sorting them).  Pairs are unique (the item is part of them), larger = better
 // score, then lower index.  out_pairs[q][j], j < how_many: the j-th best (0 = none).
+// The pass's results in ONE block for one copy to the host: out_pairs [n_queries][how_many], then per query its
+// candidate count and tau, then the overflow word.
 __global__ __launch_bounds__(256) void topn_final_kernel(const uint64_t* __restrict__ pairs, const unsigned* __restrict__ count, int cap,
-                                                         int how_many, uint64_t* __restrict__ out_pairs, unsigned* __restrict__ count_out) {
+                                                         int how_many, uint64_t* __restrict__ out_pairs, unsigned* __restrict__ count_out,
+                                                         const float* __restrict__ tau, float* __restrict__ tau_out,
+                                                         const unsigned* __restrict__ overflow, unsigned* __restrict__ overflow_out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint64_t* a = reinterpret_cast<uint64_t*>(smem);
   __shared__ uint64_t wbest[4];
   __shared__ int wwhere[4];
   const int q = blockIdx.x;
   const unsigned cq = count[(size_t)q * TOPN_COUNT_STRIDE];
-  if (threadIdx.x == 0) count_out[q] = cq;
+  if (threadIdx.x == 0) {
+    count_out[q] = cq;
+    tau_out[q] = tau[q];
+    if (q == 0) *overflow_out = *overflow;
+  }
   const int n = (int)(cq < (unsigned)cap ? cq : (unsigned)cap);
   for (int i = threadIdx.x; i < n; i += 256) a[i] = pairs[(int64_t)q * cap + i];
   __syncthreads();
@@ -536,8 +571,8 @@ __global__ __launch_bounds__(256) void topn_final_kernel(const uint64_t* __restr
 // scores[q][i] for a 64-item tile per workgroup: the tile's rows are staged in LDS (coalesced), wave w takes the queries
 // w, w + 4, ...: lane = item, the query's vectors are read with wave-uniform addresses.
 __global__ __launch_bounds__(256) void topn_exact_dense_kernel(const float* __restrict__ Y, int64_t n_items, int k,
-                                                               const float* __restrict__ vecs, const int32_t* __restrict__ vptr,
-                                                               int n_queries, float* __restrict__ scores) {
+                                                               const float* __restrict__ vecs, const int64_t* __restrict__ vrow,
+                                                               const int32_t* __restrict__ vptr, int n_queries, float* __restrict__ scores) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   float* ys = reinterpret_cast<float*>(smem);  // [64][k + 1]
   const int pitch = k + 1;
@@ -551,7 +586,7 @@ __global__ __launch_bounds__(256) void topn_exact_dense_kernel(const float* __re
       const float* y = ys + lane * pitch;
       for (int q = w; q < n_queries; q += 4) {
         const int v0 = __builtin_amdgcn_readfirstlane(vptr[q]), v1 = __builtin_amdgcn_readfirstlane(vptr[q + 1]);
-        scores[(int64_t)q * n_items + i0 + lane] = topn_ref_score(y, vecs, v0, v1, k);
+        scores[(int64_t)q * n_items + i0 + lane] = topn_ref_score(y, vecs, vrow, v0, v1, k);
       }
     }
   }
