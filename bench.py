@@ -445,22 +445,23 @@ def main():
             tally[kk][1] += stt[kk + "_ms"]
     add_tally(core.stats())
     core.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    als.iterate(args.steps, check=False)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    core.check()
-    st = core.stats()
-    add_tally(st)
-    # the same loop with the status check of every half-iteration INSIDE the timed region (mals_check: one D2H of the
-    # bad-row / suspect words + a stream sync per half, what mals_factorize and the group path always pay; ALS:346-361)
-    core.reset_stats()       # (st above keeps the timed region's tallies)
+    # THE timed region: K steps with the status check of every half-iteration inside (mals_check: one D2H of the bad-row /
+    # suspect words + a stream sync per half -- what mals_factorize and the group path always pay; ALS:346-361)
     barrier()
     t0 = time.perf_counter()
     als.iterate(args.steps, check=True)
     barrier()
+    elapsed = time.perf_counter() - t0
+    st = core.stats()
+    add_tally(st)
+    # the same K steps again without the per-half check (a diagnostic: what the check costs)
+    core.reset_stats()       # (st above keeps the timed region's tallies)
+    barrier()
+    t0 = time.perf_counter()
+    als.iterate(args.steps, check=False)
+    barrier()
     elapsed_chk = time.perf_counter() - t0
+    core.check()
     add_tally(core.stats())
     core.enable_timing(False)
     gscale = core.gather_scale()
@@ -573,13 +574,16 @@ def main():
             "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            # the same K steps again with mals_check after every half-iteration inside the timed region
-            "ms_per_step_with_check": 1e3 * elapsed_chk / args.steps,
-            "value_with_check": (n_users + n_items) / (elapsed_chk / args.steps),
+            # (value / ms_per_step include mals_check after every half-iteration; the same K steps again without it:)
+            "ms_per_step_without_check": 1e3 * elapsed_chk / args.steps,
+            "value_without_check": (n_users + n_items) / (elapsed_chk / args.steps),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            # the arithmetic type of the path: factors are fp32 like the reference's; above 16 features the per-row Gramian
+            # takes its operands split into two f16 halves (22 significand bits, exact products) and accumulates in fp32;
+            # `roofline_fp32` below is the same workload with fp32 products end to end (--gramian-mode fp32)
+            "dtype": ("f32 storage; per-row Gramian: f16x2-split operands (22 bits), f32 accumulate; Cholesky f32" if split else "f32"),
             "data": "synthetic",
             "config": {"workload": desc, "users": n_users, "items": n_items, "nnz": int(prob["nnz"]), "features": k, "planted": prob.get("planted"),
                        "alpha": 1.0, "lambda": 0.1,

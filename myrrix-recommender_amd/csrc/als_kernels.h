@@ -2053,10 +2053,15 @@ __global__ __launch_bounds__(256) void gramian_ref_kernel(const float* __restric
 // the rows after it a few low bits relative to sums it already dominates.
 // Layout: lane (g,c) holds, for rows r0 + 4g + s (s = 0..3) and every 16-block v, feature 16v + c -- the A and the B
 // operand of the instruction at once (contraction over the 16 rows of the step).
+// E = rows per lane and step (a step = 4 E rows = one MFMA contraction): 8 -> v_mfma_f32_16x16x32_f16 for T <= 4 (both
+// instructions take 16 cycles, so the x32 one halves the matrix-pipe time, and the per-step maximum / rescale logic runs half
+// as often; round 5), 4 -> v_mfma_f32_16x16x16_f16 where two buffers of 8 raw rows per tile do not fit next to the accumulators
+// (T = 6 spilled 188 bytes with E = 8).
 template <int T>
 __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __restrict__ M, int64_t n_rows, int k,
                                                                int64_t rows_per_slab, float* __restrict__ partial,
                                                                unsigned* __restrict__ ymax) {
+  constexpr int E = T <= 4 ? 8 : 4, STEP = 4 * E;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const int64_t slab = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t r0 = slab * rows_per_slab;
@@ -2070,10 +2075,10 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
   // Loads ahead of their use (until round 4 a step waited for its own loads: 8 waves x 4 KB per CU in flight, 4.6 TB/s): a step's
   // raw registers are reloaded as soon as it has converted them, under its matrix instructions.  Steps past the end of the
   // slab read clamped rows and contribute zeros.
-  auto load_step = [&](int64_t r, float (&raw)[T][4]) {
+  auto load_step = [&](int64_t r, float (&raw)[T][E]) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int64_t row = r + 4 * g + s4;
+    for (int s4 = 0; s4 < E; ++s4) {
+      const int64_t row = r + E * g + s4;
       const float* p = M + (row < r1 ? row : r0) * k;
 #pragma unroll
       for (int v = 0; v < T; ++v) {
@@ -2082,11 +2087,11 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
       }
     }
   };
-  auto do_step = [&](int64_t r, float (&raw)[T][4], int64_t reload) {
+  auto do_step = [&](int64_t r, float (&raw)[T][E], int64_t reload) {
     float amax = 0.f;
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const bool ok = r + 4 * g + s4 < r1;
+    for (int s4 = 0; s4 < E; ++s4) {
+      const bool ok = r + E * g + s4 < r1;
 #pragma unroll
       for (int v = 0; v < T; ++v) {
         if (!(ok && 16 * v + c < k)) raw[v][s4] = 0.f;
@@ -2113,15 +2118,16 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
     }
     const int pwc = pw == 100 ? 0 : (pw < -100 ? -100 : (pw > 100 ? 100 : pw));
     const float sc = __int_as_float((pwc + 127) << 23);
-    ZOp<4> zh[T], zl[T];
+    ZOp<E> zh[T], zl[T];
 #pragma unroll
     for (int v = 0; v < T; ++v) {
-      const float z0 = raw[v][0] * sc, z1 = raw[v][1] * sc, z2 = raw[v][2] * sc, z3 = raw[v][3] * sc;
-      const int h01 = pk_rn16(z0, z1), h23 = pk_rn16(z2, z3);
-      zh[v].r[0] = h01;
-      zh[v].r[1] = h23;
-      zl[v].r[0] = pk_rn16(residual_lo(h01, z0), residual_hi(h01, z1));
-      zl[v].r[1] = pk_rn16(residual_lo(h23, z2), residual_hi(h23, z3));
+#pragma unroll
+      for (int pr = 0; pr < E / 2; ++pr) {
+        const float z0 = raw[v][2 * pr] * sc, z1 = raw[v][2 * pr + 1] * sc;
+        const int h01 = pk_rn16(z0, z1);
+        zh[v].r[pr] = h01;
+        zl[v].r[pr] = pk_rn16(residual_lo(h01, z0), residual_hi(h01, z1));
+      }
     }
     // the raw registers are free: the step after the next (T <= 6: two buffers) or the next one (T = 7, 8: one buffer, the
     // accumulators leave no room for a second) is requested now and lands during the 3 tri(T) matrix instructions below
@@ -2131,28 +2137,28 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
-      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<4>(zh[i], zh[j], acc[tidx(T, i, j)]);
+      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<E>(zh[i], zh[j], acc[tidx(T, i, j)]);
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
-      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<4>(zh[i], zl[j], acc[tidx(T, i, j)]);
+      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<E>(zh[i], zl[j], acc[tidx(T, i, j)]);
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
-      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<4>(zl[i], zh[j], acc[tidx(T, i, j)]);
+      for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<E>(zl[i], zh[j], acc[tidx(T, i, j)]);
   };
   if constexpr (T <= 6) {
-    float ra[T][4], rb[T][4];
+    float ra[T][E], rb[T][E];
     load_step(r0, ra);
-    load_step(r0 + 16, rb);
-    for (int64_t r = r0; r < r1; r += 32) {
-      do_step(r, ra, r + 32);
-      do_step(r + 16, rb, r + 48);
+    load_step(r0 + STEP, rb);
+    for (int64_t r = r0; r < r1; r += 2 * STEP) {
+      do_step(r, ra, r + 2 * STEP);
+      do_step(r + STEP, rb, r + 3 * STEP);
     }
   } else {
-    float ra[T][4];
+    float ra[T][E];
     load_step(r0, ra);
-    for (int64_t r = r0; r < r1; r += 16) do_step(r, ra, r + 16);
+    for (int64_t r = r0; r < r1; r += STEP) do_step(r, ra, r + STEP);
   }
   int d2 = pw == 100 ? 0 : -2 * pw;
   d2 = d2 < -126 ? -126 : (d2 > 126 ? 126 : d2);
