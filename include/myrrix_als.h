@@ -319,6 +319,11 @@ int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, in
 int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_queries, int32_t how_many,
                            const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
                            int32_t* n_out);
+/* knownItemIDs for mals_recommend (ServerRecommender.java:394-425 takes them from generation.getKnownItemIDs(), which
+ * differ from the rows of R by the entries InputFilesReader.removeSmall pruned): a CSR over the handle's local user rows
+ * (n_rows = the local rows of side X) of dense item indices.  MALS_MEM_DEVICE arrays are borrowed, host arrays copied.
+ * row_ptr NULL: back to the rows of R.  mals_ingest_install hands them over when the ingest built them. */
+int mals_set_known_items(mals_handle h, int64_t n_rows, const int64_t* row_ptr, const int32_t* item_idx, int mem_kind);
 /* ... and for queries of SEVERAL vectors each -- recommendToMany (ServerRecommender.java:366-441: the feature
  * vectors of all the users asked for; the caller passes the intersection of their known items, :398-425, as the
  * exclusion list): query q owns vectors[vector_ptr[q] .. vector_ptr[q+1]) (rows of `vectors`, features floats

@@ -145,6 +145,7 @@ SYMBOLS = {
     "mals_reconstruction_error": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64)]),
     "mals_recommend": (ctypes.c_int, [_H, _P, _I32, _I32, _I32, _P, _P, _P]),
     "mals_recommend_vectors": (ctypes.c_int, [_H, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "mals_set_known_items": (ctypes.c_int, [_H, _I64, _P, _P, ctypes.c_int]),
     "mals_recommend_to_many": (ctypes.c_int, [_H, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "mals_ingest_create": (ctypes.c_int, [_I32, ctypes.c_float, ctypes.POINTER(_H)]),
     "mals_ingest_destroy": (ctypes.c_int, [_H]),

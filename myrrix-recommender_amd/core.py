@@ -356,6 +356,15 @@ class ALSCore:
                                                  cnt.ctypes.data_as(ctypes.c_void_p)))
         return idx, sc, cnt
 
+    def set_known_items(self, row_ptr, item_idx):
+        """knownItemIDs as a CSR over the local user rows (generation.getKnownItemIDs()); None, None: back to the rows of R."""
+        if row_ptr is None:
+            self._chk(self._L.mals_set_known_items(self._h, 0, None, None, MEM_HOST))
+            return
+        rp = _host(row_ptr, np.int64)
+        ii = _host(item_idx, np.int32)
+        self._chk(self._L.mals_set_known_items(self._h, len(rp) - 1, rp.ctypes.data_as(ctypes.c_void_p), ii.ctypes.data_as(ctypes.c_void_p), MEM_HOST))
+
     def recommend_to_many(self, queries, how_many, exclude=None):
         """recommendToMany (ServerRecommender.java:366-441): queries = list of (n_j x features) arrays, one per query; the
         score of an item is the mean of its dots with the query's vectors (RecommendIterator.java:93-104)."""

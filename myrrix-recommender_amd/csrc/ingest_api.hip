@@ -545,6 +545,10 @@ int mals_ingest_install(mals_ingest g, mals_handle h) {
     return fail(g, rc, mals_last_error(h));
   if (int rc = mals_set_matrix(h, MALS_SIDE_Y, 0, g->n_items, g->nnz, g->ptr[1], g->col[1], g->val[1], MALS_MEM_DEVICE))
     return fail(g, rc, mals_last_error(h));
+  // knownItemIDs, if they were asked for: what mals_recommend skips (ServerRecommender.java:394-425), entries that
+  // removeSmall pruned from R included
+  if (g->known_ptr)
+    if (int rc = mals_set_known_items(h, g->n_users, g->known_ptr, g->known_idx, MALS_MEM_DEVICE)) return fail(g, rc, mals_last_error(h));
   return MALS_OK;
 }
 

@@ -198,6 +198,12 @@ struct mals_handle_s {
   std::vector<PendingEvent> pending;
   unsigned long long* d_trace = nullptr;  // MALS_DEBUG_TRACE
   void* tn_ws = nullptr;  // top-N workspace (topn_host.h), grow-only
+  // knownItemIDs (mals_set_known_items): what mals_recommend skips instead of the rows of R when present
+  const int64_t* known_ptr = nullptr;
+  const int32_t* known_idx = nullptr;
+  int64_t known_rows = 0;
+  int64_t* known_ptr_own = nullptr;   // copies of host arrays
+  int32_t* known_idx_own = nullptr;
   double* d_sd = nullptr;       // mals_sample_dots: estimates, indices
   int64_t* d_sd_idx = nullptr;
   size_t sd_cap = 0, sd_idx_cap = 0;
@@ -1429,6 +1435,8 @@ int mals_destroy(mals_handle h) {
   free_dev(h->d_sd);
   free_dev(h->d_sd_idx);
   topn_free(h);
+  free_dev(h->known_ptr_own);
+  free_dev(h->known_idx_own);
   delete h;
   return MALS_OK;
 }
@@ -2418,7 +2426,8 @@ int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, in
   if (!x.F || !y.F || y.n_total == 0) return fail(h, MALS_INVALID_ARG, "factor replicas not available");
   if (n_queries < 0 || how_many <= 0 || how_many > 4096 || (n_queries > 0 && (!user_idx || !item_idx_out || !score_out)))
     return fail(h, MALS_INVALID_ARG, "bad recommend arguments (how_many in 1..4096)");
-  if (!consider_known_items && !x.has_matrix) return fail(h, MALS_INVALID_ARG, "the user-side matrix is needed to skip known items");
+  if (!consider_known_items && !x.has_matrix && !h->known_ptr)
+    return fail(h, MALS_INVALID_ARG, "the user-side matrix (or mals_set_known_items) is needed to skip known items");
   for (int q = 0; q < n_queries; ++q) {
     if (user_idx[q] < 0 || user_idx[q] >= x.n_total) return fail(h, MALS_INVALID_ARG, "user index outside the factor replica");
     if (!consider_known_items && (user_idx[q] < x.row_offset || user_idx[q] >= x.row_offset + x.n_local))
@@ -2434,6 +2443,36 @@ int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, in
   rq.score_out = score_out;
   rq.n_out = n_out;
   return topn_run(h, rq);
+}
+
+int mals_set_known_items(mals_handle h, int64_t n_rows, const int64_t* row_ptr, const int32_t* item_idx, int mem_kind) {
+  if (!h) return MALS_INVALID_ARG;
+  if (mem_kind != MALS_MEM_HOST && mem_kind != MALS_MEM_DEVICE) return fail(h, MALS_INVALID_ARG, "mem_kind must be MALS_MEM_HOST or MALS_MEM_DEVICE");
+  if (int rc = use_device(h)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_dev(h->known_ptr_own);
+  free_dev(h->known_idx_own);
+  h->known_ptr = nullptr;
+  h->known_idx = nullptr;
+  h->known_rows = 0;
+  if (!row_ptr) return MALS_OK;  // back to the rows of R
+  SideState& x = h->side[MALS_SIDE_X];
+  if (n_rows != x.n_local) return fail(h, MALS_INVALID_ARG, "known items: one row per local user row of side X");
+  if (mem_kind == MALS_MEM_DEVICE) {
+    h->known_ptr = row_ptr;
+    h->known_idx = item_idx;
+  } else {
+    const int64_t n = row_ptr[n_rows];
+    if (n < 0 || (n > 0 && !item_idx)) return fail(h, MALS_INVALID_ARG, "bad known-item arrays");
+    HIPCHK(h, hipMalloc(&h->known_ptr_own, sizeof(int64_t) * (size_t)(n_rows + 1)));
+    HIPCHK(h, hipMalloc(&h->known_idx_own, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1)));
+    HIPCHK(h, hipMemcpy(h->known_ptr_own, row_ptr, sizeof(int64_t) * (size_t)(n_rows + 1), hipMemcpyHostToDevice));
+    if (n) HIPCHK(h, hipMemcpy(h->known_idx_own, item_idx, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+    h->known_ptr = h->known_ptr_own;
+    h->known_idx = h->known_idx_own;
+  }
+  h->known_rows = n_rows;
+  return MALS_OK;
 }
 
 int mals_recommend_to_many(mals_handle h, const float* vectors, const int64_t* vector_ptr, int32_t n_queries, int32_t how_many,

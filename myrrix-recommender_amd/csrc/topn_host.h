@@ -193,7 +193,8 @@ int topn_pass_dense(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, cons
   hipLaunchKernelGGL(topn_exact_dense_kernel, dim3(grid), dim3(256), sizeof(float) * 64 * (size_t)(k + 1), h->stream, y.F, n_items, k, w->d_vecs,
                      w->d_vrow, w->d_vptr, nq, w->d_scores);
   if (ps.have_rows)
-    hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, x.row_ptr, x.col, w->d_rows, nq, 1, n_items, w->d_scores);
+    hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, h->known_ptr ? h->known_ptr : x.row_ptr,
+                       h->known_ptr ? h->known_idx : x.col, w->d_rows, nq, 1, n_items, w->d_scores);
   if (ps.have_excl)
     hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, w->d_excl_ptr, w->d_excl_idx, nq, n_items, 1, n_items,
                        w->d_scores);
@@ -339,6 +340,8 @@ int topn_pass_filter_enqueue(mals_handle h, TopnWorkspace* w, const TopnRequest&
   if (int rc = topn_grow(h, w->d_cand, w->cand_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.cap)) return rc;
   if (int rc = topn_grow(h, w->d_outp, w->outp_cap, p.stage_bytes)) return rc;
   const int64_t* d_rows = ps.have_rows ? w->d_rows : nullptr;
+  const int64_t* k_ptr = h->known_ptr ? h->known_ptr : x.row_ptr;   // knownItemIDs if the caller installed them, else the rows of R
+  const int32_t* k_idx = h->known_ptr ? h->known_idx : x.col;
   const int64_t* d_eptr = ps.have_excl ? w->d_excl_ptr : nullptr;
   const int64_t* d_eidx = ps.have_excl ? w->d_excl_idx : nullptr;
   // 0. the queries as matrix operands (every tile an instantiation may touch: padding queries never produce a hit)
@@ -347,14 +350,14 @@ int topn_pass_filter_enqueue(mals_handle h, TopnWorkspace* w, const TopnRequest&
   // 1. sample: lower bounds of every tile_stride-th tile; 2. threshold (known items out of the sample first)
   int n_fw = 0;
   if (int rc = topn_launch_filter_S<0>(h, p.S, nt, y.F, n_items, k, w, nq, p.tile_stride, p.n_sample, &n_fw)) return rc;
-  hipLaunchKernelGGL(topn_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, h->stream, w->d_lb, p.n_sample, how_many, x.row_ptr, x.col, d_rows, d_eptr,
+  hipLaunchKernelGGL(topn_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, h->stream, w->d_lb, p.n_sample, how_many, k_ptr, k_idx, d_rows, d_eptr,
                      d_eidx, n_items, p.tile_stride, w->d_tau);
   // 3. filter, 4. exact scores of the hits (known items dropped), 5. the N best
   if (int rc = topn_launch_filter_S<1>(h, p.S, nt, y.F, n_items, k, w, nq, 1, n_items, &n_fw)) return rc;
   hipLaunchKernelGGL(topn_scatter_kernel, dim3((unsigned)n_fw), dim3(256), 0, h->stream, w->d_wcount, w->d_whits, TOPN_WAVE_CAP, n_fw, p.cap,
                      w->d_count, w->d_cand, d_overflow);
   hipLaunchKernelGGL(topn_rescore_kernel, dim3(4, (unsigned)nq), dim3(256), 0, h->stream, y.F, k, w->d_vecs, w->d_vrow, w->d_vptr, w->d_count, p.cap,
-                     w->d_cand, x.row_ptr, x.col, d_rows, d_eptr, d_eidx, w->d_pairs);
+                     w->d_cand, k_ptr, k_idx, d_rows, d_eptr, d_eidx, w->d_pairs);
   uint8_t* o = w->d_outp;
   const size_t o_cnt = sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many, o_tau = o_cnt + sizeof(unsigned) * TOPN_FILTER_QUERIES,
                o_ovf = o_tau + sizeof(float) * TOPN_FILTER_QUERIES;

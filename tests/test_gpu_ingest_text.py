@@ -296,3 +296,40 @@ def test_big_plain_file_round_trip():
             assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1])
             assert np.array_equal(ca[2].view(np.uint32), cb[2].view(np.uint32))
         assert np.array_equal(a.ids(pkg.SIDE_X), b.ids(pkg.SIDE_X))
+
+
+def test_known_items_reach_the_recommender():
+    """generation.getKnownItemIDs() is what recommend() skips (ServerRecommender.java:394-425), and it keeps the entries
+    removeSmall pruned from R (IFR:173-211): a user's near-zero entry is not recommended back to him."""
+    from oracle import topn_oracle
+    rng = np.random.default_rng(5)
+    n_users, n_items, k = 60, 500, 8
+    lines = []
+    for u in range(n_users):
+        for i in rng.choice(n_items, 12, replace=False):
+            lines.append("%d,%d,%s" % (u, i, "0.00001" if rng.random() < 0.3 else "2"))
+    data = ("\n".join(lines) + "\n").encode()
+    want = to.expected([data])
+    (uid, rp, col, val) = want["csr_x"]
+    iid = want["csr_y"][0]
+    assert want["known_ptr"][-1] > rp[-1]                          # some known items are not entries of R any more
+    X = rng.standard_normal((len(uid), k)).astype(np.float32)
+    Y = rng.standard_normal((len(iid), k)).astype(np.float32)
+    with ingest.Ingest(0) as g, pkg.ALSCore(k) as core:
+        g.set_option(_lib.INGEST_OPT_KNOWN_ITEMS, 1)
+        g.append_text(data, True)
+        g.finish()
+        core.set_factor_rows(pkg.SIDE_X, len(uid))
+        core.set_factor_rows(pkg.SIDE_Y, len(iid))
+        g.install(core)                                            # hands knownItemIDs over too
+        core.set_factors(pkg.SIDE_X, X)
+        core.set_factors(pkg.SIDE_Y, Y)
+        users = np.arange(len(uid), dtype=np.int64)
+        idx, sc, cnt = core.recommend(users, 5)
+        for q in range(len(uid)):
+            known = want["known_idx"][want["known_ptr"][q]:want["known_ptr"][q + 1]]
+            oidx, osc = topn_oracle.recommend(Y, X[q], 5, known)
+            assert np.array_equal(idx[q], oidx) and np.array_equal(sc[q].view(np.uint32), osc.view(np.uint32))
+        core.set_known_items(None, None)                           # back to the rows of R: the pruned entries come back
+        idx2, _, _ = core.recommend(users, 5)
+        assert not np.array_equal(idx, idx2)
