@@ -141,33 +141,35 @@ int scan_u32(mals_ingest g, Scratch& s, const unsigned* in, unsigned* out, int64
 }
 
 // Stable LSD radix sort of (keys[0], pay[0]) by the key digits >= first_digit; *result = index of the
-// buffer pair holding the sorted data.  Digits on which all keys agree are skipped.
-template <typename P>
-int radix_sort(mals_ingest g, Scratch& s, P* const (&pay)[2], int64_t n, int* result, int first_digit = 0) {
+// buffer pair holding the sorted data.  Digits on which all keys agree are skipped.  K = uint32_t when the caller knows
+// that every key fits (ids below 2^32): 12 bytes less per record and pass, and a third workgroup per CU (LDS).
+template <typename K, typename P>
+int radix_sort(mals_ingest g, Scratch& s, K* const (&keys)[2], P* const (&pay)[2], int64_t n, int* result, int first_digit = 0) {
+  constexpr int ND = (int)sizeof(K);
   *result = 0;
   if (n <= 1) return MALS_OK;
   ICHK(g, hipMemsetAsync(s.digit_tot, 0, 8 * 256 * sizeof(unsigned long long), g->stream));
-  hipLaunchKernelGGL(rs_digit_totals_kernel, dim3(blocks_for(n, 256 * 16, 4096)), dim3(256), 0, g->stream, s.keys[0], n, s.digit_tot);
+  hipLaunchKernelGGL(rs_digit_totals_kernel<K>, dim3(blocks_for(n, 256 * 16, 4096)), dim3(256), 0, g->stream, keys[0], n, s.digit_tot);
   ICHK(g, hipGetLastError());
   std::vector<unsigned long long> tot(8 * 256);
   ICHK(g, hipMemcpyAsync(tot.data(), s.digit_tot, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream));
   ICHK(g, hipStreamSynchronize(g->stream));
-  g->bytes_moved += 8.0 * (double)n;
+  g->bytes_moved += (double)sizeof(K) * (double)n;
   const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
   const unsigned grid = (unsigned)n_blocks;
   int cur = 0;
-  for (int d = first_digit; d < 8; ++d) {
+  for (int d = first_digit; d < ND; ++d) {
     bool trivial = false;
     for (int b = 0; b < 256; ++b)
       if (tot[(size_t)d * 256 + b] == (unsigned long long)n) trivial = true;
     if (trivial) continue;
-    hipLaunchKernelGGL(rs_histogram_kernel, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], n, 8 * d, n_blocks, s.counts);
+    hipLaunchKernelGGL(rs_histogram_kernel<K>, dim3(grid), dim3(256), 0, g->stream, keys[cur], n, 8 * d, n_blocks, s.counts);
     ICHK(g, hipGetLastError());
     if (int rc = scan_u32(g, s, s.counts, s.counts, 256 * n_blocks, nullptr)) return rc;
-    hipLaunchKernelGGL(rs_scatter_kernel<P>, dim3(grid), dim3(256), 0, g->stream, s.keys[cur], pay[cur], n, 8 * d, n_blocks,
-                       s.counts, s.keys[1 - cur], pay[1 - cur]);
+    hipLaunchKernelGGL((rs_scatter_kernel<K, P>), dim3(grid), dim3(256), 0, g->stream, keys[cur], pay[cur], n, 8 * d, n_blocks,
+                       s.counts, keys[1 - cur], pay[1 - cur]);
     ICHK(g, hipGetLastError());
-    g->bytes_moved += (8.0 + 2.0 * (8.0 + sizeof(P))) * (double)n;  // histogram read; scatter read + write
+    g->bytes_moved += ((double)sizeof(K) + 2.0 * ((double)sizeof(K) + sizeof(P))) * (double)n;  // histogram read; scatter read + write
     ++g->radix_passes;
     cur = 1 - cur;
   }
@@ -287,6 +289,67 @@ static int alloc_results(mals_ingest g, unsigned n_users, unsigned n_items, unsi
   return MALS_OK;
 }
 
+// what finish_impl shares with its two sort stages
+struct FinishTmp {  // small per-finish device temporaries (sized by the number of distinct ids)
+  unsigned *head = nullptr, *scan = nullptr, *ri = nullptr, *keep = nullptr, *present = nullptr;  // arena
+  float* pair_val = nullptr;                                                   // arena
+  int32_t* coo_row = nullptr;                                                  // arena
+  unsigned *alive_u = nullptr, *alive_i = nullptr, *new_u = nullptr, *new_i = nullptr;
+  int64_t *uid_all = nullptr, *iid_all = nullptr;
+  ~FinishTmp() {
+    dfree(alive_u); dfree(alive_i); dfree(new_u); dfree(new_i); dfree(uid_all); dfree(iid_all);
+  }
+};
+
+// 1. records sorted by item id (stable: stream order inside an item); dense item rank of every position
+template <typename K>
+static int stage_items(mals_ingest g, Scratch& s, FinishTmp& t, int64_t n, bool user32, int* ra_out, unsigned* n_i_all) {
+  K* const kb[2] = {reinterpret_cast<K*>(s.keys[0]), reinterpret_cast<K*>(s.keys[1])};
+  if (user32)
+    hipLaunchKernelGGL((item_stage_kernel<K, true>), dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_item, g->d_user, g->d_value, n, kb[0], s.pay64[0]);
+  else
+    hipLaunchKernelGGL((item_stage_kernel<K, false>), dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_item, g->d_user, g->d_value, n, kb[0], s.pay64[0]);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += (12.0 + (user32 ? 8.0 : 0.0) + sizeof(K) + 8.0) * (double)n;
+  int ra = 0;
+  if (int rc = radix_sort<K, uint64_t>(g, s, kb, s.pay64, n, &ra)) return rc;
+  hipLaunchKernelGGL(heads_kernel<K>, dim3(blocks_for(n)), dim3(256), 0, g->stream, kb[ra], n, t.head);
+  ICHK(g, hipGetLastError());
+  if (int rc = scan_u32(g, s, t.head, t.scan, n, n_i_all)) return rc;
+  ICHK(g, hipMalloc(&t.iid_all, sizeof(int64_t) * (size_t)*n_i_all));
+  hipLaunchKernelGGL(position_ranks_kernel<K>, dim3(blocks_for(n)), dim3(256), 0, g->stream, kb[ra], t.head, t.scan, n, t.ri, t.iid_all);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += (sizeof(K) + 4.0 + sizeof(K) + 8.0 + 4.0) * (double)n;
+  *ra_out = ra;
+  return MALS_OK;
+}
+
+// 2. ... then by user id (stable again): the records are now ordered by (user, item, stream order) -- one sort of the
+//    composite key in two stable stages, with the item rank and the value riding along; 3. pair keys
+//    (user rank << 32 | item rank) and values in that order.  *r_out = the key buffer that holds the pair keys.
+template <typename K>
+static int stage_users(mals_ingest g, Scratch& s, FinishTmp& t, int64_t n, int ra, float* sorted_val, int* r_out, unsigned* n_u_all) {
+  constexpr bool USER32 = sizeof(K) == 4;
+  K* const kb[2] = {reinterpret_cast<K*>(s.keys[0]), reinterpret_cast<K*>(s.keys[1])};
+  // (reads pay64[ra][i] and writes pay64[0][i]: the same thread, the same index -- safe when ra == 0)
+  hipLaunchKernelGGL((user_stage_kernel<K, USER32>), dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_user, s.pay64[ra], t.ri, n, kb[0], s.pay64[0]);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += (8.0 + 4.0 + (USER32 ? 0.0 : 8.0) + sizeof(K) + 8.0) * (double)n;
+  int rb = 0;
+  if (int rc = radix_sort<K, uint64_t>(g, s, kb, s.pay64, n, &rb)) return rc;
+  hipLaunchKernelGGL(heads_kernel<K>, dim3(blocks_for(n)), dim3(256), 0, g->stream, kb[rb], n, t.head);
+  ICHK(g, hipGetLastError());
+  if (int rc = scan_u32(g, s, t.head, t.scan, n, n_u_all)) return rc;
+  ICHK(g, hipMalloc(&t.uid_all, sizeof(int64_t) * (size_t)*n_u_all));
+  const int r = 1 - rb;  // the other key buffer is free now
+  hipLaunchKernelGGL(pair_from_sorted_kernel<K>, dim3(blocks_for(n)), dim3(256), 0, g->stream, kb[rb], s.pay64[rb], t.head, t.scan, n, s.keys[r],
+                     sorted_val, t.uid_all);
+  ICHK(g, hipGetLastError());
+  g->bytes_moved += (sizeof(K) + 4.0 + sizeof(K) + 8.0 + 4.0 + 4.0 + 8.0 + 4.0) * (double)n;
+  *r_out = r;
+  return MALS_OK;
+}
+
 static int finish_impl(mals_ingest g, hipEvent_t e0) {
   const int64_t n = g->n;
   if (n == 0) {
@@ -301,16 +364,7 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
     }
     return MALS_OK;
   }
-  struct Tmp {  // small per-finish device temporaries (sized by the number of distinct ids)
-    unsigned *head = nullptr, *scan = nullptr, *ri = nullptr, *keep = nullptr, *present = nullptr;  // arena
-    float* pair_val = nullptr;                                                   // arena
-    int32_t* coo_row = nullptr;                                                  // arena
-    unsigned *alive_u = nullptr, *alive_i = nullptr, *new_u = nullptr, *new_i = nullptr;
-    int64_t *uid_all = nullptr, *iid_all = nullptr;
-    ~Tmp() {
-      dfree(alive_u); dfree(alive_i); dfree(new_u); dfree(new_i); dfree(uid_all); dfree(iid_all);
-    }
-  } t;
+  FinishTmp t;
   Scratch s;
   unsigned n_u_all = 0, n_i_all = 0, n_users = 0, n_items = 0, nnz = 0;
   const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
@@ -350,38 +404,23 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
     t.present = g->want_known ? (unsigned*)((char*)s.pay64[1] + k4) : nullptr;  // coo_row needs 4 bytes per entry at most
   }
   ICHK(g, hipEventRecord(e0, g->stream));  // the pipeline proper starts here
-  // 1. records sorted by item id (stable: stream order inside an item); dense item rank of every position
-  hipLaunchKernelGGL(item_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_item, g->d_value, n, s.keys[0], s.pay64[0]);
-  ICHK(g, hipGetLastError());
-  g->bytes_moved += 28.0 * (double)n;
+  // 0. do the ids fit 32 bits?  Then the sorts run on 32-bit keys, and the user ids ride through the first sort so that
+  //    nothing has to be gathered by record index
+  ICHK(g, hipMemsetAsync(s.digit_tot, 0, 2 * sizeof(unsigned long long), g->stream));
+  hipLaunchKernelGGL(ids_high_bits_kernel, dim3(blocks_for(n, 256, 8192)), dim3(256), 0, g->stream, g->d_user, n, s.digit_tot);
+  hipLaunchKernelGGL(ids_high_bits_kernel, dim3(blocks_for(n, 256, 8192)), dim3(256), 0, g->stream, g->d_item, n, s.digit_tot + 1);
+  unsigned long long high[2] = {1, 1};
+  ICHK(g, hipMemcpyAsync(high, s.digit_tot, sizeof(high), hipMemcpyDeviceToHost, g->stream));
+  ICHK(g, hipStreamSynchronize(g->stream));
+  const bool narrow = !std::getenv("MALS_INGEST_WIDE_KEYS");   // A/B and test switch
+  const bool user32 = high[0] == 0 && narrow, item32 = high[1] == 0 && narrow;
+  g->bytes_moved += 16.0 * (double)n;
   int ra = 0;
-  if (int rc = radix_sort(g, s, s.pay64, n, &ra)) return rc;
-  hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[ra], n, t.head);
-  ICHK(g, hipGetLastError());
-  if (int rc = scan_u32(g, s, t.head, t.scan, n, &n_i_all)) return rc;
-  ICHK(g, hipMalloc(&t.iid_all, sizeof(int64_t) * (size_t)n_i_all));
-  hipLaunchKernelGGL(position_ranks_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[ra], t.head, t.scan, n, t.ri,
-                     t.iid_all);
-  // 2. ... then by user id (stable again): the records are now ordered by (user, item, stream order) --
-  //    one sort of the composite key, with the item rank and the record index riding along
-  // (reads pay64[ra][i] and writes pay64[0][i]: the same thread, the same index -- safe when ra == 0)
-  hipLaunchKernelGGL(user_stage_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_user, s.pay64[ra], t.ri, n, s.keys[0],
-                     s.pay64[0]);
-  ICHK(g, hipGetLastError());
-  g->bytes_moved += (12.0 + 4.0 + 12.0 + 8.0 + 8.0 + 4.0 + 16.0) * (double)n;
-  int rb = 0;
-  if (int rc = radix_sort(g, s, s.pay64, n, &rb)) return rc;
-  hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[rb], n, t.head);
-  ICHK(g, hipGetLastError());
-  if (int rc = scan_u32(g, s, t.head, t.scan, n, &n_u_all)) return rc;
-  ICHK(g, hipMalloc(&t.uid_all, sizeof(int64_t) * (size_t)n_u_all));
-  // 3. pair keys (user rank << 32 | item rank) and record indices in that order
-  const int r = 1 - rb;  // the other key buffer is free now
+  if (int rc = item32 ? stage_items<uint32_t>(g, s, t, n, user32, &ra, &n_i_all) : stage_items<uint64_t>(g, s, t, n, user32, &ra, &n_i_all)) return rc;
   float* sorted_val = reinterpret_cast<float*>(s.pay[0]);
-  hipLaunchKernelGGL(pair_from_sorted_kernel, dim3(blocks_for(n)), dim3(256), 0, g->stream, s.keys[rb], s.pay64[rb], t.head, t.scan, n,
-                     s.keys[r], sorted_val, t.uid_all);
-  ICHK(g, hipGetLastError());
-  g->bytes_moved += (12.0 + 4.0 + 16.0 + 8.0 + 12.0) * (double)n;
+  int r = 0;
+  if (int rc = user32 ? stage_users<uint32_t>(g, s, t, n, ra, sorted_val, &r, &n_u_all) : stage_users<uint64_t>(g, s, t, n, ra, sorted_val, &r, &n_u_all))
+    return rc;
   // 4. replay every pair's records in order
   ICHK(g, hipMalloc(&t.alive_u, sizeof(unsigned) * (size_t)n_u_all));
   ICHK(g, hipMalloc(&t.alive_i, sizeof(unsigned) * (size_t)n_i_all));
@@ -433,7 +472,7 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
     ICHK(g, hipGetLastError());
     g->bytes_moved += 24.0 * (double)nnz;
     int r2 = 0;
-    if (int rc = radix_sort(g, s, s.pay, (int64_t)nnz, &r2, 4)) return rc;
+    if (int rc = radix_sort<uint64_t, unsigned>(g, s, s.keys, s.pay, (int64_t)nnz, &r2, 4)) return rc;
     hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], (int64_t)nnz,
                        t.coo_row, g->col[1], g->val[1]);
     ICHK(g, hipGetLastError());
@@ -450,8 +489,8 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
     hipLaunchKernelGGL(ids_to_keys_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, g->d_tags[which], nt, s.keys[0], s.pay[0]);
     ICHK(g, hipGetLastError());
     int rt = 0;
-    if (int rc = radix_sort(g, s, s.pay, nt, &rt)) return rc;
-    hipLaunchKernelGGL(heads_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, s.keys[rt], nt, t.head);
+    if (int rc = radix_sort<uint64_t, unsigned>(g, s, s.keys, s.pay, nt, &rt)) return rc;
+    hipLaunchKernelGGL(heads_kernel<uint64_t>, dim3(blocks_for(nt)), dim3(256), 0, g->stream, s.keys[rt], nt, t.head);
     ICHK(g, hipGetLastError());
     unsigned n_unique = 0;
     if (int rc = scan_u32(g, s, t.head, t.scan, nt, &n_unique)) return rc;
