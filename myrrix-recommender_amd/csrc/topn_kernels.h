@@ -277,26 +277,28 @@ __global__ __launch_bounds__(256) void topn_filter_kernel(const float* __restric
         }
     }
     f32x4t acc[U][NT];
-    bf16x8 b = bq[lane];  // the operand of step (t = 0, s = 0); the next one is fetched while this one is multiplied
+    // The B operands come from LDS one step ahead, into two alternating register sets, pinned with scheduling barriers:
+    // left to itself the compiler reloads ONE register set right before its use and waits out the LDS latency in front of
+    // every group of matrix instructions (lgkmcnt(0) 45 times per tile pair: the matrix pipe idled half the time).
+    bf16x8 bb[2];
+    bb[0] = bq[lane];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int j = 0; j < NT * (S + 1); ++j) {
+      const int t = j / (S + 1), s = j % (S + 1);
+      if (j + 1 < NT * (S + 1)) bb[(j + 1) & 1] = bq[(j + 1) * 64 + lane];
+      __builtin_amdgcn_sched_barrier(0);
+      const bf16x8 b = bb[j & 1];
 #pragma unroll
-      for (int u = 0; u < U; ++u) acc[u][t] = f32x4t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s <= S; ++s) {
-        const int nxt = t * (S + 1) + s + 1;
-        const bf16x8 bn = bq[(nxt < NT * (S + 1) ? nxt : 0) * 64 + lane];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (s < S) {
-            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][s], b, acc[u][t], 0, 0, 0);
-            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u][s], b, acc[u][t], 0, 0, 0);
-          } else {
-            acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[u], b, acc[u][t], 0, 0, 0);
-          }
+      for (int u = 0; u < U; ++u) {
+        if (s == 0) acc[u][t] = f32x4t{0.f, 0.f, 0.f, 0.f};
+        if (s < S) {
+          acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][s], b, acc[u][t], 0, 0, 0);
+          acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u][s], b, acc[u][t], 0, 0, 0);
+        } else {
+          acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[u], b, acc[u][t], 0, 0, 0);
         }
-        b = bn;
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // D layout: lane (g, c) register r = D[row 4 g + r][col c]: item 4 g + r of the tile, query 16 (t_base + t) + c
 #pragma unroll
