@@ -8,6 +8,7 @@
 // Only the solver state of Generation is mirrored; candidate filters, known-item maps, clusters and
 // locks are serving-plane state (out of scope).  Header-only, C++17.
 #pragma once
+#include <ios>
 #include <memory>
 
 #include "factorizer.hpp"
@@ -128,5 +129,67 @@ class Generation {
   int device_;
   std::unique_ptr<Solver> XTXsolver_, YTYsolver_;
 };
+
+// InputFilesReader.readInputFiles (online-local/.../generation/InputFilesReader.java:64-211) on the device: everything
+// the reference leaves behind after reading `inputDir` -- ids, R by user and by item as CSR over dense indices, the two
+// tag id sets, knownItemIDs (absent under model.noKnownItems) -- through mals_ingest_read_dir / _finish.  Throws
+// std::ios_base::failure where the reference throws IOException ("Too many bad lines; aborting", unreadable file).
+struct InputMatrices {
+  std::vector<int64_t> userIDs, itemIDs;                  // dense index -> id, ascending
+  std::vector<int64_t> rowPtr[2];                         // [0]: R by user, [1]: R^T by item
+  std::vector<int32_t> colIdx[2];
+  std::vector<float> values[2];
+  std::vector<int64_t> itemTagIDs, userTagIDs;            // IFR:159-165
+  bool hasKnownItems = false;
+  std::vector<int64_t> knownPtr;                          // knownItemIDs over the dense users (IFR:173-191)
+  std::vector<int32_t> knownItems;
+  int64_t lines = 0, badLines = 0;
+};
+
+inline InputMatrices readInputFiles(const std::string& inputDir, int device = 0, float zeroThreshold = 1.0e-4f, bool knownItems = true) {
+  mals_ingest g = nullptr;
+  if (mals_ingest_create(device, zeroThreshold, &g) != MALS_OK) throw std::runtime_error("mals_ingest_create failed: a HIP device is required");
+  struct Guard {
+    mals_ingest g;
+    ~Guard() { mals_ingest_destroy(g); }
+  } guard{g};
+  auto ok = [&](int rc) {
+    if (rc == MALS_IO_ERROR) throw std::ios_base::failure(mals_ingest_last_error(g));
+    if (rc != MALS_OK) throw std::runtime_error(mals_ingest_last_error(g));
+  };
+  if (knownItems) ok(mals_ingest_set_option(g, MALS_INGEST_OPT_KNOWN_ITEMS, 1));
+  int32_t files = 0;
+  ok(mals_ingest_read_dir(g, inputDir.c_str(), &files));
+  ok(mals_ingest_finish(g));
+  InputMatrices m;
+  int64_t records = 0, users = 0, items = 0, nnz = 0;
+  ok(mals_ingest_counts(g, &records, &users, &items, &nnz));
+  m.userIDs.resize((size_t)users);
+  m.itemIDs.resize((size_t)items);
+  ok(mals_ingest_get_ids(g, MALS_SIDE_X, m.userIDs.data()));
+  ok(mals_ingest_get_ids(g, MALS_SIDE_Y, m.itemIDs.data()));
+  for (int side = 0; side < 2; ++side) {
+    m.rowPtr[side].resize((size_t)(side == 0 ? users : items) + 1);
+    m.colIdx[side].resize((size_t)nnz);
+    m.values[side].resize((size_t)nnz);
+    ok(mals_ingest_get_csr(g, side, m.rowPtr[side].data(), m.colIdx[side].data(), m.values[side].data()));
+  }
+  mals_ingest_text_info_t info;
+  info.struct_size = (int32_t)sizeof(info);
+  ok(mals_ingest_text_info(g, &info));
+  m.lines = info.lines;
+  m.badLines = info.bad_lines;
+  m.itemTagIDs.resize((size_t)info.n_item_tag_ids);
+  m.userTagIDs.resize((size_t)info.n_user_tag_ids);
+  ok(mals_ingest_get_tag_ids(g, MALS_ITEM_TAG_IDS, m.itemTagIDs.data()));
+  ok(mals_ingest_get_tag_ids(g, MALS_USER_TAG_IDS, m.userTagIDs.data()));
+  if (knownItems) {
+    m.hasKnownItems = true;
+    m.knownPtr.resize((size_t)users + 1);
+    m.knownItems.resize((size_t)std::max<int64_t>(info.n_known_items, 0));
+    ok(mals_ingest_get_known_items(g, m.knownPtr.data(), m.knownItems.data()));
+  }
+  return m;
+}
 
 }  // namespace myrrix

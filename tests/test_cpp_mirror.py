@@ -41,3 +41,13 @@ def test_model_file_through_the_cpp_mirror(tmp_path):
     r = subprocess.run([os.path.join(CPP, "test_model_file"), str(tmp_path), TINY_STREAM.hex()], capture_output=True, text=True,
                        timeout=120)
     assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_read_input_files_through_the_cpp_mirror(tmp_path):
+    """myrrix::readInputFiles (include/myrrix/generation.hpp) = InputFilesReader.readInputFiles on the device: two files
+    in last-modified order, a header, a removal, a pruned entry, both kinds of tag with the reference's own hash vectors,
+    knownItemIDs, and the bad-line abort as std::ios_base::failure."""
+    subprocess.check_call(["make", "-C", CPP, "test_read_input_files"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(CPP, "test_read_input_files"), str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
