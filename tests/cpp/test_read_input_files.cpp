@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
   put(dir + "/a.csv", "user,item\n3,12,1\n3,12,\n4,\"\",1\n#comment\n\n5,13", 1600000100);
   put(dir + "/notes.txt", "9,9,9\n", 1600000200);
   const myrrix::InputMatrices m = myrrix::readInputFiles(dir);
-XX
+  CHECK(m.lines == 13 && m.badLines == 1);                       // a.csv's "header" is line 7: a bad line
   // users alive at the end: 1 (item 11), 2 (item 10, pruned from R but known), "foobar", 4, 5; user 3's entry was removed
   CHECK(m.userIDs.size() == 5 && m.userIDs[0] == 1 && m.userIDs[1] == 2 && m.userIDs[2] == 4 && m.userIDs[3] == 5 &&
         m.userIDs[4] == 4060265690780417169LL);                  // OneWayMigratorTest.java:28
