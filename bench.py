@@ -609,8 +609,9 @@ def main():
                                        "binding": "hbm" if (st["rows_bytes"] + st["segments_bytes"] + st["finish_bytes"] + st["dual_bytes"] + st["gramian_bytes"]) / args.steps / (HBM_PEAK_GBS * 1e6) >= k3_ms_at_peak else "mfma_fp32"}},
             "kernels_ms_per_step": {name: st[name + "_ms"] / args.steps for name in ("rows", "segments", "finish", "gramian", "dual", "rotate")},
             "gramian": {"ms_per_step": st["gramian_ms"] / args.steps,
-                        "kernel": "mals::gramian_split_kernel<T=%d> (M^T M on v_mfma_f32_16x16x16_f16, split-f16 operands, fp32 slab sums + fp64 across slabs) "
-                                  "from 262144 rows on; mals::gramian_partial_kernel<T=%d> (v_mfma_f64_16x16x4_f64) below" % (T_blocks, T_blocks),
+                        "kernel": "mals::gramian_split_kernel<T=%d> (M^T M on %s, split-f16 operands, fp32 slab sums + fp64 across slabs) "
+                                  "from 262144 rows on; mals::gramian_partial_kernel<T=%d> (v_mfma_f64_16x16x4_f64) below"
+                                  % (T_blocks, "v_mfma_f32_16x16x32_f16" if T_blocks <= 4 else "v_mfma_f32_16x16x16_f16", T_blocks),
                         # rows x tri(T) upper tiles x 512 flop per row and tile (2 x 16 x 16), whichever kernel ran
                         "effective_TFLOPs": (st["gramian_bytes"] / (4.0 * k)) * (T_blocks * (T_blocks + 1) // 2) * 512.0 / max(st["gramian_ms"], 1e-9) / 1e9,
                         "mfma_busy_frac": gram_busy,
