@@ -2,61 +2,78 @@
 // exactness in topn_kernels.h).  Included by mals_api.hip inside its anonymous namespace, after mals_handle_s.
 #pragma once
 
-struct TopnWorkspace {
-  // inputs of one pass: ONE device block, the image of the pinned block of the pass's slot (one copy); the pointers
-  // below are views into it
+constexpr int TOPN_SLOTS = 3;  // passes in flight (each on its own stream)
+
+// Everything one pass of the filter path owns.  Passes are independent (Y, X and the known items are only read), so
+// pass p runs on stream p % TOPN_SLOTS: while the streaming filter kernel of one pass has the chip, the small kernels
+// either side of it (prepare / sample / threshold of the next pass, scatter / rescore / final of the previous one) run
+// beside it instead of in its shadow -- serialised on one stream they and the launch gaps between them were two thirds
+// of a pass.
+struct TopnSlot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
+  // inputs of the pass: ONE device block, the image of the slot's pinned block (one copy); the pointers below are views
+  // into it
   uint8_t* d_in = nullptr;
   size_t din_cap = 0;
+  uint8_t* h_in = nullptr;            // pinned input block (offsets, rows, vectors, exclusion lists)
+  size_t in_cap = 0;
   const float* d_vecs = nullptr;      // [n_vecs][k] (caller's vectors) or X itself (model users: rows d_vrow)
   const int64_t* d_vrow = nullptr;    // vector v = row d_vrow[v] of d_vecs; NULL: row v
   const int32_t* d_vptr = nullptr;    // [nq + 1]
   const int64_t* d_rows = nullptr;    // [nq]: local row of the query's user (known items), -1 = none
   const int64_t* d_excl_ptr = nullptr;
   const int64_t* d_excl_idx = nullptr;
-  // filter path
-  float *d_tau = nullptr, *d_lb = nullptr;
+  float *d_tau = nullptr, *d_bmax = nullptr;  // thresholds; the sample's bucket maxima [queries][16 x TOPN_SAMPLE_GROUPS] ...
+  uint32_t* d_bidx = nullptr;                 // ... and the items that attain them
   unsigned* d_count = nullptr;
   uint32_t* d_cand = nullptr;
   uint64_t* d_pairs = nullptr;
-  uint8_t* d_outp = nullptr;    // the pass's results: [nq][how_many] pairs | counts | taus | overflow word
-  void* d_img = nullptr;        // the pass's queries as split bf16 MFMA operands (topn_image_kernel)
+  void* d_img = nullptr;        // the pass's queries as split bf16 MFMA operands (topn_prepare_kernel)
   unsigned* d_wcount = nullptr; // hits per wave of the filter kernel, [n_waves] + one overflow word
   uint2* d_whits = nullptr;     // [n_waves][TOPN_WAVE_CAP] (item, query)
   size_t wh_cap = 0;
-  size_t lb_cap = 0, cand_cap = 0, pairs_cap = 0, outp_cap = 0;
+  size_t cand_cap = 0, pairs_cap = 0;
+  uint8_t* h_stage = nullptr;   // pinned: the pass's results, [nq][how_many] pairs | counts | taus | overflow word (topn_final_kernel
+                                // writes them there), decoded while later passes run
+  size_t stage_cap = 0;
+};
+
+struct TopnWorkspace {
+  TopnSlot slot[TOPN_SLOTS];
+  hipEvent_t ev_begin = nullptr;  // the caller's stream at the start of the call: every slot stream waits for it
   // dense path
   float* d_scores = nullptr;
   uint32_t* d_sel = nullptr;
   TopnState* d_state = nullptr;
   unsigned* d_hist = nullptr;
   size_t scores_cap = 0, sel_cap = 0;
-  // pinned staging, two slots: pass p's results are decoded while pass p + 1 runs
-  uint8_t* h_stage[2] = {nullptr, nullptr};
-  size_t stage_cap = 0;
-  uint8_t* h_in[2] = {nullptr, nullptr};   // pinned input blocks (offsets, rows, vectors, exclusion lists)
-  size_t in_cap[2] = {0, 0};
-  hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
 void topn_free(mals_handle h) {
   TopnWorkspace* w = static_cast<TopnWorkspace*>(h->tn_ws);
   if (!w) return;
-  free_dev(w->d_in);
-  free_dev(w->d_tau); free_dev(w->d_lb); free_dev(w->d_count); free_dev(w->d_cand);
-  free_dev(w->d_pairs); free_dev(w->d_outp); free_dev(w->d_img); free_dev(w->d_wcount); free_dev(w->d_whits); free_dev(w->d_scores); free_dev(w->d_sel); free_dev(w->d_state); free_dev(w->d_hist);
-  for (int s = 0; s < 2; ++s) {
-    if (w->h_stage[s]) (void)hipHostFree(w->h_stage[s]);
-    if (w->h_in[s]) (void)hipHostFree(w->h_in[s]);
-    if (w->ev[s]) (void)hipEventDestroy(w->ev[s]);
+  for (TopnSlot& s : w->slot) {
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    free_dev(s.d_in);
+    free_dev(s.d_tau); free_dev(s.d_bmax); free_dev(s.d_bidx); free_dev(s.d_count); free_dev(s.d_cand);
+    free_dev(s.d_pairs); free_dev(s.d_img); free_dev(s.d_wcount); free_dev(s.d_whits);
+    if (s.h_stage) (void)hipHostFree(s.h_stage);
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
   }
+  if (w->ev_begin) (void)hipEventDestroy(w->ev_begin);
+  free_dev(w->d_scores); free_dev(w->d_sel); free_dev(w->d_state); free_dev(w->d_hist);
   delete w;
   h->tn_ws = nullptr;
 }
 
+// grow a buffer only `stream` uses
 template <typename P>
-int topn_grow(mals_handle h, P*& p, size_t& cap, size_t want) {
+int topn_grow(mals_handle h, hipStream_t stream, P*& p, size_t& cap, size_t want) {
   if (want <= cap) return MALS_OK;
-  HIPCHK(h, hipStreamSynchronize(h->stream));  // a pass still in flight may use the old buffer
+  HIPCHK(h, hipStreamSynchronize(stream));  // a pass still in flight may use the old buffer
   free_dev(p);
   cap = 0;
   HIPCHK(h, hipMalloc(&p, sizeof(P) * want));
@@ -104,9 +121,10 @@ void topn_emit(std::vector<TopnCand>& cand, int how_many, int64_t* item_idx_out,
   }
 }
 
-// The pass's vectors, offsets, known-item rows and exclusion lists on the device: assembled in the pinned input block
-// of `slot` and sent with ONE asynchronous copy (the host never waits for the pass that is still running).
-int topn_upload_pass(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, TopnPass& ps, int slot) {
+// The pass's vectors, offsets, known-item rows and exclusion lists on the device: assembled in the slot's pinned input
+// block and sent with ONE asynchronous copy on `stream` (the host never waits for a pass that is still running; the slot's
+// previous pass has been decoded before the slot is used again).
+int topn_upload_pass(mals_handle h, TopnSlot& sl, hipStream_t stream, const TopnRequest& rq, TopnPass& ps) {
   const int k = h->cfg.features;
   SideState& x = h->side[MALS_SIDE_X];
   const bool own_vectors = !rq.user_idx;
@@ -123,27 +141,27 @@ int topn_upload_pass(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, Top
                o_eptr = o_uidx + 8 * TOPN_FILTER_QUERIES, o_vecs = o_eptr + 8 * (TOPN_FILTER_QUERIES + 1),
                o_eidx = o_vecs + ((own_vectors ? sizeof(float) * (size_t)ps.n_vecs * (size_t)k : 0) + 15) / 16 * 16,
                total = o_eidx + 8 * (size_t)n_ex;
-  if (total > w->in_cap[slot]) {
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // an earlier pass may still be reading the old block
-    if (w->h_in[slot]) (void)hipHostFree(w->h_in[slot]);
-    w->h_in[slot] = nullptr;
-    w->in_cap[slot] = 0;
-    HIPCHK(h, hipHostMalloc(&w->h_in[slot], total + total / 2, hipHostMallocDefault));
-    w->in_cap[slot] = total + total / 2;
+  if (total > sl.in_cap) {
+    HIPCHK(h, hipStreamSynchronize(stream));  // an earlier copy may still be reading the old block
+    if (sl.h_in) (void)hipHostFree(sl.h_in);
+    sl.h_in = nullptr;
+    sl.in_cap = 0;
+    HIPCHK(h, hipHostMalloc(&sl.h_in, total + total / 2, hipHostMallocDefault));
+    sl.in_cap = total + total / 2;
   }
-  if (int rc = topn_grow(h, w->d_in, w->din_cap, total + total / 2)) return rc;
-  uint8_t* in = w->h_in[slot];
+  if (int rc = topn_grow(h, stream, sl.d_in, sl.din_cap, total + total / 2)) return rc;
+  uint8_t* in = sl.h_in;
   int32_t* vptr = reinterpret_cast<int32_t*>(in + o_vptr);
   for (int q = 0; q <= ps.nq; ++q) vptr[q] = (rq.user_idx || !rq.vec_ptr) ? q : (int32_t)(rq.vec_ptr[ps.q0 + q] - ps.v0);
   ps.have_rows = ps.have_excl = false;
-  w->d_vptr = reinterpret_cast<const int32_t*>(w->d_in + o_vptr);
-  w->d_rows = reinterpret_cast<const int64_t*>(w->d_in + o_rows);
-  w->d_excl_ptr = reinterpret_cast<const int64_t*>(w->d_in + o_eptr);
-  w->d_excl_idx = reinterpret_cast<const int64_t*>(w->d_in + o_eidx);
+  sl.d_vptr = reinterpret_cast<const int32_t*>(sl.d_in + o_vptr);
+  sl.d_rows = reinterpret_cast<const int64_t*>(sl.d_in + o_rows);
+  sl.d_excl_ptr = reinterpret_cast<const int64_t*>(sl.d_in + o_eptr);
+  sl.d_excl_idx = reinterpret_cast<const int64_t*>(sl.d_in + o_eidx);
   if (rq.user_idx) {
     std::memcpy(in + o_uidx, rq.user_idx + ps.q0, sizeof(int64_t) * (size_t)ps.nq);
-    w->d_vecs = x.F;
-    w->d_vrow = reinterpret_cast<const int64_t*>(w->d_in + o_uidx);
+    sl.d_vecs = x.F;
+    sl.d_vrow = reinterpret_cast<const int64_t*>(sl.d_in + o_uidx);
     if (rq.skip_known) {
       int64_t* rows = reinterpret_cast<int64_t*>(in + o_rows);
       for (int q = 0; q < ps.nq; ++q) rows[q] = rq.user_idx[ps.q0 + q] - x.row_offset;
@@ -151,8 +169,8 @@ int topn_upload_pass(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, Top
     }
   } else {
     std::memcpy(in + o_vecs, rq.vectors + ps.v0 * k, sizeof(float) * (size_t)ps.n_vecs * (size_t)k);
-    w->d_vecs = reinterpret_cast<const float*>(w->d_in + o_vecs);
-    w->d_vrow = nullptr;
+    sl.d_vecs = reinterpret_cast<const float*>(sl.d_in + o_vecs);
+    sl.d_vrow = nullptr;
   }
   if (n_ex > 0) {
     int64_t* eptr = reinterpret_cast<int64_t*>(in + o_eptr);
@@ -160,11 +178,12 @@ int topn_upload_pass(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, Top
     std::memcpy(in + o_eidx, rq.excl_idx + rq.excl_ptr[ps.q0], sizeof(int64_t) * (size_t)n_ex);
     ps.have_excl = true;
   }
-  HIPCHK(h, hipMemcpyAsync(w->d_in, in, total, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(sl.d_in, in, total, hipMemcpyHostToDevice, stream));
   return MALS_OK;
 }
 
-// ---- dense path: exact scores of every item ------------------------------------------------------------------------
+// ---- dense path: exact scores of every item (on the caller's stream, with slot 0's input block; nothing else of the
+// workspace is in flight when it runs) -------------------------------------------------------------------------------
 int topn_select_threshold(mals_handle h, const float* d_scores, int64_t n_row, int nq, int how_many, TopnState* d_st, unsigned* d_hist,
                           unsigned* slabs_out) {
   hipLaunchKernelGGL(topn_init_kernel, dim3((unsigned)((nq * 256 + 255) / 256)), dim3(256), 0, h->stream, d_st, d_hist, nq, how_many);
@@ -178,25 +197,25 @@ int topn_select_threshold(mals_handle h, const float* d_scores, int64_t n_row, i
   return MALS_OK;
 }
 
-int topn_pass_dense(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, const TopnPass& ps) {
+int topn_pass_dense(mals_handle h, TopnWorkspace* w, TopnSlot& sl, const TopnRequest& rq, const TopnPass& ps) {
   SideState& y = h->side[MALS_SIDE_Y];
   SideState& x = h->side[MALS_SIDE_X];
   const int k = h->cfg.features, nq = ps.nq, how_many = rq.how_many;
   const int64_t n_items = y.n_total;
   const int cap_ties = 1024;
   const size_t per_q = 2 * ((size_t)how_many + cap_ties);
-  if (int rc = topn_grow(h, w->d_scores, w->scores_cap, (size_t)TOPN_MAX_QUERIES * (size_t)n_items)) return rc;
-  if (int rc = topn_grow(h, w->d_sel, w->sel_cap, (size_t)TOPN_MAX_QUERIES * per_q)) return rc;
+  if (int rc = topn_grow(h, h->stream, w->d_scores, w->scores_cap, (size_t)TOPN_MAX_QUERIES * (size_t)n_items)) return rc;
+  if (int rc = topn_grow(h, h->stream, w->d_sel, w->sel_cap, (size_t)TOPN_MAX_QUERIES * per_q)) return rc;
   if (!w->d_state) HIPCHK(h, hipMalloc(&w->d_state, sizeof(TopnState) * TOPN_MAX_QUERIES));
   if (!w->d_hist) HIPCHK(h, hipMalloc(&w->d_hist, sizeof(unsigned) * 256 * TOPN_MAX_QUERIES));
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_items + 63) / 64, (int64_t)h->n_cu * 8));
-  hipLaunchKernelGGL(topn_exact_dense_kernel, dim3(grid), dim3(256), sizeof(float) * 64 * (size_t)(k + 1), h->stream, y.F, n_items, k, w->d_vecs,
-                     w->d_vrow, w->d_vptr, nq, w->d_scores);
+  hipLaunchKernelGGL(topn_exact_dense_kernel, dim3(grid), dim3(256), sizeof(float) * 64 * (size_t)(k + 1), h->stream, y.F, n_items, k, sl.d_vecs,
+                     sl.d_vrow, sl.d_vptr, nq, w->d_scores);
   if (ps.have_rows)
     hipLaunchKernelGGL(topn_mask_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, h->known_ptr ? h->known_ptr : x.row_ptr,
-                       h->known_ptr ? h->known_idx : x.col, w->d_rows, nq, 1, n_items, w->d_scores);
+                       h->known_ptr ? h->known_idx : x.col, sl.d_rows, nq, 1, n_items, w->d_scores);
   if (ps.have_excl)
-    hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, w->d_excl_ptr, w->d_excl_idx, nq, n_items, 1, n_items,
+    hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, sl.d_excl_ptr, sl.d_excl_idx, nq, n_items, 1, n_items,
                        w->d_scores);
   unsigned slabs = 1;
   if (int rc = topn_select_threshold(h, w->d_scores, n_items, nq, how_many, w->d_state, w->d_hist, &slabs)) return rc;
@@ -242,70 +261,71 @@ int topn_max_tiles(int S) { return S == 1 ? 16 : S == 2 ? 15 : S == 3 ? 10 : 7; 
 
 constexpr int TOPN_WAVE_CAP = 2048;  // hits a wave of the filter kernel can record (expected: a hundred)
 
-template <int S, int MODE>
-int topn_launch_filter(mals_handle h, int nt, const float* Y, int64_t n_items, int k, TopnWorkspace* w, int nq, int tile_stride,
-                       int64_t n_out, int* n_waves_out) {
+// topn_stream_kernel: QT = query tiles per wave, 4 QT per workgroup.  MODE 0: *n_out = workgroups of the sample (16
+// buckets each); MODE 1: *n_out = waves of the filter (one hit list each).
+template <int S, int QT, int MODE>
+int topn_launch_stream_QT(mals_handle h, TopnSlot& sl, const float* Y, int64_t n_items, int k, int nq, int tile_stride, int* n_out) {
   const int64_t tiles = (n_items + 16 * (int64_t)tile_stride - 1) / (16 * (int64_t)tile_stride);
-  // NT = query tiles per workgroup, GY = workgroup rows over the query tiles.  The sample (MODE 0) is a thousand item tiles:
-  // it is spread over the query tiles as well, four at a time.
-#define MALS_TOPN_LAUNCH(NT, GY)                                                                                                      \
-  do {                                                                                                                                \
-    const size_t lds = (size_t)NT * (S + 1) * 64 * 16;                                                                                \
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(150 * 1024) / lds)); /* workgroups resident per CU */          \
-    if (MODE == 1 && NT > 8) per_cu = std::min(per_cu, 2); /* ~250 registers: two waves per SIMD */                                   \
-    if (const char* e = std::getenv("MALS_TOPN_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e));                                   \
-    const int64_t groups = MODE == 1 ? (tiles + 1) / 2 : tiles;                                                                       \
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((groups + 3) / 4, (int64_t)h->n_cu * per_cu / (GY)));      \
-    if (MODE == 1) {                                                                                                                  \
-      const size_t nw = (size_t)grid * 4;                                                                                             \
-      if (nw * TOPN_WAVE_CAP > w->wh_cap) {                                                                                           \
-        HIPCHK(h, hipStreamSynchronize(h->stream));                                                                                   \
-        free_dev(w->d_whits);                                                                                                         \
-        free_dev(w->d_wcount);                                                                                                        \
-        w->wh_cap = 0;                                                                                                                \
-        HIPCHK(h, hipMalloc(&w->d_whits, sizeof(uint2) * nw * TOPN_WAVE_CAP));                                                        \
-        HIPCHK(h, hipMalloc(&w->d_wcount, sizeof(unsigned) * (nw + 1)));                                                              \
-        w->wh_cap = nw * TOPN_WAVE_CAP;                                                                                               \
-      }                                                                                                                               \
-      *n_waves_out = (int)nw;                                                                                                         \
-    }                                                                                                                                 \
-    if (k == 32 * S)                                                                                                                  \
-      hipLaunchKernelGGL((topn_filter_kernel<S, NT, MODE, true>), dim3(grid, (unsigned)(GY)), dim3(256), lds, h->stream, Y, n_items, k, \
-                         static_cast<const bf16x8*>(w->d_img), nq, tile_stride, n_out, w->d_lb, w->d_tau, TOPN_WAVE_CAP, w->d_wcount, \
-                         w->d_whits);                                                                                                 \
-    else                                                                                                                              \
-      hipLaunchKernelGGL((topn_filter_kernel<S, NT, MODE, false>), dim3(grid, (unsigned)(GY)), dim3(256), lds, h->stream, Y, n_items, k, \
-                         static_cast<const bf16x8*>(w->d_img), nq, tile_stride, n_out, w->d_lb, w->d_tau, TOPN_WAVE_CAP, w->d_wcount, \
-                         w->d_whits);                                                                                                 \
-  } while (0)
-  constexpr int NTMAX = S == 1 ? 16 : S == 2 ? 15 : S == 3 ? 10 : 7;
-  if constexpr (MODE == 0) {
-    if (nt <= 1) MALS_TOPN_LAUNCH(1, 1);
-    else MALS_TOPN_LAUNCH(4, (nt + 3) / 4);
+  const int64_t stages = (tiles + 3) / 4;
+  // resident workgroups per CU: LDS 4 (S + 1) KB each; registers ~70 (QT = 1) .. ~110 (QT = 4) per lane
+  int per_cu = QT <= 2 ? 6 : QT == 3 ? 5 : 4;
+  if (const char* e = std::getenv("MALS_TOPN_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e));
+  // the filter is a persistent grid; the sample's workgroups each keep 16 buckets per query
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(stages, MODE == 0 ? TOPN_SAMPLE_GROUPS : (int64_t)h->n_cu * per_cu));
+  if (MODE == 1) {
+    const size_t nw = (size_t)grid * 4;
+    if (nw * TOPN_WAVE_CAP > sl.wh_cap) {
+      HIPCHK(h, hipStreamSynchronize(sl.stream));
+      free_dev(sl.d_whits);
+      free_dev(sl.d_wcount);
+      sl.wh_cap = 0;
+      HIPCHK(h, hipMalloc(&sl.d_whits, sizeof(uint2) * nw * TOPN_WAVE_CAP));
+      HIPCHK(h, hipMalloc(&sl.d_wcount, sizeof(unsigned) * (nw + 1)));
+      sl.wh_cap = nw * TOPN_WAVE_CAP;
+    }
+    *n_out = (int)nw;
   } else {
-    if (nt <= 1) MALS_TOPN_LAUNCH(1, 1);
-    else if (nt <= 4) MALS_TOPN_LAUNCH(4, 1);
-    else if (nt <= 8 && NTMAX > 8) MALS_TOPN_LAUNCH(8, 1);
-    else MALS_TOPN_LAUNCH(NTMAX, 1);
+    *n_out = (int)grid;
   }
-#undef MALS_TOPN_LAUNCH
+  if (k == 32 * S)
+    hipLaunchKernelGGL((topn_stream_kernel<S, QT, MODE, true>), dim3(grid), dim3(256), 0, sl.stream, Y, n_items, k,
+                       static_cast<const bf16x8*>(sl.d_img), nq, tile_stride, sl.d_bmax, sl.d_bidx, sl.d_tau, TOPN_WAVE_CAP, sl.d_wcount,
+                       sl.d_whits);
+  else
+    hipLaunchKernelGGL((topn_stream_kernel<S, QT, MODE, false>), dim3(grid), dim3(256), 0, sl.stream, Y, n_items, k,
+                       static_cast<const bf16x8*>(sl.d_img), nq, tile_stride, sl.d_bmax, sl.d_bidx, sl.d_tau, TOPN_WAVE_CAP, sl.d_wcount,
+                       sl.d_whits);
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
 }
 template <int MODE>
-int topn_launch_filter_S(mals_handle h, int S, int nt, const float* Y, int64_t n_items, int k, TopnWorkspace* w, int nq, int tile_stride,
-                         int64_t n_out, int* n_waves_out) {
+int topn_launch_stream(mals_handle h, TopnSlot& sl, int S, int nt, const float* Y, int64_t n_items, int k, int nq, int tile_stride, int* n_out) {
+  const int qt = (nt + 3) / 4;
+#define MALS_TOPN_STREAM(SS, QQ) return topn_launch_stream_QT<SS, QQ, MODE>(h, sl, Y, n_items, k, nq, tile_stride, n_out)
   switch (S) {
-    case 1: return topn_launch_filter<1, MODE>(h, nt, Y, n_items, k, w, nq, tile_stride, n_out, n_waves_out);
-    case 2: return topn_launch_filter<2, MODE>(h, nt, Y, n_items, k, w, nq, tile_stride, n_out, n_waves_out);
-    case 3: return topn_launch_filter<3, MODE>(h, nt, Y, n_items, k, w, nq, tile_stride, n_out, n_waves_out);
-    default: return topn_launch_filter<4, MODE>(h, nt, Y, n_items, k, w, nq, tile_stride, n_out, n_waves_out);
+    case 1:
+      if (qt <= 1) MALS_TOPN_STREAM(1, 1);
+      if (qt == 2) MALS_TOPN_STREAM(1, 2);
+      if (qt == 3) MALS_TOPN_STREAM(1, 3);
+      MALS_TOPN_STREAM(1, 4);
+    case 2:
+      if (qt <= 1) MALS_TOPN_STREAM(2, 1);
+      if (qt == 2) MALS_TOPN_STREAM(2, 2);
+      if (qt == 3) MALS_TOPN_STREAM(2, 3);
+      MALS_TOPN_STREAM(2, 4);
+    case 3:  // at most 10 query tiles per pass
+      if (qt <= 1) MALS_TOPN_STREAM(3, 1);
+      if (qt == 2) MALS_TOPN_STREAM(3, 2);
+      MALS_TOPN_STREAM(3, 3);
+    default:  // at most 7
+      if (qt <= 1) MALS_TOPN_STREAM(4, 1);
+      MALS_TOPN_STREAM(4, 2);
   }
+#undef MALS_TOPN_STREAM
 }
 
 struct TopnFilterPlan {
   int S, cap, cap_pad, tile_stride;
-  int64_t n_sample;
   size_t stage_bytes;
 };
 TopnFilterPlan topn_plan(mals_handle h, int how_many) {
@@ -315,66 +335,79 @@ TopnFilterPlan topn_plan(mals_handle h, int how_many) {
   p.cap = 48 * how_many + 2048;
   p.cap_pad = 1;
   while (p.cap_pad < p.cap) p.cap_pad <<= 1;
-  const int64_t target = std::max<int64_t>(512 * (int64_t)how_many, 16384);  // sample items: expected candidates = how_many x stride
+  // sample items: expected candidates per query = how_many x stride.  An eighth of the items (at most 131072): the sample
+  // kernel keeps only bucket maxima, so its cost is an eighth of a filter pass, and every candidate less is less hit
+  // bookkeeping in the filter, less to scatter and rescore (16384 -> 131072 at a million items: 1.4x the queries per second)
+  int64_t target = std::max<int64_t>(512 * (int64_t)how_many, std::max<int64_t>(16384, std::min<int64_t>(131072, n_items / 8)));
+  if (const char* e = std::getenv("MALS_TOPN_SAMPLE_ITEMS")) target = std::max<int64_t>(1024, std::atoll(e));  // tuning override
   p.tile_stride = (int)std::max<int64_t>(1, n_items / target);
-  p.n_sample = ((n_items + 16 * (int64_t)p.tile_stride - 1) / (16 * (int64_t)p.tile_stride)) * 16;
   p.stage_bytes = (size_t)TOPN_FILTER_QUERIES * ((size_t)how_many * 8 + 8) + 16;  // pairs | counts | taus | overflow word
   return p;
 }
 
-// enqueue one pass; its results land in pinned slot `slot` behind event ev[slot]
-int topn_pass_filter_enqueue(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, const TopnPass& ps, const TopnFilterPlan& p, int slot) {
+// the kernels of one pass on the slot's stream (plain launches, or recorded into a graph while the stream is capturing)
+int topn_pass_filter_launch(mals_handle h, TopnSlot& sl, const TopnRequest& rq, const TopnPass& ps, const TopnFilterPlan& p) {
   SideState& y = h->side[MALS_SIDE_Y];
   SideState& x = h->side[MALS_SIDE_X];
   const int k = h->cfg.features, nq = ps.nq, how_many = rq.how_many;
   const int64_t n_items = y.n_total;
   const int nt = (nq + 15) / 16;
-  if (!w->d_tau) {
-    HIPCHK(h, hipMalloc(&w->d_tau, sizeof(float) * TOPN_FILTER_QUERIES));
-    HIPCHK(h, hipMalloc(&w->d_count, sizeof(unsigned) * (TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE + 1)));  // padded counters, then the overflow word
-    HIPCHK(h, hipMalloc(&w->d_img, (size_t)16 * 5 * 64 * 16));
-  }
-  unsigned* d_overflow = w->d_count + (size_t)TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE;
-  if (int rc = topn_grow(h, w->d_lb, w->lb_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.n_sample)) return rc;
-  if (int rc = topn_grow(h, w->d_pairs, w->pairs_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.cap)) return rc;
-  if (int rc = topn_grow(h, w->d_cand, w->cand_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.cap)) return rc;
-  if (int rc = topn_grow(h, w->d_outp, w->outp_cap, p.stage_bytes)) return rc;
-  const int64_t* d_rows = ps.have_rows ? w->d_rows : nullptr;
+  hipStream_t st = sl.stream;
+  unsigned* d_overflow = sl.d_count + (size_t)TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE;
+  const int64_t* d_rows = ps.have_rows ? sl.d_rows : nullptr;
   const int64_t* k_ptr = h->known_ptr ? h->known_ptr : x.row_ptr;   // knownItemIDs if the caller installed them, else the rows of R
   const int32_t* k_idx = h->known_ptr ? h->known_idx : x.col;
-  const int64_t* d_eptr = ps.have_excl ? w->d_excl_ptr : nullptr;
-  const int64_t* d_eidx = ps.have_excl ? w->d_excl_idx : nullptr;
+  const int64_t* d_eptr = ps.have_excl ? sl.d_excl_ptr : nullptr;
+  const int64_t* d_eidx = ps.have_excl ? sl.d_excl_idx : nullptr;
   // 0. the queries as matrix operands (every tile an instantiation may touch: padding queries never produce a hit)
-  hipLaunchKernelGGL(topn_prepare_kernel, dim3(16), dim3(256), 0, h->stream, w->d_vecs, w->d_vrow, w->d_vptr, nq, k, p.S,
-                     static_cast<bf16x8*>(w->d_img), w->d_count, d_overflow);
-  // 1. sample: lower bounds of every tile_stride-th tile; 2. threshold (known items out of the sample first)
-  int n_fw = 0;
-  if (int rc = topn_launch_filter_S<0>(h, p.S, nt, y.F, n_items, k, w, nq, p.tile_stride, p.n_sample, &n_fw)) return rc;
-  hipLaunchKernelGGL(topn_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, h->stream, w->d_lb, p.n_sample, how_many, k_ptr, k_idx, d_rows, d_eptr,
-                     d_eidx, n_items, p.tile_stride, w->d_tau);
-  // 3. filter, 4. exact scores of the hits (known items dropped), 5. the N best
-  if (int rc = topn_launch_filter_S<1>(h, p.S, nt, y.F, n_items, k, w, nq, 1, n_items, &n_fw)) return rc;
-  hipLaunchKernelGGL(topn_scatter_kernel, dim3((unsigned)n_fw), dim3(256), 0, h->stream, w->d_wcount, w->d_whits, TOPN_WAVE_CAP, n_fw, p.cap,
-                     w->d_count, w->d_cand, d_overflow);
-  hipLaunchKernelGGL(topn_rescore_kernel, dim3(4, (unsigned)nq), dim3(256), 0, h->stream, y.F, k, w->d_vecs, w->d_vrow, w->d_vptr, w->d_count, p.cap,
-                     w->d_cand, k_ptr, k_idx, d_rows, d_eptr, d_eidx, w->d_pairs);
-  uint8_t* o = w->d_outp;
+  hipLaunchKernelGGL(topn_prepare_kernel, dim3(16), dim3(256), 0, st, sl.d_vecs, sl.d_vrow, sl.d_vptr, nq, k, p.S,
+                     static_cast<bf16x8*>(sl.d_img), sl.d_count, d_overflow);
+  // 1. sample: bucket maxima of the lower bounds of every tile_stride-th tile; 2. threshold (buckets won by known items dropped)
+  int n_groups = 0, n_fw = 0;
+  if (int rc = topn_launch_stream<0>(h, sl, p.S, nt, y.F, n_items, k, nq, p.tile_stride, &n_groups)) return rc;
+  hipLaunchKernelGGL(topn_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, st, sl.d_bmax, sl.d_bidx, n_groups, how_many, k_ptr, k_idx, d_rows,
+                     d_eptr, d_eidx, n_items, p.tile_stride, sl.d_tau);
+  // 3. filter, 4. exact scores of the hits (known items dropped), 5. the N best -- written straight into the slot's pinned
+  // block (device-visible host memory: no copy kernel, no copy call)
+  if (int rc = topn_launch_stream<1>(h, sl, p.S, nt, y.F, n_items, k, nq, 1, &n_fw)) return rc;
+  hipLaunchKernelGGL(topn_scatter_kernel, dim3((unsigned)n_fw), dim3(256), 0, st, sl.d_wcount, sl.d_whits, TOPN_WAVE_CAP, n_fw, p.cap,
+                     sl.d_count, sl.d_cand, d_overflow);
+  hipLaunchKernelGGL(topn_rescore_kernel, dim3(8, (unsigned)nq), dim3(64), sizeof(float) * 64 * (size_t)(k + 1), st, y.F, k, sl.d_vecs, sl.d_vrow, sl.d_vptr, sl.d_count, p.cap,
+                     sl.d_cand, k_ptr, k_idx, d_rows, d_eptr, d_eidx, sl.d_pairs);
+  uint8_t* o = sl.h_stage;
   const size_t o_cnt = sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many, o_tau = o_cnt + sizeof(unsigned) * TOPN_FILTER_QUERIES,
                o_ovf = o_tau + sizeof(float) * TOPN_FILTER_QUERIES;
-  hipLaunchKernelGGL(topn_final_kernel, dim3((unsigned)nq), dim3(256), sizeof(uint64_t) * (size_t)p.cap, h->stream, w->d_pairs, w->d_count, p.cap,
-                     how_many, reinterpret_cast<uint64_t*>(o), reinterpret_cast<unsigned*>(o + o_cnt), w->d_tau, reinterpret_cast<float*>(o + o_tau),
+  hipLaunchKernelGGL(topn_final_kernel, dim3((unsigned)nq), dim3(256), sizeof(uint64_t) * (size_t)p.cap, st, sl.d_pairs, sl.d_count, p.cap,
+                     how_many, reinterpret_cast<uint64_t*>(o), reinterpret_cast<unsigned*>(o + o_cnt), sl.d_tau, reinterpret_cast<float*>(o + o_tau),
                      d_overflow, reinterpret_cast<unsigned*>(o + o_ovf));
   HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(w->h_stage[slot], o, p.stage_bytes, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipEventRecord(w->ev[slot], h->stream));
+  return MALS_OK;
+}
+
+// enqueue one pass on its slot's stream; its results land in the slot's pinned block behind the slot's event
+int topn_pass_filter_enqueue(mals_handle h, TopnSlot& sl, const TopnRequest& rq, const TopnPass& ps, const TopnFilterPlan& p) {
+  hipStream_t st = sl.stream;
+  if (!sl.d_tau) {
+    HIPCHK(h, hipMalloc(&sl.d_tau, sizeof(float) * TOPN_FILTER_QUERIES));
+    HIPCHK(h, hipMalloc(&sl.d_count, sizeof(unsigned) * (TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE + 1)));  // padded counters, then the overflow word
+    HIPCHK(h, hipMalloc(&sl.d_img, (size_t)16 * 5 * 64 * 16));
+    HIPCHK(h, hipMalloc(&sl.d_bmax, sizeof(float) * TOPN_FILTER_QUERIES * 16 * TOPN_SAMPLE_GROUPS));
+    HIPCHK(h, hipMalloc(&sl.d_bidx, sizeof(uint32_t) * TOPN_FILTER_QUERIES * 16 * TOPN_SAMPLE_GROUPS));
+  }
+  if (int rc = topn_grow(h, st, sl.d_pairs, sl.pairs_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.cap)) return rc;
+  if (int rc = topn_grow(h, st, sl.d_cand, sl.cand_cap, (size_t)TOPN_FILTER_QUERIES * (size_t)p.cap)) return rc;
+  // (one graph launch per pass instead of nine kernel launches was tried: no faster -- the device, not the host's launch
+  // calls, sets the pace even at 64 queries per pass)
+  if (int rc = topn_pass_filter_launch(h, sl, rq, ps, p)) return rc;
+  HIPCHK(h, hipEventRecord(sl.ev, st));
   return MALS_OK;
 }
 
 // decode a finished pass; *ok = false: a query overflowed its candidate buffer or had a thin sample (the dense path answers)
-int topn_pass_filter_finish(mals_handle h, TopnWorkspace* w, const TopnRequest& rq, const TopnPass& ps, const TopnFilterPlan& p, int slot, bool* ok) {
-  HIPCHK(h, hipEventSynchronize(w->ev[slot]));
+int topn_pass_filter_finish(mals_handle h, TopnSlot& sl, const TopnRequest& rq, const TopnPass& ps, const TopnFilterPlan& p, bool* ok) {
+  HIPCHK(h, hipEventSynchronize(sl.ev));
   const int how_many = rq.how_many;
-  const uint8_t* st = w->h_stage[slot];
+  const uint8_t* st = sl.h_stage;
   const uint64_t* outp = reinterpret_cast<const uint64_t*>(st);
   const unsigned* count = reinterpret_cast<const unsigned*>(st + sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many);
   const float* tau = reinterpret_cast<const float*>(st + sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many + sizeof(unsigned) * TOPN_FILTER_QUERIES);
@@ -414,58 +447,76 @@ int topn_run(mals_handle h, const TopnRequest& rq) {
       TopnPass ps;
       ps.q0 = q0;
       ps.nq = std::min(TOPN_MAX_QUERIES, rq.n_queries - q0);
-      if (int rc = topn_upload_pass(h, w, rq, ps, 0)) return rc;
-      if (int rc = topn_pass_dense(h, w, rq, ps)) return rc;
+      if (int rc = topn_upload_pass(h, w->slot[0], h->stream, rq, ps)) return rc;
+      if (int rc = topn_pass_dense(h, w, w->slot[0], rq, ps)) return rc;
     }
     return MALS_OK;
   }
   const TopnFilterPlan p = topn_plan(h, rq.how_many);
-  if (w->stage_cap < p.stage_bytes) {
-    for (int s = 0; s < 2; ++s) {
-      if (w->h_stage[s]) (void)hipHostFree(w->h_stage[s]);
-      w->h_stage[s] = nullptr;
+  for (TopnSlot& sl : w->slot) {
+    if (!sl.stream) HIPCHK(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    if (!sl.ev) HIPCHK(h, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.stage_cap < p.stage_bytes) {
+      HIPCHK(h, hipStreamSynchronize(sl.stream));
+      if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+      sl.h_stage = nullptr;
+      sl.stage_cap = 0;
+      HIPCHK(h, hipHostMalloc(&sl.h_stage, p.stage_bytes, hipHostMallocDefault));
+      sl.stage_cap = p.stage_bytes;
     }
-    w->stage_cap = 0;
-    for (int s = 0; s < 2; ++s) HIPCHK(h, hipHostMalloc(&w->h_stage[s], p.stage_bytes, hipHostMallocDefault));
-    w->stage_cap = p.stage_bytes;
   }
-  for (int s = 0; s < 2; ++s)
-    if (!w->ev[s]) HIPCHK(h, hipEventCreateWithFlags(&w->ev[s], hipEventDisableTiming));
+  if (!w->ev_begin) HIPCHK(h, hipEventCreateWithFlags(&w->ev_begin, hipEventDisableTiming));
+  // whatever the caller's stream still has to do (an iteration, a factor upload) comes first
+  HIPCHK(h, hipEventRecord(w->ev_begin, h->stream));
+  for (TopnSlot& sl : w->slot) HIPCHK(h, hipStreamWaitEvent(sl.stream, w->ev_begin, 0));
   int per_pass = 16 * topn_max_tiles(p.S);
   if (const char* e = std::getenv("MALS_TOPN_QUERIES_PER_PASS")) per_pass = std::max(16, std::min(per_pass, std::atoi(e) / 16 * 16));  // tuning override
-  // pass i + 1 is enqueued before pass i is decoded: the device does not wait for the host between passes
-  TopnPass prev;
-  bool have_prev = false;
-  int prev_slot = 0, slot = 0;
-  auto finish_prev = [&]() -> int {
-    if (!have_prev) return MALS_OK;
-    have_prev = false;
+  int n_slots = TOPN_SLOTS;
+  if (const char* e = std::getenv("MALS_TOPN_SLOTS")) n_slots = std::max(1, std::min(TOPN_SLOTS, std::atoi(e)));  // tuning override
+  // Passes go round the slots; pass i is decoded after pass i + n_slots - 1 has been enqueued, right before its slot is
+  // needed again: the device never waits for the host between passes.
+  TopnPass inflight[TOPN_SLOTS];
+  bool busy[TOPN_SLOTS] = {};
+  auto finish = [&](int s) -> int {
+    if (!busy[s]) return MALS_OK;
+    busy[s] = false;
     bool ok = true;
-    if (int rc = topn_pass_filter_finish(h, w, rq, prev, p, prev_slot, &ok)) return rc;
-    if (!ok) {  // rare: answer the pass exactly the slow way (its own input block is free again: the pass has finished)
-      for (int q0 = prev.q0; q0 < prev.q0 + prev.nq; q0 += TOPN_MAX_QUERIES) {
+    const TopnPass done = inflight[s];
+    if (int rc = topn_pass_filter_finish(h, w->slot[s], rq, done, p, &ok)) return rc;
+    if (!ok) {  // rare: answer the pass exactly the slow way (the slot's input block is free again: its pass has finished)
+      for (int q0 = done.q0; q0 < done.q0 + done.nq; q0 += TOPN_MAX_QUERIES) {
         TopnPass ps;
         ps.q0 = q0;
-        ps.nq = std::min(TOPN_MAX_QUERIES, prev.q0 + prev.nq - q0);
+        ps.nq = std::min(TOPN_MAX_QUERIES, done.q0 + done.nq - q0);
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (int rc = topn_upload_pass(h, w, rq, ps, prev_slot)) return rc;
-        if (int rc = topn_pass_dense(h, w, rq, ps)) return rc;
+        if (int rc = topn_upload_pass(h, w->slot[s], h->stream, rq, ps)) return rc;
+        if (int rc = topn_pass_dense(h, w, w->slot[s], rq, ps)) return rc;
       }
     }
     return MALS_OK;
   };
-  for (int q0 = 0; q0 < rq.n_queries; q0 += per_pass) {
+  int s = 0;
+  int rc_all = MALS_OK;
+  for (int q0 = 0; q0 < rq.n_queries && rc_all == MALS_OK; q0 += per_pass) {
+    if ((rc_all = finish(s))) break;
     TopnPass ps;
     ps.q0 = q0;
     ps.nq = std::min(per_pass, rq.n_queries - q0);
-    if (int rc = topn_upload_pass(h, w, rq, ps, slot)) return rc;
-    if (int rc = topn_pass_filter_enqueue(h, w, rq, ps, p, slot)) return rc;
-    const int this_slot = slot;
-    slot = 1 - slot;
-    if (int rc = finish_prev()) return rc;  // the pass enqueued one iteration ago; its slots are free for the next one
-    prev = ps;
-    prev_slot = this_slot;
-    have_prev = true;
+    if ((rc_all = topn_upload_pass(h, w->slot[s], w->slot[s].stream, rq, ps))) break;
+    if ((rc_all = topn_pass_filter_enqueue(h, w->slot[s], rq, ps, p))) break;
+    inflight[s] = ps;
+    busy[s] = true;
+    s = (s + 1) % n_slots;
   }
-  return finish_prev();
+  // drain in enqueue order (also on an error: nothing of this call may still be running when it returns)
+  for (int i = 0; i < n_slots; ++i) {
+    const int t = (s + i) % n_slots;
+    if (rc_all != MALS_OK) {
+      if (w->slot[t].stream) (void)hipStreamSynchronize(w->slot[t].stream);
+      busy[t] = false;
+    } else {
+      rc_all = finish(t);
+    }
+  }
+  return rc_all;
 }

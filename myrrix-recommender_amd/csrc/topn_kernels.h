@@ -9,28 +9,32 @@
 // computed by topn_exact_* below with exactly those operations, so scores and -- with ties in ascending item index --
 // indices are bit-identical to the oracle's.  What makes that affordable on a million items is a FILTER in front:
 //   1. sample     every `stride`-th 16-item tile is scored approximately against all queries of the pass on
-//                 v_mfma_f32_16x16x32_bf16 (item rows split into two bf16 halves, query vectors one bf16), fp32
-//                 accumulate.  |approx - exact| <= 2^-8 |x| |y_i| (bound below), so lb_i = approx - margin_i is a
-//                 LOWER bound of the exact score.  Known items are masked out.
-//   2. threshold  per query tau = (a lower estimate of) the N-th largest lb of the sample: at least N unmasked items
-//                 score >= tau exactly, hence the exact N-th best score is >= tau.
+//                 v_mfma_f32_16x16x32_bf16 (item rows and query vectors one bf16 each), fp32 accumulate.
+//                 |approx - exact| <= margin_i = 1.25 * 2^-8 |x| |y_i| (bound below), so lb_i = approx - margin_i is a
+//                 LOWER bound of the exact score.  The sample is reduced on the fly to a few thousand BUCKET maxima per
+//                 query (bucket = a fixed subset of the sample's items) with the item that attains each.
+//   2. threshold  buckets whose best item is a known / excluded item of the query are dropped; tau = (a lower estimate
+//                 of) the N-th largest of the remaining bucket maxima: at least N distinct unmasked items score >= tau
+//                 exactly, hence the exact N-th best score is >= tau.
 //   3. filter     ALL items streamed once per pass (Y is read once for up to 256 queries: HBM-bound, n_items * 4k
 //                 bytes), same approximate score; item i is a candidate of query q iff approx + margin_i >= tau_q --
 //                 a superset of {i: exact score >= tau_q}, which contains the exact top N with all its ties.
 //   4. rescore    exact reference arithmetic on the candidates only (a few hundred per query), known items struck.
 //   5. final      per query the N largest (score key, ~index) pairs: the N best, ties by ascending index.
 // Nothing approximate reaches the output; if a query's candidates overflow their buffer, or its sample holds fewer than
-// N unmasked items, the pass is answered by the dense path: exact scores of every item (topn_exact_dense_kernel), known
+// N unmasked buckets, the pass is answered by the dense path: exact scores of every item (topn_exact_dense_kernel), known
 // items masked, 4-pass radix select of the N-th best, everything above it plus the ties sorted on the host.
 //
-// Error bound of the approximate score.  The item rows enter split, y = hi + lo + r with hi = bf16(y), lo = bf16(y - hi),
-// |r| <= 2^-18 |y|; the query vector enters as one bf16, x = xh + e, |e| <= 2^-9 |x|.  approx = sum (hi + lo) xh on
-// v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulate): |approx - sum x y| <= (2^-9 + 2^-18) sum |x_f y_f| plus the
-// accumulation of <= 128 terms (2^-17 of it); the reference's own roundings (fp32 products, final cast) are <= 2^-23 of
-// it.  In total < 2^-8.9 sum |x_f y_f| <= 2^-8.9 |x|_2 |y_i|_2 (Cauchy-Schwarz); the kernels use 2^-8, round both
-// factors of the margin UP to bf16, and add an absolute floor for the subnormal range.  For a query of n vectors the
-// filter vector is their mean and |x| is the mean of their norms (an upper bound of the norm of the mean, and of the
-// per-vector error sum).
+// Error bound of the approximate score.  Both operands enter as ONE bf16: y = yh + ey, |ey| <= 2^-9 |y|; x = xh + ex,
+// |ex| <= 2^-9 |x|.  approx = sum yh xh on v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulate):
+// |approx - sum x y| <= sum |x| |ey| + |ex| |yh| <= 2^-8 (1 + 2^-10) sum |x_f y_f|, plus the accumulation of <= 128 terms
+// (< 2^-16 of it) and the reference's own roundings (fp32 products, final cast: <= 2^-23 of it): in total
+// < 1.01 * 2^-8 sum |x_f y_f| <= 1.01 * 2^-8 |x|_2 |y_i|_2 (Cauchy-Schwarz).  The kernels use 1.25 * 2^-8, round both
+// factors of the margin UP to bf16, and add an absolute floor for the subnormal range.  (Until the middle of round 5 the item
+// rows entered split into two bf16 halves with a 2^-8 margin: one more matrix instruction and three more vector
+// instructions per element for 20 % fewer candidates -- not worth it: the filter is bound by instruction issue.)  For a
+// query of n vectors the filter vector is their mean and |x| is the mean of their norms (an upper bound of the norm of
+// the mean, and of the per-vector error sum).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,7 +44,8 @@ namespace mals {
 constexpr int TOPN_MAX_QUERIES = 64;      // dense path: queries per pass
 constexpr int TOPN_FILTER_QUERIES = 256;  // filter path: queries scored per read of Y
 constexpr int TOPN_FILTER_MAX_N = 64;     // largest how_many the filter path takes (the candidates of a query sit in LDS)
-constexpr float TOPN_MARGIN = 0.00390625f;  // 2^-8
+constexpr int TOPN_SAMPLE_GROUPS = 512;   // most workgroups of the sample kernel: 16 buckets per workgroup and query
+constexpr float TOPN_MARGIN = 0.0048828125f;  // 1.25 * 2^-8
 constexpr float TOPN_MARGIN_FLOOR = 1e-30f;
 constexpr int TOPN_COUNT_STRIDE = 32;  // candidate counters one per 128-byte line: atomics on one LINE serialise in L2 (97 us per pass when packed)
 
@@ -161,52 +166,62 @@ __global__ __launch_bounds__(256) void topn_prepare_kernel(const float* __restri
   }
 }
 
-// S = contraction steps of 32 features (features padded to 32 S); NT = query tiles of 16 per workgroup; the workgroup's
-// query tiles are [NT blockIdx.y, NT blockIdx.y + NT).
-// MODE 0: sample -- lower bounds (approx - margin) of every tile_stride-th tile into lb[q][slot], row length n_out;
-// MODE 1: filter -- (item i, query q) is a hit iff approx + margin_i - tau_q >= 0.  Hits go to a list PRIVATE to the
-//         wave (wave_hits[wave][..], wave_count[wave] counts them, also past wave_cap): positions come from a ballot, not
-//         from an atomic -- a returning atomic in this loop waits on the same counter as the prefetched rows, and with
-//         240 queries nearly every tile has a hit (measured: 284 us per pass with atomics).  topn_scatter_kernel
-//         sorts the hits into per-query candidate lists afterwards.
-// A wave owns U 16-item tiles at a time (U = 2 in MODE 1: every B operand fetched from LDS serves both): lane (g, c)
-// reads the contiguous quarter [8 S g, 8 S (g + 1)) of item c's row (the order of the features inside the contraction
-// is free); MFMA step s contracts features 8 S g + 8 s + j.  The item rows are split (hi + lo, 16 bits), the queries are
-// not (8 bits): |approx - exact| <= 2^-9 sum |x y|, the margin uses 2^-8.  The grid is persistent (as many workgroups as
-// fit the chip at once): the LDS image is loaded once per workgroup.
-template <int S, int NT, int MODE, bool ALIGNED>
-__global__ __launch_bounds__(256) void topn_filter_kernel(const float* __restrict__ Y, int64_t n_items, int k,
-                                                          const bf16x8* __restrict__ img, int n_queries,
-                                                          int tile_stride, int64_t n_out, float* __restrict__ lb,
+// ---- the streaming kernel: sample (MODE 0) and filter (MODE 1) ---------------------------------------------------------
+// S = contraction steps of 32 features (features padded to 32 S); QT = query tiles of 16 per wave, 4 QT per workgroup.
+// Query-stationary: wave w of the workgroup keeps its QT query tiles (tiles 4 j + w) as B operands in REGISTERS for the
+// whole kernel (QT (S + 1) x 4 registers).  A stage is 64 items = 4 item tiles: wave w loads tile w (prefetched one stage
+// ahead; lane (g, c) reads the contiguous quarter [8 S g, 8 S (g + 1)) of item c's row -- the order of the features inside
+// the contraction is free), converts it to bf16, computes the margin operand and writes the tile's S + 1 A operands to
+// LDS (3 KB at S = 2); after the barrier every wave runs all four tiles against its own query tiles: 4 QT accumulator
+// registers per tile, 4-5 waves per SIMD.  MFMA step s contracts features 8 S g + 8 s + j; the last step is the "margin
+// step": A = {|y_i|, 1, 1, 1, 0..}, B = the query's margin entry, so every accumulator ends as approx -+ margin_i (- tau_q).
+// (The first kernel of round 5 kept the ITEM operands in registers and fetched every query operand from LDS for every
+// pair of item tiles -- 75 KB of LDS reads per 32 items, 120 accumulator registers, one wave per SIMD: 138 us per pass
+// of 240 queries where the matrix pipe needs 31.)
+// MODE 0: sample -- every tile_stride-th tile; acc = approx - margin = a lower bound of the exact score.  Lane (g, c)
+//         register r of query tile j keeps the best lower bound it has seen and the item that attained it: the workgroup's
+//         BUCKET 4 g + r of query 16 (4 j + w) + c.  bmax / bidx [q][16 blockIdx.x + 4 g + r], row length 16 gridDim.x.
+//         An item's bucket follows from its index: stage = item / (64 tile_stride), workgroup = stage % gridDim.x,
+//         bucket = 16 workgroup + (item & 15).
+// MODE 1: filter -- all tiles; acc = approx + margin_i - tau_q; (item i, query q) is a hit iff acc is not below zero.
+//         Hits go to a list PRIVATE to the wave (wave_hits[wave][..], wave_count[wave] counts them, also past wave_cap):
+//         positions come from a ballot, not from an atomic -- a returning atomic in this loop waits on the same counter as
+//         the prefetched rows.  topn_scatter_kernel sorts the hits into per-query candidate lists afterwards.
+// The filter's grid is persistent (as many workgroups as fit the chip at once).
+template <int S, int QT, int MODE, bool ALIGNED>
+__global__ __launch_bounds__(256) void topn_stream_kernel(const float* __restrict__ Y, int64_t n_items, int k,
+                                                          const bf16x8* __restrict__ img, int n_queries, int tile_stride,
+                                                          float* __restrict__ bmax, uint32_t* __restrict__ bidx,
                                                           const float* __restrict__ tau, int wave_cap, unsigned* __restrict__ wave_count,
                                                           uint2* __restrict__ wave_hits) {
   constexpr int CH = 8 * S;  // features per lane
-  constexpr int U = MODE == 1 ? 2 : 1;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  bf16x8* bq = reinterpret_cast<bf16x8*>(smem);  // [NT][S + 1][64 lanes]
-  const int t_base = NT * blockIdx.y;
-  for (int i = threadIdx.x; i < NT * (S + 1) * 64; i += 256) bq[i] = img[(int64_t)t_base * (S + 1) * 64 + i];
-  __syncthreads();
-  if (MODE == 1) {  // -tau_q = hi + lo (lo rounded up) into slots 2, 3 of the margin entries
-    for (int i = threadIdx.x; i < NT * 16; i += 256) {
-      const int q = 16 * t_base + i;
+  constexpr int E = S + 1;   // A operands per item tile: S contraction steps + the margin step
+  __shared__ __attribute__((aligned(16))) bf16x8 sa[4 * E * 64];  // [item tile of the stage][operand][lane]
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  // this wave's query tiles, once
+  bf16x8 bq[QT][S], bm[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    const int t = 4 * j + w;
+#pragma unroll
+    for (int s = 0; s < S; ++s) bq[j][s] = img[(t * (S + 1) + s) * 64 + lane];
+    bf16x8 m = img[(t * (S + 1) + S) * 64 + lane];
+    if (MODE == 1 && g == 0) {  // -tau_q = hi + lo (lo rounded up) into slots 2, 3 of the margin entry
+      const int q = 16 * t + c;
       if (q < n_queries) {
         const float tq = tau[q];
         float v = -tq;
         if (!(tq > -__builtin_huge_valf())) v = 1e30f;  // no threshold: everything is a candidate (the pass falls back)
         const __bf16 hi = (__bf16)v;
-        const __bf16 lo = bf16_up(v - (float)hi);
-        bf16x8 m = bq[((i >> 4) * (S + 1) + S) * 64 + (i & 15)];
         m[2] = hi;
-        m[3] = lo;
-        bq[((i >> 4) * (S + 1) + S) * 64 + (i & 15)] = m;
+        m[3] = bf16_up(v - (float)hi);
       }
     }
-    __syncthreads();
+    bm[j] = m;
   }
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-  const int64_t step = (int64_t)tile_stride * 16;  // items between consecutive processed tiles
+  const int64_t step = (int64_t)tile_stride * 16;       // items between consecutive processed tiles
+  const int64_t n_proc = (n_items + step - 1) / step;   // processed tiles
+  const int64_t n_stages = (n_proc + 3) / 4;
   // ALIGNED (k == 32 S): four-float loads.  Otherwise one load per feature, the index clamped into the row: the padding
   // features meet zeros in the query operand, so what they hold does not matter -- and nothing here may branch on or
   // touch a loaded value (a wait for the loads would turn the prefetch into a plain load).
@@ -228,101 +243,105 @@ __global__ __launch_bounds__(256) void topn_filter_kernel(const float* __restric
       }
     }
   };
-  // wave w takes tile groups w, w + n_waves, ...; group j = tiles U j .. U j + U - 1 (of the processed tiles)
-  const int64_t n_proc = (n_items + step - 1) / step;       // processed tiles
-  const int64_t n_groups = (n_proc + U - 1) / U;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w;
   unsigned n_hits = 0;  // wave-uniform
   uint2* my_hits = MODE == 1 ? wave_hits + wave * (int64_t)wave_cap : nullptr;
-  float ynext[U][CH];
-  if (wave < n_groups)
+  f32x4t best[MODE == 0 ? QT : 1];
+  uint32_t besti[MODE == 0 ? QT : 1][4];
+  if (MODE == 0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) load_rows16((wave * U + u) * step, ynext[u]);
-  for (int64_t grp = wave; grp < n_groups; grp += n_waves) {
-    float yv[U][CH];
+    for (int j = 0; j < QT; ++j)
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int r = 0; r < 4; ++r) {
+        best[j][r] = -__builtin_huge_valf();
+        besti[j][r] = 0xffffffffu;
+      }
+  }
+  float ynext[CH];
+  if ((int64_t)blockIdx.x < n_stages) load_rows16((4 * (int64_t)blockIdx.x + w) * step, ynext);
+  for (int64_t st = blockIdx.x; st < n_stages; st += gridDim.x) {
+    float yv[CH];
 #pragma unroll
-      for (int s = 0; s < CH; ++s) yv[u][s] = ynext[u][s];
-    if (grp + n_waves < n_groups)
-#pragma unroll
-      for (int u = 0; u < U; ++u) load_rows16(((grp + n_waves) * U + u) * step, ynext[u]);  // the next rows fly during the MFMAs
-    bf16x8 ah[U][S], al[U][S], am[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      // |y_c| of the tile's 16 items: this lane's quarter, then the other three
+    for (int s = 0; s < CH; ++s) yv[s] = ynext[s];
+    if (st + gridDim.x < n_stages) load_rows16((4 * (st + gridDim.x) + w) * step, ynext);  // the next stage's rows fly during this one
+    // this wave's tile of the stage as A operands
+    bf16x8 ah[S], am;
+    {
       float nsq = 0.f;
 #pragma unroll
       for (int s = 0; s < CH; ++s)
-        if (ALIGNED || g * CH + s < k) nsq = __builtin_fmaf(yv[u][s], yv[u][s], nsq);
+        if (ALIGNED || g * CH + s < k) nsq = __builtin_fmaf(yv[s], yv[s], nsq);
       nsq += __shfl_xor(nsq, 16);
       nsq += __shfl_xor(nsq, 32);
-      const float ny = __builtin_sqrtf(nsq) * 1.0000005f;
+      const float ny = __builtin_sqrtf(nsq) * 1.0000005f;  // |y_c| of the tile's 16 items
 #pragma unroll
-      for (int j = 0; j < 8; ++j) am[u][j] = (__bf16)0.f;
+      for (int j = 0; j < 8; ++j) am[j] = (__bf16)0.f;
       if (g == 0) {
-        const float sgn = MODE == 0 ? -1.f : 1.f;  // the sample wants approx - margin
-        am[u][0] = MODE == 0 ? (__bf16)(-(float)bf16_up(ny)) : bf16_up(ny);
-        am[u][1] = (__bf16)sgn;
-        am[u][2] = (__bf16)1.f;
-        am[u][3] = (__bf16)1.f;
+        am[0] = MODE == 0 ? (__bf16)(-(float)bf16_up(ny)) : bf16_up(ny);  // the sample wants approx - margin
+        am[1] = (__bf16)(MODE == 0 ? -1.f : 1.f);
+        am[2] = (__bf16)1.f;
+        am[3] = (__bf16)1.f;
       }
 #pragma unroll
       for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = yv[u][8 * s + j];
-          const __bf16 h = (__bf16)v;
-          ah[u][s][j] = h;
-          al[u][s][j] = (__bf16)(v - (float)h);
-        }
+        for (int j = 0; j < 8; ++j) ah[s][j] = (__bf16)yv[8 * s + j];
     }
-    f32x4t acc[U][NT];
-    // The B operands come from LDS one step ahead, into two alternating register sets, pinned with scheduling barriers:
-    // left to itself the compiler reloads ONE register set right before its use and waits out the LDS latency in front of
-    // every group of matrix instructions (lgkmcnt(0) 45 times per tile pair: the matrix pipe idled half the time).
-    bf16x8 bb[2];
-    bb[0] = bq[lane];
+    __syncthreads();  // the previous stage has been read by everyone
 #pragma unroll
-    for (int j = 0; j < NT * (S + 1); ++j) {
-      const int t = j / (S + 1), s = j % (S + 1);
-      if (j + 1 < NT * (S + 1)) bb[(j + 1) & 1] = bq[(j + 1) * 64 + lane];
-      __builtin_amdgcn_sched_barrier(0);
-      const bf16x8 b = bb[j & 1];
+    for (int s = 0; s < S; ++s) sa[(w * E + s) * 64 + lane] = ah[s];
+    sa[(w * E + S) * 64 + lane] = am;
+    __syncthreads();
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (s == 0) acc[u][t] = f32x4t{0.f, 0.f, 0.f, 0.f};
-        if (s < S) {
-          acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[u][s], b, acc[u][t], 0, 0, 0);
-          acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[u][s], b, acc[u][t], 0, 0, 0);
-        } else {
-          acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[u], b, acc[u][t], 0, 0, 0);
+    for (int jt = 0; jt < 4; ++jt) {
+      const int64_t i0 = (4 * st + jt) * step;
+      bf16x8 a[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) a[e] = sa[(jt * E + e) * 64 + lane];
+      f32x4t acc[QT];
+#pragma unroll
+      for (int j = 0; j < QT; ++j) acc[j] = f32x4t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s], bq[j][s], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < QT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[S], bm[j], acc[j], 0, 0, 0);
+      if (i0 >= n_items) continue;  // uniform
+      // D layout: lane (g, c) register r = D[row 4 g + r][col c]: item 4 g + r of the tile, query 16 (4 j + w) + c
+      if (MODE == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t it = i0 + 4 * g + r;
+          const bool in = it < n_items;
+#pragma unroll
+          for (int j = 0; j < QT; ++j)
+            if (in && acc[j][r] > best[j][r]) {  // a NaN never wins
+              best[j][r] = acc[j][r];
+              besti[j][r] = (uint32_t)it;
+            }
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // D layout: lane (g, c) register r = D[row 4 g + r][col c]: item 4 g + r of the tile, query 16 (t_base + t) + c
+      } else {
+        // A candidate is an accumulator that is not below zero.  As signed integers the non-negative floats (and the
+        // quiet NaN the matrix pipe makes of an overflowing approximation, 0x7fc00000) are >= 0 and everything below zero
+        // is < 0: one signed maximum over the wave's 4 QT accumulators per item tile, the rare hits inside.
+        int32_t mj[QT];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t i0 = (grp * U + u) * step;
-      if (i0 >= n_items) continue;
+        for (int j = 0; j < QT; ++j)
+          mj[j] = max(max((int32_t)__float_as_uint(acc[j][0]), (int32_t)__float_as_uint(acc[j][1])),
+                      max((int32_t)__float_as_uint(acc[j][2]), (int32_t)__float_as_uint(acc[j][3])));
+        int32_t mx = mj[0];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int q = 16 * (t_base + t) + c;
-        if (MODE == 0) {
-          if (q < n_queries) {
+        for (int j = 1; j < QT; ++j) mx = max(mx, mj[j]);
+        if (__ballot(mx >= 0)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (i0 + 4 * g + r < n_items) lb[(int64_t)q * n_out + (grp * U + u) * 16 + 4 * g + r] = acc[u][t][r];
-          }
-        } else {
-          // a candidate is an accumulator that is not negative: one test per wave and query tile, the rare hits inside
-          const uint32_t all_neg = __float_as_uint(acc[u][t][0]) & __float_as_uint(acc[u][t][1]) & __float_as_uint(acc[u][t][2]) &
-                                   __float_as_uint(acc[u][t][3]);
-          if (__ballot(!(all_neg >> 31))) {
+          for (int j = 0; j < QT; ++j) {
+            if (!__ballot(mj[j] >= 0)) continue;
+            const int q = 16 * (4 * j + w) + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int64_t it = i0 + 4 * g + r;
-              const bool hit = !(acc[u][t][r] < 0.f) && it < n_items && q < n_queries;  // a NaN (overflow of the approximation) is a hit too
+              const bool hit = (int32_t)__float_as_uint(acc[j][r]) >= 0 && it < n_items && q < n_queries;
               const uint64_t hm = __ballot(hit);
               if (hm) {
                 const unsigned at = n_hits + (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
@@ -332,6 +351,18 @@ __global__ __launch_bounds__(256) void topn_filter_kernel(const float* __restric
             }
           }
         }
+      }
+    }
+  }
+  if (MODE == 0) {
+    const int64_t row_len = 16 * (int64_t)gridDim.x;
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+      const int q = 16 * (4 * j + w) + c;
+      if (q < n_queries) {
+        const int64_t at = (int64_t)q * row_len + 16 * (int64_t)blockIdx.x + 4 * g;
+        *reinterpret_cast<float4*>(bmax + at) = make_float4(best[j][0], best[j][1], best[j][2], best[j][3]);
+        *reinterpret_cast<uint4*>(bidx + at) = make_uint4(besti[j][0], besti[j][1], besti[j][2], besti[j][3]);
       }
     }
   }
@@ -384,40 +415,42 @@ __global__ void topn_exclude_kernel(const int64_t* __restrict__ excl_ptr, const 
   }
 }
 
-// tau[q] = a value that at least how_many entries of row q reach: the how_many-th largest of the 1024 per-thread
-// maxima of the row (thread t owns entries t, t + 1024, ...).  Those maxima are distinct entries, so the claim holds;
-// it is the exact how_many-th largest unless two of the best how_many share a thread, and a lower tau only lets a
-// few more candidates through.  -inf if fewer than how_many threads hold a finite entry (the dense path answers).
-// The known / excluded items of the query (RecommendIterator.java:75-82) are taken out of its row first, by this
-// workgroup (the row is its own).
-__global__ __launch_bounds__(1024) void topn_threshold_kernel(float* __restrict__ rows, int64_t n_row, int how_many,
-                                                              const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
+// tau[q] = a value that at least how_many unmasked items of the sample reach: the how_many-th largest of the 1024
+// per-thread maxima of the query's bucket row (thread t owns buckets t, t + 1024, ...).  Bucket maxima belong to distinct
+// items, so the claim holds; it is a lower estimate of the true how_many-th best of the sample, and a lower tau only lets
+// a few more candidates through.  -inf if fewer than how_many threads hold a finite entry (the dense path answers).
+// The known / excluded items of the query (RecommendIterator.java:75-82) go first: a bucket whose best item is one of
+// them is dropped whole (what else it holds is not known), by this workgroup (the row is its own).
+__global__ __launch_bounds__(1024) void topn_threshold_kernel(float* __restrict__ bmax, const uint32_t* __restrict__ bidx, int n_groups,
+                                                              int how_many, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                                               const int64_t* __restrict__ query_row, const int64_t* __restrict__ excl_ptr,
                                                               const int64_t* __restrict__ excl_idx, int64_t n_items, int tile_stride,
                                                               float* __restrict__ tau) {
   __shared__ unsigned h[256], sfx[256];
   __shared__ uint32_t s_prefix, s_rem;
   const int q = blockIdx.x;
-  float* row = rows + (int64_t)q * n_row;
+  const int64_t n_row = 16 * (int64_t)n_groups;
+  float* row = bmax + (int64_t)q * n_row;
+  const uint32_t* idx = bidx + (int64_t)q * n_row;
   const uint32_t ninf_key = score_key(-__builtin_huge_valf());
+  auto drop = [&](int64_t it) {
+    if (it < 0 || it >= n_items) return;
+    const int64_t tile = it >> 4;
+    if (tile % tile_stride) return;  // not in the sample
+    const int64_t b = 16 * (((tile / tile_stride) >> 2) % n_groups) + (it & 15);
+    if (idx[b] == (uint32_t)it) row[b] = -__builtin_huge_valf();
+  };
   if (query_row) {
     const int64_t r = query_row[q];
     if (r >= 0)
-      for (int64_t i = row_ptr[r] + threadIdx.x; i < row_ptr[r + 1]; i += 1024) {
-        const int64_t slot = topn_row_slot(col[i], tile_stride);
-        if (slot >= 0) row[slot] = -__builtin_huge_valf();
-      }
+      for (int64_t i = row_ptr[r] + threadIdx.x; i < row_ptr[r + 1]; i += 1024) drop(col[i]);
   }
   if (excl_ptr)
-    for (int64_t i = excl_ptr[q] + threadIdx.x; i < excl_ptr[q + 1]; i += 1024) {
-      const int64_t it = excl_idx[i];
-      const int64_t slot = (it >= 0 && it < n_items) ? topn_row_slot(it, tile_stride) : -1;
-      if (slot >= 0) row[slot] = -__builtin_huge_valf();
-    }
+    for (int64_t i = excl_ptr[q] + threadIdx.x; i < excl_ptr[q + 1]; i += 1024) drop(excl_idx[i]);
   __threadfence_block();
   __syncthreads();
   float best = -__builtin_huge_valf();
-  for (int64_t i = threadIdx.x; i < n_row; i += 1024) best = fmaxf(best, row[i]);   // NaN lower bounds are dropped by fmaxf
+  for (int64_t i = threadIdx.x; i < n_row; i += 1024) best = fmaxf(best, row[i]);
   const uint32_t key = score_key(best);
   if (threadIdx.x == 0) {
     s_prefix = 0;
@@ -471,14 +504,20 @@ __global__ __launch_bounds__(1024) void topn_threshold_kernel(float* __restrict_
 
 // ---- exact rescoring of the candidates --------------------------------------------------------------------------------
 // pairs[q][p] = (score key << 32) | ~item for p < min(count[q], cap), 0 for a candidate that is a known / excluded item
-// of the query (RecommendIterator.java:75-82).  One thread per candidate.
-__global__ __launch_bounds__(256) void topn_rescore_kernel(const float* __restrict__ Y, int k, const float* __restrict__ vecs,
-                                                           const int64_t* __restrict__ vrow, const int32_t* __restrict__ vptr, const unsigned* __restrict__ count, int cap,
-                                                           const uint32_t* __restrict__ cand, const int64_t* __restrict__ row_ptr,
-                                                           const int32_t* __restrict__ col, const int64_t* __restrict__ query_row,
-                                                           const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx,
-                                                           uint64_t* __restrict__ pairs) {
-  const int q = blockIdx.y;
+// of the query (RecommendIterator.java:75-82).  One wave per workgroup, 64 candidates at a time: their rows are staged in
+// LDS with coalesced loads (16 lanes per row), then lane l computes candidate l's score from LDS in the reference's
+// order.  (A lane walking its own row in global memory is 64 loads that each touch 64 different lines: 60 us per pass of
+// 240 queries.)  The query's known and excluded items pass through LDS a thousand at a time.
+__global__ __launch_bounds__(64) void topn_rescore_kernel(const float* __restrict__ Y, int k, const float* __restrict__ vecs,
+                                                          const int64_t* __restrict__ vrow, const int32_t* __restrict__ vptr, const unsigned* __restrict__ count, int cap,
+                                                          const uint32_t* __restrict__ cand, const int64_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ col, const int64_t* __restrict__ query_row,
+                                                          const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx,
+                                                          uint64_t* __restrict__ pairs) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  float* ys = reinterpret_cast<float*>(smem);  // [64][k + 1]
+  __shared__ uint32_t sk[1024];
+  const int q = blockIdx.y, lane = threadIdx.x, pitch = k + 1;
   const unsigned cq = count[(size_t)q * TOPN_COUNT_STRIDE];
   const unsigned n = cq < (unsigned)cap ? cq : (unsigned)cap;
   int64_t kb = 0, ke = 0, eb = 0, ee = 0;
@@ -493,24 +532,81 @@ __global__ __launch_bounds__(256) void topn_rescore_kernel(const float* __restri
     eb = excl_ptr[q];
     ee = excl_ptr[q + 1];
   }
-  for (unsigned p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
-    const uint32_t it = cand[(int64_t)q * cap + p];
+  const int64_t n_list = (ke - kb) + (ee - eb);
+  const int v0 = vptr[q], v1 = vptr[q + 1];
+  for (unsigned base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {
+    const unsigned p = base + lane;
+    const bool valid = p < n;
+    const uint32_t it = valid ? cand[(int64_t)q * cap + p] : 0u;
     bool struck = false;
-    for (int64_t i = kb; i < ke; ++i) struck |= (uint32_t)col[i] == it;           // the same list for the whole workgroup
-    for (int64_t i = eb; i < ee; ++i) struck |= excl_idx[i] == (int64_t)it;
-    uint64_t out = 0;
-    if (!struck) {
-      const float sc = topn_ref_score(Y + (int64_t)it * k, vecs, vrow, vptr[q], vptr[q + 1], k);
-      out = ((uint64_t)score_key(sc) << 32) | (uint64_t)(0xffffffffu - it);
+    for (int64_t c0 = 0; c0 < n_list; c0 += 1024) {
+      __syncthreads();
+      for (int i = lane; i < 1024 && c0 + i < n_list; i += 64) {
+        const int64_t at = c0 + i;
+        uint32_t v;
+        if (at < ke - kb) {
+          v = (uint32_t)col[kb + at];
+        } else {
+          const int64_t e = excl_idx[eb + (at - (ke - kb))];
+          v = (e >= 0 && e < 0xffffffffll) ? (uint32_t)e : 0xffffffffu;  // no candidate has this index
+        }
+        sk[i] = v;
+      }
+      __syncthreads();
+      const int len = (int)(n_list - c0 < 1024 ? n_list - c0 : 1024);
+      for (int i = 0; i < len; ++i) struck |= sk[i] == it;
     }
-    pairs[(int64_t)q * cap + p] = out;
+    // the 64 candidates' rows -> LDS: lane group (lane >> 4) takes row r + (lane >> 4), 16 lanes across the row
+    __syncthreads();
+    // (all sixteen loads of a sweep are issued before the first store: one memory latency per sweep, not sixteen)
+    if ((k & 3) == 0) {
+      for (int e0 = 0; e0 < k; e0 += 64) {
+        const int e = e0 + 4 * (lane & 15);
+        float4 t4[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t item = (uint32_t)__shfl((int)it, 4 * r + (lane >> 4));
+          t4[r] = e < k ? *reinterpret_cast<const float4*>(Y + (int64_t)item * k + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (e < k) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* d = ys + (4 * r + (lane >> 4)) * pitch + e;
+            d[0] = t4[r].x; d[1] = t4[r].y; d[2] = t4[r].z; d[3] = t4[r].w;
+          }
+        }
+      }
+    } else {
+      for (int e0 = 0; e0 < k; e0 += 16) {
+        const int e = e0 + (lane & 15);
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t item = (uint32_t)__shfl((int)it, 4 * r + (lane >> 4));
+          t[r] = e < k ? Y[(int64_t)item * k + e] : 0.f;
+        }
+        if (e < k) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ys[(4 * r + (lane >> 4)) * pitch + e] = t[r];
+        }
+      }
+    }
+    __syncthreads();
+    if (valid) {
+      uint64_t out = 0;
+      if (!struck) {
+        const float sc = topn_ref_score(ys + lane * pitch, vecs, vrow, v0, v1, k);
+        out = ((uint64_t)score_key(sc) << 32) | (uint64_t)(0xffffffffu - it);
+      }
+      pairs[(int64_t)q * cap + p] = out;
+    }
   }
 }
 // The N best of every query: how_many rounds of "largest remaining pair" over the query's candidates in LDS (a few
 // hundred pairs, N <= 64: cheaper than sorting them).  Pairs are unique (the item is part of them), larger = better
 // score, then lower index.  out_pairs[q][j], j < how_many: the j-th best (0 = none).
-// The pass's results in ONE block for one copy to the host: out_pairs [n_queries][how_many], then per query its
-// candidate count and tau, then the overflow word.
+// The pass's results in ONE block (the host's pinned block, written from here): out_pairs [n_queries][how_many], then per
+// query its candidate count and tau, then the overflow word.
 __global__ __launch_bounds__(256) void topn_final_kernel(const uint64_t* __restrict__ pairs, const unsigned* __restrict__ count, int cap,
                                                          int how_many, uint64_t* __restrict__ out_pairs, unsigned* __restrict__ count_out,
                                                          const float* __restrict__ tau, float* __restrict__ tau_out,
@@ -567,6 +663,7 @@ __global__ __launch_bounds__(256) void topn_final_kernel(const uint64_t* __restr
     }
     __syncthreads();
   }
+  if (threadIdx.x == 0) __threadfence_system();  // the block may be host memory (the pass's pinned result block)
 }
 
 // ---- the dense path: exact scores of every item -----------------------------------------------------------------------
