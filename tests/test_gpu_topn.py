@@ -129,6 +129,49 @@ def test_filter_path_matches_oracle(k, n_items, how_many):
             same_ranking(idx2[q], sc2[q], oidx, osc)
 
 
+@pytest.mark.parametrize("k,n_queries", [(64, 250), (80, 170), (16, 700), (128, 120), (50, 190)])
+def test_filter_path_full_passes_every_tile_count_and_all_slots(k, n_queries):
+    """Passes with 1-4 query tiles per wave (240 / 160 / 112 queries per pass at 32-64 / 65-96 / 97-128 features), a ragged last
+    pass, and more passes than streams: every query of the batch answered as if it were alone."""
+    core, X, Y, rp, col = big_core(k, 140_000, n_queries, 40, 500 + k)
+    with core:
+        users = np.arange(n_queries, dtype=np.int64)
+        idx, sc, cnt = core.recommend(users, 10)
+        rng = np.random.default_rng(k)
+        for q in sorted(set([0, 15, 16, n_queries - 1] + rng.integers(0, n_queries, 8).tolist())):
+            known = col[rp[q]:rp[q + 1]]
+            oidx, osc = to.recommend(Y, X[q], 10, known)
+            assert cnt[q] == 10
+            same_ranking(idx[q], sc[q], oidx, osc)
+        one = core.recommend(users[37:38], 10)
+        assert np.array_equal(one[0][0], idx[37]) and np.array_equal(one[1][0], sc[37])
+
+
+def test_filter_path_when_the_sample_is_won_by_known_items():
+    """A user whose known items are exactly the best-scoring items: the buckets they win are dropped from the threshold's
+    sample, the filter still finds the best of the rest."""
+    k, n_items = 32, 150_000
+    rng = np.random.default_rng(99)
+    Y = (rng.standard_normal((n_items, k)) / np.sqrt(k)).astype(np.float32)
+    X = (rng.standard_normal((3, k)) / np.sqrt(k)).astype(np.float32)
+    order = np.argsort(-(Y.astype(np.float64) @ X[1].astype(np.float64)))
+    known1 = np.sort(order[:5000]).astype(np.int32)                    # user 1 knows its 5000 best items
+    rp = np.array([0, 3, 3 + len(known1), 3 + len(known1)], dtype=np.int64)
+    col = np.concatenate([np.array([1, 2, 3], np.int32), known1])
+    with pkg.ALSCore(k) as core:
+        core.set_factor_rows(pkg.SIDE_X, 3)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_factors(pkg.SIDE_X, X)
+        core.set_factors(pkg.SIDE_Y, Y)
+        core.set_matrix(pkg.SIDE_X, rp, col, np.ones(len(col), np.float32))
+        idx, sc, cnt = core.recommend(np.arange(3, dtype=np.int64), 20)
+        for q in range(3):
+            known = col[rp[q]:rp[q + 1]]
+            oidx, osc = to.recommend(Y, X[q], 20, known)
+            same_ranking(idx[q], sc[q], oidx, osc)
+            assert not set(idx[q].tolist()) & set(known.tolist())
+
+
 def test_filter_path_equals_full_path(monkeypatch):
     core, X, Y, rp, col = big_core(32, 160_000, 20, 500, 3)
     with core:

@@ -57,10 +57,30 @@ def main():
         out["queries_per_pass"] = per_pass
         out["value"] = out["batches"]["4096"]["queries_per_s"]
         big = out["batches"]["4096"]
+        # the same 4096 queries with fewer queries per read of Y (MALS_TOPN_QUERIES_PER_PASS, the tuning knob of csrc/topn_host.h):
+        # more passes, each nearer the speed of one stream of Y
+        out["by_queries_per_pass"] = {}
+        users = rng.integers(0, a.users, 4096).astype(np.int64)
+        for pp in sorted({64, 128, per_pass}):
+            if pp > per_pass:
+                continue
+            os.environ["MALS_TOPN_QUERIES_PER_PASS"] = str(pp)
+            core.recommend(users, a.how_many)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                core.recommend(users, a.how_many)
+            dt = (time.perf_counter() - t0) / 10
+            passes = (4096 + pp - 1) // pp
+            out["by_queries_per_pass"][str(pp)] = {"ms_per_call": dt * 1e3, "queries_per_s": 4096 / dt, "passes": passes, "us_per_pass": dt * 1e6 / passes,
+                                                   "Y_GBps": passes * a.items * k * 4 / dt / 1e9, "Y_stream_frac": passes * a.items * k * 4 / dt / 8e12}
+        del os.environ["MALS_TOPN_QUERIES_PER_PASS"]
+        best = max(out["by_queries_per_pass"].values(), key=lambda d: d["Y_stream_frac"])
         out["roofline"] = {"bound": "hbm", "achieved": big["Y_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": big["Y_stream_frac"],
-                           "algorithmic_bytes": "items * 4k per pass of %d queries (Y streamed once per pass)" % per_pass,
+                           "algorithmic_bytes": "items * 4k per pass of %d queries (Y streamed once per pass; passes overlap on three streams)" % per_pass,
                            "at_64_queries_per_call": out["batches"]["64"]["Y_stream_frac"],
-                           "at_one_pass_per_call": out["batches"][str(per_pass)]["Y_stream_frac"]}
+                           "at_one_pass_per_call": out["batches"][str(per_pass)]["Y_stream_frac"],
+                           "best_over_queries_per_pass": {"frac": best["Y_stream_frac"], "queries_per_s": best["queries_per_s"],
+                                                          "queries_per_pass": [int(kk) for kk, v in out["by_queries_per_pass"].items() if v is best][0]}}
     if not a.no_cpu_baseline:
         from oracle import topn_oracle as to
         t0 = time.perf_counter()
