@@ -2044,8 +2044,8 @@ __global__ __launch_bounds__(256) void gramian_ref_kernel(const float* __restric
 // is 8 % of a k = 128 iteration; v_mfma_f32_16x16x16_f16 on operands split into two f16 halves (hi = the value rounded
 // to f16, lo = the exact residual rounded to f16: 22 significand bits, unbiased, every product exact) does a
 // 16x16x16 block in 3 x 16 cycles.  What fp64 bought -- no rounding in the sum -- is kept where it matters: a wave
-// accumulates in fp32 only over its slab of rows_per_slab rows (512: 32 steps), the slab partials are summed in fp64
-// in a fixed order by gramian_finalize_kernel.  Per slab the fp32 sum carries <= 6e-8 x sqrt(32) relative (random);
+// accumulates in fp32 only over its slab of rows_per_slab rows (512 .. 2048: gramian_slab_rows in mals_api.hip), the slab partials
+// are summed in fp64 in a fixed order by gramian_finalize_kernel.  Per slab the fp32 sum carries <= 6e-8 x sqrt(roundings) relative (random; 48 .. 192 roundings);
 // over the hundreds of slabs this kernel is used for that averages far below the reference's own product rounding
 // (MU:232 rounds every product to fp32), and stays at 3e-7 even when a handful of rows dominate G.  Small matrices keep the fp64 kernel (launch_gramian).
 // Operand scale: a power of two per wave, lowered (with an exact rescale of the accumulators) whenever a 16-row
@@ -2063,7 +2063,7 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
                                                                unsigned* __restrict__ ymax) {
   constexpr int E = T <= 4 ? 8 : 4, STEP = 4 * E;
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  const int64_t slab = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t slab = uniform64((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6));
   const int64_t r0 = slab * rows_per_slab;
   int64_t r1 = r0 + rows_per_slab;
   if (r1 > n_rows) r1 = n_rows;
@@ -2075,29 +2075,65 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
   // Loads ahead of their use (until round 4 a step waited for its own loads: 8 waves x 4 KB per CU in flight, 4.6 TB/s): a step's
   // raw registers are reloaded as soon as it has converted them, under its matrix instructions.  Steps past the end of the
   // slab read clamped rows and contribute zeros.
-  auto load_step = [&](int64_t r, float (&raw)[T][E]) {
+  // Addresses are 32-bit element offsets from the slab's (wave-uniform) base, one add per row of the step; rows and
+  // features are clamped / zeroed only in the steps that need it (the last step of a ragged slab; the last 16-block
+  // when k < 16 T).  Until the second half of round 5 every load carried a 64-bit row x k multiply and a clamp and every
+  // element a select: 550 vector instructions per step against 30 matrix instructions, 4.8 TB/s.
+  const int n_slab = (int)(r1 - r0);            // rows of this slab (uniform; <= 0 for the padding slabs of the last workgroup)
+  const float* __restrict__ base = M + (n_slab > 0 ? r0 : 0) * k;
+  const bool kfull = k == 16 * T;               // uniform
+  int fo[T];                                    // this lane's feature of 16-block v, clamped into the row
 #pragma unroll
-    for (int s4 = 0; s4 < E; ++s4) {
-      const int64_t row = r + E * g + s4;
-      const float* p = M + (row < r1 ? row : r0) * k;
+  for (int v = 0; v < T; ++v) fo[v] = 16 * v + c < k ? 16 * v + c : k - 1;
+  auto load_step = [&](int rl, float (&raw)[T][E]) {
+    if (rl + STEP <= n_slab) {  // uniform: every row of the step exists
+      // byte offsets: uniform base + 32-bit lane offset + the 16-block as the instruction's immediate
+      const char* bb = reinterpret_cast<const char*>(base);
+      const unsigned o0 = 4u * (unsigned)((rl + E * g) * k + c), last = 4u * (unsigned)(fo[T - 1] - c);
+      if (kfull) {  // uniform
 #pragma unroll
-      for (int v = 0; v < T; ++v) {
-        const int f = 16 * v + c;
-        raw[v][s4] = p[f < k ? f : k - 1];
+        for (int s4 = 0; s4 < E; ++s4) {
+          const unsigned o = o0 + 4u * (unsigned)(s4 * k);
+#pragma unroll
+          for (int v = 0; v < T; ++v) raw[v][s4] = *reinterpret_cast<const float*>(bb + o + 64 * v);
+        }
+      } else {
+#pragma unroll
+        for (int s4 = 0; s4 < E; ++s4) {
+          const unsigned o = o0 + 4u * (unsigned)(s4 * k);
+#pragma unroll
+          for (int v = 0; v < T - 1; ++v) raw[v][s4] = *reinterpret_cast<const float*>(bb + o + 64 * v);
+          raw[T - 1][s4] = *reinterpret_cast<const float*>(bb + (o + last));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s4 = 0; s4 < E; ++s4) {
+        const int row = rl + E * g + s4;
+        const unsigned o = (unsigned)((row < n_slab ? row : 0) * k);
+#pragma unroll
+        for (int v = 0; v < T; ++v) raw[v][s4] = base[o + (unsigned)fo[v]];
       }
     }
   };
-  auto do_step = [&](int64_t r, float (&raw)[T][E], int64_t reload) {
+  auto do_step = [&](int rl, float (&raw)[T][E], int reload) {
+    if (rl + STEP > n_slab) {  // uniform: rows past the end of the slab contribute zeros
+#pragma unroll
+      for (int s4 = 0; s4 < E; ++s4)
+        if (!(rl + E * g + s4 < n_slab))
+#pragma unroll
+          for (int v = 0; v < T; ++v) raw[v][s4] = 0.f;
+    }
+    if (!kfull) {  // uniform: so do the padding features of the last 16-block
+      if (!(16 * (T - 1) + c < k))
+#pragma unroll
+        for (int s4 = 0; s4 < E; ++s4) raw[T - 1][s4] = 0.f;
+    }
     float amax = 0.f;
 #pragma unroll
-    for (int s4 = 0; s4 < E; ++s4) {
-      const bool ok = r + E * g + s4 < r1;
+    for (int s4 = 0; s4 < E; ++s4)
 #pragma unroll
-      for (int v = 0; v < T; ++v) {
-        if (!(ok && 16 * v + c < k)) raw[v][s4] = 0.f;
-        amax = fmaxf(amax, fabsf(raw[v][s4]));
-      }
-    }
+      for (int v = 0; v < T; ++v) amax = fmaxf(amax, fabsf(raw[v][s4]));
     int m = __float_as_int(amax);  // non-negative floats order like their bit patterns
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     m = uniform(m);
@@ -2149,16 +2185,16 @@ __global__ __launch_bounds__(256, 2) void gramian_split_kernel(const float* __re
   };
   if constexpr (T <= 6) {
     float ra[T][E], rb[T][E];
-    load_step(r0, ra);
-    load_step(r0 + STEP, rb);
-    for (int64_t r = r0; r < r1; r += 2 * STEP) {
-      do_step(r, ra, r + 2 * STEP);
-      do_step(r + STEP, rb, r + 3 * STEP);
+    load_step(0, ra);
+    load_step(STEP, rb);
+    for (int rl = 0; rl < n_slab; rl += 2 * STEP) {
+      do_step(rl, ra, rl + 2 * STEP);
+      do_step(rl + STEP, rb, rl + 3 * STEP);
     }
   } else {
     float ra[T][E];
-    load_step(r0, ra);
-    for (int64_t r = r0; r < r1; r += STEP) do_step(r, ra, r + STEP);
+    load_step(0, ra);
+    for (int rl = 0; rl < n_slab; rl += STEP) do_step(rl, ra, rl + STEP);
   }
   int d2 = pw == 100 ? 0 : -2 * pw;
   d2 = d2 < -126 ? -126 : (d2 > 126 ? 126 : d2);

@@ -534,7 +534,17 @@ int drain_events(mals_handle h) {
 // slabs) from there on: even when a few rows dominate G (no averaging over slabs) the fp32 slab sums stay within
 // 6e-8 x sqrt(32) of it (als_kernels.h, gramian_split_kernel)
 constexpr int64_t GRAMIAN_SPLIT_MIN_ROWS = 262144;
-constexpr int64_t GRAMIAN_SLAB_ROWS = 512;
+// Rows a wave of gramian_split_kernel sums in fp32 before its partial goes to the fp64 stages.  512 keeps a 262144-row matrix
+// at 128 workgroups; from 4M rows on the 10 KB partial per slab (200 MB written and read again at 10M rows, a sixth of the
+// input) is worth more than the extra waves: 2048 there (10M x 64: 0.67 -> 0.53 ms).  fp32 roundings per accumulator and slab:
+// 3 per 32-row step, 192 at 2048 rows -- 8e-7 relative at random, averaged over thousands of slabs in fp64.
+inline int64_t gramian_slab_rows(int64_t n_rows) {
+  static const int64_t forced = std::getenv("MALS_GRAMIAN_SLAB_ROWS") ? std::atoll(std::getenv("MALS_GRAMIAN_SLAB_ROWS")) : 0;  // tuning override (a multiple of 64)
+  if (forced > 0) return forced;
+  int64_t slab = 512;
+  while (slab < 2048 && n_rows / (2 * slab) / 4 >= 1024) slab *= 2;
+  return slab;
+}
 
 template <int T>
 int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows, double* G_out, float* Gf_out, unsigned* ymax) {
@@ -542,7 +552,8 @@ int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows
   const int elems = tri(T) * 256;
   static const bool force_f64 = std::getenv("MALS_GRAMIAN_F64") != nullptr;  // A/B
   if (n_rows >= GRAMIAN_SPLIT_MIN_ROWS && !force_f64) {
-    int64_t n_slabs = (n_rows + GRAMIAN_SLAB_ROWS - 1) / GRAMIAN_SLAB_ROWS;
+    const int64_t slab_rows = gramian_slab_rows(n_rows);
+    int64_t n_slabs = (n_rows + slab_rows - 1) / slab_rows;
     n_slabs = (n_slabs + 3) & ~(int64_t)3;  // whole workgroups
     constexpr int GROUPS = 64;              // first-stage sums (doubles) behind the slab partials (floats)
     const size_t slab_bytes = sizeof(float) * (size_t)n_slabs * tri(T) * 256;
@@ -558,7 +569,7 @@ int launch_gramian_T(mals_handle h, SideState& s, const float* M, int64_t n_rows
     float* pf = reinterpret_cast<float*>(s.partials);
     double* pd = reinterpret_cast<double*>(reinterpret_cast<char*>(s.partials) + slab_bytes);  // slab_bytes is a multiple of 1024
     hipLaunchKernelGGL((gramian_split_kernel<T>), dim3((unsigned)(n_slabs / 4)), dim3(256), 0, h->stream, M, n_rows, k,
-                       GRAMIAN_SLAB_ROWS, pf, ymax);
+                       slab_rows, pf, ymax);
     hipLaunchKernelGGL(gramian_reduce_slabs_kernel, dim3((unsigned)((elems + 255) / 256), GROUPS), dim3(256), 0, h->stream, pf, n_slabs,
                        elems, GROUPS, pd);
     hipLaunchKernelGGL((gramian_finalize_kernel<T, false>), dim3(elems / 64), dim3(256), 0, h->stream, pd, (int64_t)GROUPS, k, G_out, Gf_out);
