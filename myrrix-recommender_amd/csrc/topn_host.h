@@ -2,7 +2,7 @@
 // exactness in topn_kernels.h).  Included by mals_api.hip inside its anonymous namespace, after mals_handle_s.
 #pragma once
 
-constexpr int TOPN_SLOTS = 3;  // passes in flight (each on its own stream)
+constexpr int TOPN_SLOTS = 3;  // passes in flight (each on its own stream; 4-6 measured no better)
 
 // Everything one pass of the filter path owns.  Passes are independent (Y, X and the known items are only read), so
 // pass p runs on stream p % TOPN_SLOTS: while the streaming filter kernel of one pass has the chip, the small kernels

@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void topn_prepare_kernel(const float* __restri
 // ahead; lane (g, c) reads the contiguous quarter [8 S g, 8 S (g + 1)) of item c's row -- the order of the features inside
 // the contraction is free), converts it to bf16, computes the margin operand and writes the tile's S + 1 A operands to
 // LDS (3 KB at S = 2); after the barrier every wave runs all four tiles against its own query tiles: 4 QT accumulator
-// registers per tile, 4-5 waves per SIMD.  MFMA step s contracts features 8 S g + 8 s + j; the last step is the "margin
+// registers per tile, 4-5 waves per SIMD.  (__launch_bounds__(256, 2): with at most 256 registers per lane the compiler puts
+// the accumulators into ordinary registers; with the default bound they land in AGPRs and every one of them costs a
+// v_accvgpr_read before the hit test -- a third of the kernel's vector instructions.)  MFMA step s contracts features 8 S g + 8 s + j; the last step is the "margin
 // step": A = {|y_i|, 1, 1, 1, 0..}, B = the query's margin entry, so every accumulator ends as approx -+ margin_i (- tau_q).
 // (The first kernel of round 5 kept the ITEM operands in registers and fetched every query operand from LDS for every
 // pair of item tiles -- 75 KB of LDS reads per 32 items, 120 accumulator registers, one wave per SIMD: 138 us per pass
@@ -189,14 +191,14 @@ __global__ __launch_bounds__(256) void topn_prepare_kernel(const float* __restri
 //         the prefetched rows.  topn_scatter_kernel sorts the hits into per-query candidate lists afterwards.
 // The filter's grid is persistent (as many workgroups as fit the chip at once).
 template <int S, int QT, int MODE, bool ALIGNED>
-__global__ __launch_bounds__(256) void topn_stream_kernel(const float* __restrict__ Y, int64_t n_items, int k,
+__global__ __launch_bounds__(256, 2) void topn_stream_kernel(const float* __restrict__ Y, int64_t n_items, int k,
                                                           const bf16x8* __restrict__ img, int n_queries, int tile_stride,
                                                           float* __restrict__ bmax, uint32_t* __restrict__ bidx,
                                                           const float* __restrict__ tau, int wave_cap, unsigned* __restrict__ wave_count,
                                                           uint2* __restrict__ wave_hits) {
   constexpr int CH = 8 * S;  // features per lane
   constexpr int E = S + 1;   // A operands per item tile: S contraction steps + the margin step
-  __shared__ __attribute__((aligned(16))) bf16x8 sa[4 * E * 64];  // [item tile of the stage][operand][lane]
+  __shared__ __attribute__((aligned(16))) bf16x8 sa2[2][4 * E * 64];  // two stages x [item tile of the stage][operand][lane]
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   // this wave's query tiles, once
   bf16x8 bq[QT][S], bm[QT];
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(256) void topn_stream_kernel(const float* __restric
   }
   float ynext[CH];
   if ((int64_t)blockIdx.x < n_stages) load_rows16((4 * (int64_t)blockIdx.x + w) * step, ynext);
+  int buf = 0;
   for (int64_t st = blockIdx.x; st < n_stages; st += gridDim.x) {
     float yv[CH];
 #pragma unroll
@@ -287,7 +290,10 @@ __global__ __launch_bounds__(256) void topn_stream_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) ah[s][j] = (__bf16)yv[8 * s + j];
     }
-    __syncthreads();  // the previous stage has been read by everyone
+    // two LDS buffers, one barrier per stage: a wave writes buffer b again only after the barrier of the stage in between,
+    // which every wave reaches after it has finished reading b (the second barrier per stage cost a quarter of the kernel)
+    bf16x8* sa = sa2[buf];
+    buf ^= 1;
 #pragma unroll
     for (int s = 0; s < S; ++s) sa[(w * E + s) * 64 + lane] = ah[s];
     sa[(w * E + S) * 64 + lane] = am;
