@@ -267,8 +267,19 @@ template <int S, int QT, int MODE>
 int topn_launch_stream_QT(mals_handle h, TopnSlot& sl, const float* Y, int64_t n_items, int k, int nq, int tile_stride, int* n_out) {
   const int64_t tiles = (n_items + 16 * (int64_t)tile_stride - 1) / (16 * (int64_t)tile_stride);
   const int64_t stages = (tiles + 3) / 4;
-  // resident workgroups per CU: LDS 4 (S + 1) KB each; registers ~70 (QT = 1) .. ~110 (QT = 4) per lane
-  int per_cu = QT <= 2 ? 6 : QT == 3 ? 5 : 4;
+  // resident workgroups per CU: what the instantiation's registers and LDS (two buffers of 4 (S + 1) KB) allow, asked once
+  const int lm = k == 32 * S ? 1 : (k & 3) == 0 ? 2 : (k & 1) == 0 ? 3 : 0;  // topn_stream_kernel's load mode
+  static int cached[4] = {0, 0, 0, 0};
+  int& per_cu_cached = cached[lm];
+  if (!per_cu_cached) {
+    int nb = 0;
+    const hipError_t e = lm == 1   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, topn_stream_kernel<S, QT, MODE, 1>, 256, 0)
+                         : lm == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, topn_stream_kernel<S, QT, MODE, 2>, 256, 0)
+                         : lm == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, topn_stream_kernel<S, QT, MODE, 3>, 256, 0)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, topn_stream_kernel<S, QT, MODE, 0>, 256, 0);
+    per_cu_cached = (e == hipSuccess && nb > 0) ? std::min(nb, 6) : 2;
+  }
+  int per_cu = per_cu_cached;
   if (const char* e = std::getenv("MALS_TOPN_BLOCKS_PER_CU")) per_cu = std::max(1, std::atoi(e));
   // the filter is a persistent grid; the sample's workgroups each keep 16 buckets per query
   const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(stages, MODE == 0 ? TOPN_SAMPLE_GROUPS : (int64_t)h->n_cu * per_cu));
@@ -287,14 +298,15 @@ int topn_launch_stream_QT(mals_handle h, TopnSlot& sl, const float* Y, int64_t n
   } else {
     *n_out = (int)grid;
   }
-  if (k == 32 * S)
-    hipLaunchKernelGGL((topn_stream_kernel<S, QT, MODE, true>), dim3(grid), dim3(256), 0, sl.stream, Y, n_items, k,
-                       static_cast<const bf16x8*>(sl.d_img), nq, tile_stride, sl.d_bmax, sl.d_bidx, sl.d_tau, TOPN_WAVE_CAP, sl.d_wcount,
-                       sl.d_whits);
-  else
-    hipLaunchKernelGGL((topn_stream_kernel<S, QT, MODE, false>), dim3(grid), dim3(256), 0, sl.stream, Y, n_items, k,
-                       static_cast<const bf16x8*>(sl.d_img), nq, tile_stride, sl.d_bmax, sl.d_bidx, sl.d_tau, TOPN_WAVE_CAP, sl.d_wcount,
-                       sl.d_whits);
+#define MALS_TOPN_GO(LM)                                                                                                              \
+  hipLaunchKernelGGL((topn_stream_kernel<S, QT, MODE, LM>), dim3(grid), dim3(256), 0, sl.stream, Y, n_items, k,                           \
+                     static_cast<const bf16x8*>(sl.d_img), nq, tile_stride, sl.d_bmax, sl.d_bidx, sl.d_tau, TOPN_WAVE_CAP, sl.d_wcount,   \
+                     sl.d_whits)
+  if (lm == 1) MALS_TOPN_GO(1);
+  else if (lm == 2) MALS_TOPN_GO(2);
+  else if (lm == 3) MALS_TOPN_GO(3);
+  else MALS_TOPN_GO(0);
+#undef MALS_TOPN_GO
   HIPCHK(h, hipGetLastError());
   return MALS_OK;
 }
@@ -335,10 +347,12 @@ TopnFilterPlan topn_plan(mals_handle h, int how_many) {
   p.cap = 48 * how_many + 2048;
   p.cap_pad = 1;
   while (p.cap_pad < p.cap) p.cap_pad <<= 1;
-  // sample items: expected candidates per query = how_many x stride.  An eighth of the items (at most 131072): the sample
-  // kernel keeps only bucket maxima, so its cost is an eighth of a filter pass, and every candidate less is less hit
-  // bookkeeping in the filter, less to scatter and rescore (16384 -> 131072 at a million items: 1.4x the queries per second)
-  int64_t target = std::max<int64_t>(512 * (int64_t)how_many, std::max<int64_t>(16384, std::min<int64_t>(131072, n_items / 8)));
+  // sample items: expected candidates per query = how_many x stride, spread like a negative binomial (sigma = mean / sqrt(N)).
+  // An eighth of the items: the sample kernel keeps only bucket maxima, so it costs an eighth of a filter pass whatever the
+  // catalogue, and every candidate less is less hit bookkeeping in the filter, less to scatter and rescore (16384 -> 131072 at
+  // a million items: 1.4x the queries per second).  A sample that does NOT grow with the catalogue lets the candidates grow
+  // with it instead: at 10M items a 131072-item sample put every fourth pass of 240 queries over its candidate buffers.
+  int64_t target = std::max<int64_t>(512 * (int64_t)how_many, std::max<int64_t>(16384, n_items / 8));
   if (const char* e = std::getenv("MALS_TOPN_SAMPLE_ITEMS")) target = std::max<int64_t>(1024, std::atoll(e));  // tuning override
   p.tile_stride = (int)std::max<int64_t>(1, n_items / target);
   p.stage_bytes = (size_t)TOPN_FILTER_QUERIES * ((size_t)how_many * 8 + 8) + 16;  // pairs | counts | taus | overflow word
@@ -403,8 +417,10 @@ int topn_pass_filter_enqueue(mals_handle h, TopnSlot& sl, const TopnRequest& rq,
   return MALS_OK;
 }
 
-// decode a finished pass; *ok = false: a query overflowed its candidate buffer or had a thin sample (the dense path answers)
-int topn_pass_filter_finish(mals_handle h, TopnSlot& sl, const TopnRequest& rq, const TopnPass& ps, const TopnFilterPlan& p, bool* ok) {
+// decode a finished pass; failed[q] != 0: query q of the pass overflowed its candidate buffer or had a thin sample (the dense
+// path answers it); all of them if a wave's hit list overflowed (whose hits are missing is not known)
+int topn_pass_filter_finish(mals_handle h, TopnSlot& sl, const TopnRequest& rq, const TopnPass& ps, const TopnFilterPlan& p,
+                            std::vector<uint8_t>& failed, bool* any_failed) {
   HIPCHK(h, hipEventSynchronize(sl.ev));
   const int how_many = rq.how_many;
   const uint8_t* st = sl.h_stage;
@@ -413,11 +429,15 @@ int topn_pass_filter_finish(mals_handle h, TopnSlot& sl, const TopnRequest& rq, 
   const float* tau = reinterpret_cast<const float*>(st + sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many + sizeof(unsigned) * TOPN_FILTER_QUERIES);
   const unsigned wave_overflow = *reinterpret_cast<const unsigned*>(st + sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many +
                                                                     (sizeof(unsigned) + sizeof(float)) * TOPN_FILTER_QUERIES);
-  *ok = wave_overflow == 0;
+  failed.assign((size_t)ps.nq, 0);
+  *any_failed = false;
   for (int q = 0; q < ps.nq; ++q)
-    if (count[q] > (unsigned)p.cap || !(tau[q] > -std::numeric_limits<float>::infinity())) *ok = false;
-  if (!*ok) return MALS_OK;
+    if (wave_overflow != 0 || count[q] > (unsigned)p.cap || !(tau[q] > -std::numeric_limits<float>::infinity())) {
+      failed[(size_t)q] = 1;
+      *any_failed = true;
+    }
   for (int q = 0; q < ps.nq; ++q) {
+    if (failed[(size_t)q]) continue;
     const size_t qq = (size_t)(ps.q0 + q);
     int n = 0;
     for (int j = 0; j < how_many; ++j) {
@@ -477,20 +497,28 @@ int topn_run(mals_handle h, const TopnRequest& rq) {
   // needed again: the device never waits for the host between passes.
   TopnPass inflight[TOPN_SLOTS];
   bool busy[TOPN_SLOTS] = {};
+  std::vector<uint8_t> failed;
   auto finish = [&](int s) -> int {
     if (!busy[s]) return MALS_OK;
     busy[s] = false;
-    bool ok = true;
+    bool any_failed = false;
     const TopnPass done = inflight[s];
-    if (int rc = topn_pass_filter_finish(h, w->slot[s], rq, done, p, &ok)) return rc;
-    if (!ok) {  // rare: answer the pass exactly the slow way (the slot's input block is free again: its pass has finished)
-      for (int q0 = done.q0; q0 < done.q0 + done.nq; q0 += TOPN_MAX_QUERIES) {
+    if (int rc = topn_pass_filter_finish(h, w->slot[s], rq, done, p, failed, &any_failed)) return rc;
+    if (any_failed) {  // rare: answer those queries exactly the slow way, run by run (the slot's input block is free again: its pass has finished)
+      for (int q = 0; q < done.nq;) {
+        if (!failed[(size_t)q]) {
+          ++q;
+          continue;
+        }
+        int e = q;
+        while (e < done.nq && failed[(size_t)e] && e - q < TOPN_MAX_QUERIES) ++e;
         TopnPass ps;
-        ps.q0 = q0;
-        ps.nq = std::min(TOPN_MAX_QUERIES, done.q0 + done.nq - q0);
+        ps.q0 = done.q0 + q;
+        ps.nq = e - q;
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (int rc = topn_upload_pass(h, w->slot[s], h->stream, rq, ps)) return rc;
         if (int rc = topn_pass_dense(h, w, w->slot[s], rq, ps)) return rc;
+        q = e;
       }
     }
     return MALS_OK;

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void topn_prepare_kernel(const float* __restri
 //         positions come from a ballot, not from an atomic -- a returning atomic in this loop waits on the same counter as
 //         the prefetched rows.  topn_scatter_kernel sorts the hits into per-query candidate lists afterwards.
 // The filter's grid is persistent (as many workgroups as fit the chip at once).
-template <int S, int QT, int MODE, bool ALIGNED>
+template <int S, int QT, int MODE, int LM>
 __global__ __launch_bounds__(256, 2) void topn_stream_kernel(const float* __restrict__ Y, int64_t n_items, int k,
                                                           const bf16x8* __restrict__ img, int n_queries, int tile_stride,
                                                           float* __restrict__ bmax, uint32_t* __restrict__ bidx,
@@ -224,18 +224,33 @@ __global__ __launch_bounds__(256, 2) void topn_stream_kernel(const float* __rest
   const int64_t step = (int64_t)tile_stride * 16;       // items between consecutive processed tiles
   const int64_t n_proc = (n_items + step - 1) / step;   // processed tiles
   const int64_t n_stages = (n_proc + 3) / 4;
-  // ALIGNED (k == 32 S): four-float loads.  Otherwise one load per feature, the index clamped into the row: the padding
-  // features meet zeros in the query operand, so what they hold does not matter -- and nothing here may branch on or
-  // touch a loaded value (a wait for the loads would turn the prefetch into a plain load).
+  // LM = how a lane loads its CH features: 1: k == 32 S, four-float loads; 2: k % 4 == 0, four-float loads with the index
+  // clamped into the row; 3: k % 2 == 0, two-float loads, clamped; 0: one load per feature, clamped.  The padding features
+  // meet zeros in the query operand, so what the clamped loads bring does not matter (they are left out of |y|) -- and
+  // nothing here may branch on or touch a loaded value (a wait for the loads would turn the prefetch into a plain load).
   auto load_rows16 = [&](int64_t i0, float (&yv)[CH]) {
     const int64_t item = i0 + c;
     const float* row = Y + (item < n_items ? item : 0) * k;  // rows past the end read row 0; dropped in the epilogue
-    if (ALIGNED) {
+    if (LM == 1) {
       const float4* y4 = reinterpret_cast<const float4*>(row + g * CH);
 #pragma unroll
       for (int v = 0; v < CH / 4; ++v) {
         const float4 t4 = y4[v];
         yv[4 * v] = t4.x; yv[4 * v + 1] = t4.y; yv[4 * v + 2] = t4.z; yv[4 * v + 3] = t4.w;
+      }
+    } else if (LM == 2) {
+#pragma unroll
+      for (int v = 0; v < CH / 4; ++v) {
+        const int f = g * CH + 4 * v;
+        const float4 t4 = *reinterpret_cast<const float4*>(row + (f < k ? f : k - 4));
+        yv[4 * v] = t4.x; yv[4 * v + 1] = t4.y; yv[4 * v + 2] = t4.z; yv[4 * v + 3] = t4.w;
+      }
+    } else if (LM == 3) {
+#pragma unroll
+      for (int v = 0; v < CH / 2; ++v) {
+        const int f = g * CH + 2 * v;
+        const float2 t2 = *reinterpret_cast<const float2*>(row + (f < k ? f : k - 2));
+        yv[2 * v] = t2.x; yv[2 * v + 1] = t2.y;
       }
     } else {
 #pragma unroll
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void topn_stream_kernel(const float* __rest
       float nsq = 0.f;
 #pragma unroll
       for (int s = 0; s < CH; ++s)
-        if (ALIGNED || g * CH + s < k) nsq = __builtin_fmaf(yv[s], yv[s], nsq);
+        if (LM == 1 || g * CH + s < k) nsq = __builtin_fmaf(yv[s], yv[s], nsq);
       nsq += __shfl_xor(nsq, 16);
       nsq += __shfl_xor(nsq, 32);
       const float ny = __builtin_sqrtf(nsq) * 1.0000005f;  // |y_c| of the tile's 16 items
