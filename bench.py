@@ -590,7 +590,9 @@ def main():
                        "arithmetic": ("per-row Gramian: operands split into two f16 halves (22 significand bits), exact products, fp32 accumulate"
                                       if split else "per-row Gramian: fp32 products, fp32 accumulate") +
                                      "; M^T M: fp64; Cholesky and solves: fp32; factors stored fp32 like the reference",
-                       "sharding": ("rows x%d, cost-balanced slices, RCCL below the C-ABI (mals_group_*): kxk all-reduce + exchange in %d chunks behind the solve" % (world, args.exchange_chunks))
+                       "sharding": ("rows x%d, cost-balanced slices, RCCL below the C-ABI (mals_group_*): kxk all-reduce + exchange in %d chunks behind the solve; "
+                                    "communicator size read back from every rank: %s"
+                                    % (world, args.exchange_chunks, sorted({r.get("comm_size") for r in ranks_info}) if ranks_info else "n/a"))
                                    if use_group else
                                    ("rows x%d, %s all-gather + kxk all-reduce (torch.distributed)" % (world, "in-place" if chunk_rows == 0 else "chunked (%d rows) pipelined" % chunk_rows)),
                        "slices": slice_info,

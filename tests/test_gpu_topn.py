@@ -172,6 +172,21 @@ def test_filter_path_when_the_sample_is_won_by_known_items():
             assert not set(idx[q].tolist()) & set(known.tolist())
 
 
+def test_queries_that_overflow_their_candidate_buffer_fall_back_one_by_one(monkeypatch):
+    """A sample far too small for the catalogue (tuning override): the thresholds are low, some queries of the pass collect more
+    candidates than their buffer holds and are answered by the dense path, the others by the filter -- all of them exactly."""
+    core, X, Y, rp, col = big_core(32, 200_000, 48, 30, 4242)
+    with core:
+        users = np.arange(48, dtype=np.int64)
+        want = core.recommend(users, 10)
+        monkeypatch.setenv("MALS_TOPN_SAMPLE_ITEMS", "1100")
+        got = core.recommend(users, 10)
+        assert all(np.array_equal(a, b) for a, b in zip(want, got))
+        for q in (0, 7, 47):
+            oidx, osc = to.recommend(Y, X[q], 10, col[rp[q]:rp[q + 1]])
+            same_ranking(got[0][q], got[1][q], oidx, osc)
+
+
 def test_filter_path_equals_full_path(monkeypatch):
     core, X, Y, rp, col = big_core(32, 160_000, 20, 500, 3)
     with core:
