@@ -311,7 +311,7 @@ int mals_reconstruction_error(mals_handle h, double* sum_out, int64_t* count_out
  * tags stay with the caller (tag items: pass them as exclusions).  On large item sets a bf16 MFMA pass with a
  * proven error margin only narrows the items down to a few hundred candidates per query, whose scores are then
  * computed exactly (csrc/topn_kernels.h); Y is streamed once per up to 240 queries, the passes of a call overlap
- * on three internal streams (ordered after the work already on the handle's stream; the call returns when all have
+ * on six internal streams (ordered after the work already on the handle's stream; the call returns when all have
  * finished). */
 int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, int32_t how_many, int32_t consider_known_items,
                    int64_t* item_idx_out, float* score_out, int32_t* n_out);

@@ -2,7 +2,7 @@
 // exactness in topn_kernels.h).  Included by mals_api.hip inside its anonymous namespace, after mals_handle_s.
 #pragma once
 
-constexpr int TOPN_SLOTS = 3;  // passes in flight (each on its own stream; 4-6 measured no better)
+constexpr int TOPN_SLOTS = 6;  // passes in flight, each on its own stream (3 -> 6: 3-4 % at 64-128 queries per pass, nothing at 240)
 
 // Everything one pass of the filter path owns.  Passes are independent (Y, X and the known items are only read), so
 // pass p runs on stream p % TOPN_SLOTS: while the streaming filter kernel of one pass has the chip, the small kernels
@@ -504,6 +504,11 @@ int topn_run(mals_handle h, const TopnRequest& rq) {
     bool any_failed = false;
     const TopnPass done = inflight[s];
     if (int rc = topn_pass_filter_finish(h, w->slot[s], rq, done, p, failed, &any_failed)) return rc;
+    if (any_failed && std::getenv("MALS_TOPN_DEBUG")) {
+      int nf = 0;
+      for (uint8_t f : failed) nf += f;
+      std::fprintf(stderr, "[mals top-N] pass at query %d (%d queries): %d to the dense path\n", done.q0, done.nq, nf);
+    }
     if (any_failed) {  // rare: answer those queries exactly the slow way, run by run (the slot's input block is free again: its pass has finished)
       for (int q = 0; q < done.nq;) {
         if (!failed[(size_t)q]) {

@@ -30,7 +30,7 @@ def main():
         core.set_matrix(pkg.SIDE_X, rp, col, val)
         users = rng.integers(0, n_users, 4096).astype(np.int64)
         ref = None
-        for slots, per_pass, sample in itertools.product((1, 3), (64, 128, 240), (65536, 131072)):
+        for slots, per_pass, sample in itertools.product((1, 3, 6), (64, 128, 240), (125000,)):
             os.environ["MALS_TOPN_SLOTS"] = str(slots)
             os.environ["MALS_TOPN_QUERIES_PER_PASS"] = str(per_pass)
             os.environ["MALS_TOPN_SAMPLE_ITEMS"] = str(sample)
