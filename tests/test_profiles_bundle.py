@@ -60,3 +60,20 @@ def test_documents_quote_this_bundle():
         q = ("%.1f" if w["ms_per_step"] >= 100 else "%.2f" if w["ms_per_step"] < 20 else "%.1f") % w["ms_per_step"]
         for doc in ("DESIGN.md", "BASELINE.md"):
             assert q in open(os.path.join(ROOT, doc)).read(), (doc, wl, q)
+
+
+def test_the_next_rows_carry_roofline_and_cpu_baseline_too():
+    t = last_json("r5_topn_1M_bench.json")
+    assert t["unit"] == "queries/s" and t["value"] == t["batches"]["4096"]["queries_per_s"]
+    r = t["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert set(t["by_queries_per_pass"]) >= {"64", "128"} and r["best_over_queries_per_pass"]["frac"] >= r["frac"] * 0.95
+    assert t["cpu_baseline"]["kind"] == "port" and t["cpu_baseline"]["value"] > 0
+    stats = open(os.path.join(PROF, "r5_topn_1M_kernel_stats.txt")).read()
+    assert "topn_stream_kernel" in stats and "topn_rescore_kernel" in stats
+    for name, unit in (("r5_ingest_text_1e9_bench.json", "lines/s"), ("r5_ingest_1e9_bench.json", "records/s")):
+        i = last_json(name)
+        assert i["unit"] == unit and i["value"] > 1e9 and 0.0 < i["roofline"]["frac"] < 1.0
+        assert i["cpu_baseline"]["kind"] == "port" and i["cpu_baseline"]["value"] > 0
+    i = last_json("r5_ingest_text_1e9_bench.json")
+    assert abs(i["value"] - i["lines"] / (i["ms"] * 1e-3)) / i["value"] < 1e-6 and i["full_parser_lines"] >= 0
