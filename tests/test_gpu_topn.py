@@ -187,6 +187,33 @@ def test_queries_that_overflow_their_candidate_buffer_fall_back_one_by_one(monke
             same_ranking(got[0][q], got[1][q], oidx, osc)
 
 
+def test_recommend_sees_the_half_iteration_enqueued_before_it():
+    """The passes of a call run on the library's own streams: they must wait for what is already on the handle's stream.  A
+    half-iteration (asynchronous) rewrites X; the recommendations that follow are those of the NEW user vectors."""
+    k, n_items, n_users = 32, 140_000, 300
+    rng = np.random.default_rng(31)
+    Y = (rng.standard_normal((n_items, k)) / np.sqrt(k)).astype(np.float32)
+    X0 = np.zeros((n_users, k), np.float32)                             # stale user vectors: all-zero scores
+    deg = 20
+    rp = np.arange(n_users + 1, dtype=np.int64) * deg
+    col = np.concatenate([np.sort(rng.choice(n_items, deg, replace=False)) for _ in range(n_users)]).astype(np.int32)
+    val = rng.uniform(0.5, 3.0, len(col)).astype(np.float32)
+    with pkg.ALSCore(k) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_factors(pkg.SIDE_X, X0)
+        core.set_factors(pkg.SIDE_Y, Y)
+        core.set_matrix(pkg.SIDE_X, rp, col, val)
+        users = np.arange(n_users, dtype=np.int64)
+        core.half_iteration(pkg.SIDE_X)                                 # enqueued, not waited for
+        idx, sc, cnt = core.recommend(users, 10)
+        X1 = core.get_factors(pkg.SIDE_X)
+        assert np.abs(X1).max() > 0
+        for q in (0, 17, 299):
+            oidx, osc = to.recommend(Y, X1[q], 10, col[rp[q]:rp[q + 1]])
+            same_ranking(idx[q], sc[q], oidx, osc)
+
+
 def test_filter_path_equals_full_path(monkeypatch):
     core, X, Y, rp, col = big_core(32, 160_000, 20, 500, 3)
     with core:
