@@ -89,8 +89,12 @@ def test_reference_shaped_file():
     assert info["header_lines"] == 1 and info["bad_lines"] == 0 and info["records"] == 9
 
 
+# MALS_TEXT_SEEDS=N: N more corpora of 2000-5000 lines with every share of odd lines (a longer hunt; profiles/r5_parity_evidence.txt)
+_MORE_TEXT = [(1000 + i, 2000 + 37 * (i % 83), [0.05, 0.25, 0.5, 0.75, 0.95][i % 5]) for i in range(int(os.environ.get("MALS_TEXT_SEEDS", "0")))]
+
+
 @pytest.mark.parametrize("seed,n_lines,p_odd", [(1, 1, 0.5), (2, 63, 0.5), (3, 64, 0.3), (4, 257, 0.6), (5, 5000, 0.25), (6, 40000, 0.1),
-                                                (7, 3000, 0.9), (8, 20000, 0.5)])
+                                                (7, 3000, 0.9), (8, 20000, 0.5)] + _MORE_TEXT)
 def test_fuzzed_corpus_matches_oracle(seed, n_lines, p_odd):
     info = check([build_corpus(seed, n_lines, p_odd)])
     if p_odd >= 0.25 and n_lines >= 3000:

@@ -1,5 +1,7 @@
 """top-N scoring on the device (mals_recommend / mals_recommend_vectors)
 against the oracle's restatement of RecommendIterator + TopN."""
+import os
+
 import numpy as np
 import pytest
 
@@ -240,7 +242,7 @@ def test_filter_path_with_massive_ties_and_exclusions():
             assert np.array_equal(idx[j], oidx) and np.array_equal(sc[j], osc)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MALS_TOPN_SEEDS", "40"))))   # MALS_TOPN_SEEDS=400: a longer hunt
 def test_seeded_recommend_sweep(seed):
     """Random feature counts, catalogue sizes (below and above the filter path's threshold), result counts, query
     batches, known-item handling and score structures (ties, negative scores, fewer candidates than results) against
