@@ -22,7 +22,7 @@
 //   4. rescore    exact reference arithmetic on the candidates only (a few hundred per query), known items struck.
 //   5. final      per query the N largest (score key, ~index) pairs: the N best, ties by ascending index.
 // Nothing approximate reaches the output; if a query's candidates overflow their buffer, or its sample holds fewer than
-// N unmasked buckets, the pass is answered by the dense path: exact scores of every item (topn_exact_dense_kernel), known
+// N unmasked buckets, that query is answered by the dense path (all queries of the pass if a wave's hit list overflowed): exact scores of every item (topn_exact_dense_kernel), known
 // items masked, 4-pass radix select of the N-th best, everything above it plus the ties sorted on the host.
 //
 // Error bound of the approximate score.  Both operands enter as ONE bf16: y = yh + ey, |ey| <= 2^-9 |y|; x = xh + ex,
