@@ -216,6 +216,32 @@ def test_recommend_sees_the_half_iteration_enqueued_before_it():
             same_ranking(idx[q], sc[q], oidx, osc)
 
 
+def test_a_million_items_at_the_bench_shape():
+    """The shape tools/bench_topn.py times (1M items, k = 64, N = 10, known items skipped), a 4096-query call: sampled queries
+    against the oracle, and every query's list a strictly descending-or-tied sequence of finite scores with no known item."""
+    k, n_items, n_users, deg = 64, 1_000_000, 5000, 100
+    rng = np.random.default_rng(20260929)
+    Y = (rng.standard_normal((n_items, k)) / np.sqrt(k)).astype(np.float32)
+    X = (rng.standard_normal((n_users, k)) / np.sqrt(k)).astype(np.float32)
+    rp = np.arange(n_users + 1, dtype=np.int64) * deg
+    col = np.sort(rng.integers(0, n_items, (n_users, deg)), axis=1).astype(np.int32).ravel()
+    with pkg.ALSCore(k) as core:
+        core.set_factor_rows(pkg.SIDE_X, n_users)
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_factors(pkg.SIDE_X, X)
+        core.set_factors(pkg.SIDE_Y, Y)
+        core.set_matrix(pkg.SIDE_X, rp, col, np.ones(len(col), np.float32))
+        users = rng.integers(0, n_users, 4096).astype(np.int64)
+        idx, sc, cnt = core.recommend(users, 10)
+        assert (cnt == 10).all() and np.isfinite(sc).all() and (np.diff(sc, axis=1) <= 0).all()
+        known = col.reshape(n_users, deg)[users]
+        assert not (idx[:, :, None] == known[:, None, :]).any()
+        for q in (0, 239, 240, 4095, int(rng.integers(0, 4096))):
+            u = users[q]
+            oidx, osc = to.recommend(Y, X[u], 10, col[rp[u]:rp[u + 1]])
+            same_ranking(idx[q], sc[q], oidx, osc)
+
+
 def test_filter_path_equals_full_path(monkeypatch):
     core, X, Y, rp, col = big_core(32, 160_000, 20, 500, 3)
     with core:
