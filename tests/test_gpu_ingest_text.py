@@ -302,6 +302,44 @@ def test_big_plain_file_round_trip():
         assert np.array_equal(a.ids(pkg.SIDE_X), b.ids(pkg.SIDE_X))
 
 
+def test_a_hundred_million_lines_equal_their_records():
+    """1e8 lines formatted on the device (with removes), in pieces split inside lines: the text path leaves exactly the
+    matrices, ids and counts the record path leaves for the same (user, item, value) stream -- the size-independent property
+    of this row (the pure-Python oracle replays 4e4 lines a second)."""
+    import torch
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_ingest", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_ingest.py"))
+    bi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bi)
+    n, n_users, n_items = 100_000_000, 5_000_000, 600_000
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    u = torch.randint(0, n_users, (n,), device="cuda", generator=gen)
+    i = (torch.rand(n, device="cuda", generator=gen).pow_(2.0) * n_items).long().clamp_(max=n_items - 1)
+    v = torch.randint(1, 6, (n,), device="cuda", generator=gen).float()
+    v[torch.rand(n, device="cuda", generator=gen) < 0.02] = float("nan")           # "user,item," = remove (IFR:137,165-167)
+    with ingest.Ingest(0) as a, ingest.Ingest(0) as b:
+        piece = 12_500_000
+        carry = None
+        for lo in range(0, n, piece):
+            t = bi.format_lines(torch, u[lo:lo + piece], i[lo:lo + piece], v[lo:lo + piece])
+            if carry is not None:
+                t = torch.cat([carry, t])
+            cut = t.numel() - 7 if lo + piece < n else t.numel()                   # hand over all but 7 bytes: a split inside a line
+            a.append_text(t[:cut], end_of_file=lo + piece >= n)
+            carry = t[cut:].clone() if cut < t.numel() else None
+            del t
+        info = a.text_info()
+        assert info["lines"] == n and info["records"] == n and info["bad_lines"] == 0 and info["header_lines"] == 0
+        b.append(u, i, v)
+        a.finish()
+        b.finish()
+        assert a.counts() == b.counts()
+        for side in (pkg.SIDE_X, pkg.SIDE_Y):
+            ca, cb = a.csr(side), b.csr(side)
+            assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1]) and np.array_equal(ca[2].view(np.uint32), cb[2].view(np.uint32))
+            assert np.array_equal(a.ids(side), b.ids(side))
+
+
 def test_known_items_reach_the_recommender():
     """generation.getKnownItemIDs() is what recommend() skips (ServerRecommender.java:394-425), and it keeps the entries
     removeSmall pruned from R (IFR:173-211): a user's near-zero entry is not recommended back to him."""
