@@ -368,8 +368,13 @@ __global__ void replay_pairs_kernel(const uint64_t* __restrict__ keys, const flo
       }
     }
     if (present) {
-      user_alive[(unsigned)(k >> 32)] = 1u;
-      item_alive[(unsigned)(k & 0xffffffffu)] = 1u;
+      // (test first: a popular item's flag is set by its first pair and then only read -- a billion 4-byte stores into the few
+      // megabytes of the item table are write traffic the L2 has to serialise per line; the flags are idempotent, a race only
+      // repeats a store)
+      unsigned* ua = user_alive + (unsigned)(k >> 32);
+      unsigned* ia = item_alive + (unsigned)(k & 0xffffffffu);
+      if (__atomic_load_n(ua, __ATOMIC_RELAXED) == 0u) *ua = 1u;
+      if (__atomic_load_n(ia, __ATOMIC_RELAXED) == 0u) *ia = 1u;
       pair_val[i] = v;
       if (present_out) present_out[i] = 1u;
       keep[i] = (fabsf(v) < zero_threshold) ? 0u : 1u;  // removeSmall, IFR:200-211 (NaN sums are kept, like there)
