@@ -143,18 +143,26 @@ int scan_u32(mals_ingest g, Scratch& s, const unsigned* in, unsigned* out, int64
 // Stable LSD radix sort of (keys[0], pay[0]) by the key digits >= first_digit; *result = index of the
 // buffer pair holding the sorted data.  Digits on which all keys agree are skipped.  K = uint32_t when the caller knows
 // that every key fits (ids below 2^32): 12 bytes less per record and pass, and a third workgroup per CU (LDS).
+// key_bound (optional): a value no key exceeds, when the caller knows one (dense ranks): the digits above it are skipped
+// without the pass over the keys that counts them.
 template <typename K, typename P>
-int radix_sort(mals_ingest g, Scratch& s, K* const (&keys)[2], P* const (&pay)[2], int64_t n, int* result, int first_digit = 0) {
+int radix_sort(mals_ingest g, Scratch& s, K* const (&keys)[2], P* const (&pay)[2], int64_t n, int* result, int first_digit = 0,
+               uint64_t key_bound = 0) {
   constexpr int ND = (int)sizeof(K);
   *result = 0;
   if (n <= 1) return MALS_OK;
-  ICHK(g, hipMemsetAsync(s.digit_tot, 0, 8 * 256 * sizeof(unsigned long long), g->stream));
-  hipLaunchKernelGGL(rs_digit_totals_kernel<K>, dim3(blocks_for(n, 256 * 16, 4096)), dim3(256), 0, g->stream, keys[0], n, s.digit_tot);
-  ICHK(g, hipGetLastError());
-  std::vector<unsigned long long> tot(8 * 256);
-  ICHK(g, hipMemcpyAsync(tot.data(), s.digit_tot, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream));
-  ICHK(g, hipStreamSynchronize(g->stream));
-  g->bytes_moved += (double)sizeof(K) * (double)n;
+  std::vector<unsigned long long> tot(8 * 256, 0ull);
+  if (key_bound != 0) {
+    for (int d = 0; d < ND; ++d)
+      if ((key_bound >> (8 * d)) == 0) tot[(size_t)d * 256] = (unsigned long long)n;  // every key has a zero there
+  } else {
+    ICHK(g, hipMemsetAsync(s.digit_tot, 0, 8 * 256 * sizeof(unsigned long long), g->stream));
+    hipLaunchKernelGGL(rs_digit_totals_kernel<K>, dim3(blocks_for(n, 256 * 16, 4096)), dim3(256), 0, g->stream, keys[0], n, s.digit_tot);
+    ICHK(g, hipGetLastError());
+    ICHK(g, hipMemcpyAsync(tot.data(), s.digit_tot, tot.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, g->stream));
+    ICHK(g, hipStreamSynchronize(g->stream));
+    g->bytes_moved += (double)sizeof(K) * (double)n;
+  }
   const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
   const unsigned grid = (unsigned)n_blocks;
   int cur = 0;
@@ -472,7 +480,8 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
     ICHK(g, hipGetLastError());
     g->bytes_moved += 24.0 * (double)nnz;
     int r2 = 0;
-    if (int rc = radix_sort<uint64_t, unsigned>(g, s, s.keys, s.pay, (int64_t)nnz, &r2, 4)) return rc;
+    // (the item half of the key is a dense index below n_items: no counting pass)
+    if (int rc = radix_sort<uint64_t, unsigned>(g, s, s.keys, s.pay, (int64_t)nnz, &r2, 4, ((uint64_t)(n_items > 0 ? n_items - 1 : 0) << 32) | 0xffffffffull)) return rc;
     hipLaunchKernelGGL(transpose_gather_kernel, dim3(blocks_for(nnz)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], (int64_t)nnz,
                        t.coo_row, g->col[1], g->val[1]);
     ICHK(g, hipGetLastError());
