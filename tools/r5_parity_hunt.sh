@@ -1,7 +1,7 @@
 #!/bin/bash
 # A longer parity hunt than the default suite (GPU box): more seeds of the ALS sweeps, of the top-N sweep and of the text-ingest
 # corpora, against their oracles.  Output: gpurun_out/r5_parity_evidence.txt
-export MALS_FUZZ_SEEDS=1500 MALS_TOPN_SEEDS=400 MALS_TEXT_SEEDS=150
+export MALS_FUZZ_SEEDS=${MALS_FUZZ_SEEDS:-1500} MALS_TOPN_SEEDS=${MALS_TOPN_SEEDS:-400} MALS_TEXT_SEEDS=${MALS_TEXT_SEEDS:-150}
 {
   echo "# MALS_FUZZ_SEEDS=$MALS_FUZZ_SEEDS MALS_TOPN_SEEDS=$MALS_TOPN_SEEDS MALS_TEXT_SEEDS=$MALS_TEXT_SEEDS (one MI355X, the library of this commit)"
   echo "## ALS sweeps (tests/test_gpu_fuzz.py)"
