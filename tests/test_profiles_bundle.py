@@ -77,3 +77,16 @@ def test_the_next_rows_carry_roofline_and_cpu_baseline_too():
         assert i["cpu_baseline"]["kind"] == "port" and i["cpu_baseline"]["value"] > 0
     i = last_json("r5_ingest_text_1e9_bench.json")
     assert abs(i["value"] - i["lines"] / (i["ms"] * 1e-3)) / i["value"] < 1e-6 and i["full_parser_lines"] >= 0
+
+
+def test_documents_quote_the_next_rows_of_this_bundle():
+    i = last_json("r5_ingest_text_1e9_bench.json")
+    ms = "%.0f ms" % i["ms"]
+    for doc in ("DESIGN.md", "BASELINE.md", "README.md"):
+        assert ms in open(os.path.join(ROOT, doc)).read(), (doc, ms)
+    t = last_json("r5_topn_1M_bench.json")
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for pp in ("64", "128"):
+        v = t["by_queries_per_pass"][pp]
+        assert ("%.2e" % v["queries_per_s"]).replace("e+0", "e") in text, (pp, v["queries_per_s"])
+    assert ("%.2e" % t["value"]).replace("e+0", "e") in text
