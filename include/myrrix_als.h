@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MALS_ABI_VERSION 4
+#define MALS_ABI_VERSION 5
 
 typedef struct mals_handle_s* mals_handle;
 
@@ -150,6 +150,9 @@ int mals_destroy(mals_handle h);
  * ExecutionException instead of a bare "create failed" (jni/myrrix_als_jni.c nativeCreateError). */
 int mals_create_error(char* buf, size_t cap);
 int mals_group_create_error(char* buf, size_t cap);
+
+/* cfg.features of the handle (0 for a null handle): lets a binding size-check factor and query-vector arrays. */
+int mals_features(mals_handle h);
 
 /* Human-readable message for the last non-OK status on this handle ("" if none). */
 const char* mals_last_error(mals_handle h);
@@ -315,6 +318,26 @@ int mals_reconstruction_error(mals_handle h, double* sum_out, int64_t* count_out
  * finished). */
 int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, int32_t how_many, int32_t consider_known_items,
                    int64_t* item_idx_out, float* score_out, int32_t* n_out);
+/* THREADS.  The reference's top-N is entered by every request thread at once, one user per call (ServerRecommender.java:
+ * 359-441 -> multithreadedTopN :443-508).  mals_recommend, mals_recommend_vectors and mals_recommend_to_many may be
+ * called on ONE handle from any number of threads concurrently (with each other -- not with calls that change the
+ * handle's matrices, factors, known or tag items).  A call is cheap only as part of a pass (one read of Y answers up to 240
+ * queries), so concurrent calls are folded into passes behind the ABI: every call becomes a ticket in the handle's queue;
+ * the first thread that finds no leader leads -- it packs the queued by-user calls of fewer than 64 queries into the next
+ * pass, enqueues it, decodes finished passes, wakes their callers -- and hands leadership on when its own answer is there.
+ * At most `passes_in_flight` passes (default 2, environment MALS_TOPN_FRONT_DEPTH at mals_create) are on the device at a
+ * time; what arrives meanwhile forms the next one.  Larger calls and caller-supplied vectors run exclusively, in queue
+ * order.  Every result is what the call alone would have returned (bit-identical).  mals_recommend_front_stats:
+ * out4 = {calls, queries, coalesced passes, exclusive calls} since mals_create. */
+int mals_recommend_front_stats(mals_handle h, int64_t* out4);
+int mals_recommend_set_depth(mals_handle h, int32_t passes_in_flight);   /* 1..6; not while calls are in flight */
+/* userTagIDs (RecommendIterator.java:72 -- "if (userTagIDs.contains(itemID)) return null"; likewise MostSimilarItemIterator
+ * .java:77): rows of Y that stand for tags of users (InputFilesReader.java:159-165) are never recommended, to anybody, by
+ * any mals_recommend* call.  item_idx: n dense item indices (host or device; entries outside [0, rows of Y) are ignored:
+ * a tag whose entries were all removed owns no row).  n = 0 clears.  Needs the item factor rows declared
+ * (mals_set_factor_rows).  mals_ingest_install / mals_ingest_install_group hand the ingest's userTagIDs over. */
+int mals_set_tag_items(mals_handle h, int64_t n, const int64_t* item_idx, int mem_kind);
+int mals_get_tag_item_count(mals_handle h, int64_t* n_out);   /* distinct rows of Y currently struck */
 /* The same for caller-supplied query vectors (n_queries x features, host) -- anonymous users / fold-in
  * (SR:561-606) -- with optional per-query lists of item indices to skip (CSR: exclude_ptr has
  * n_queries+1 entries; both NULL = none). */
@@ -348,7 +371,10 @@ int mals_recommend_to_many(mals_handle h, const float* vectors, const int64_t* v
  *   which may leave existing rows empty (IFR:200-211 removes entries, not rows).
  * Dense indices are assigned in ascending id order; CSR columns ascend within a row.  Side X = R by
  * user, side Y = R^T by item.  Records come from the caller (mals_ingest_append) or from the text of the
- * input files (mals_ingest_append_text / _read_file / _read_dir, below).  At most 2^31 records per ingest. */
+ * input files (mals_ingest_append_text / _read_file / _read_dir, below).  Up to 2^31 - 256 records go through one sort
+ * pipeline; more (C5: 5e9 lines) are finished user-id range by user-id range (MALS_INGEST_OPT_PARTITION_RECORDS), bounded
+ * by device memory: 24 bytes per record held + 8 per entry and matrix + the workspace of one range.  Dense indices are
+ * 32-bit: at most 2^31 - 256 distinct users and items. */
 typedef struct mals_ingest_s* mals_ingest;
 int mals_ingest_create(int32_t device, float zero_threshold, mals_ingest* out);
 int mals_ingest_destroy(mals_ingest g);
@@ -365,10 +391,19 @@ int mals_ingest_device_csr(mals_ingest g, int side, const int64_t** row_ptr, con
 /* mals_set_matrix(MALS_MEM_DEVICE) of both sides into a factorizer handle on the same device; the
  * handle borrows the arrays, so the ingest object must outlive their use. */
 int mals_ingest_install(mals_ingest g, mals_handle h);
+/* The device the ingest lives on, and its userTagIDs as rows of R^T: device_idx_out = a device array owned by the ingest
+ * (valid until the next finish / destroy) holding, per userTagID in ascending id order (mals_ingest_get_tag_ids), its dense
+ * item index, or -1 for a tag that owns no row at the end of the stream; n_out = the number of userTagIDs.  What
+ * mals_ingest_install passes to mals_set_tag_items. */
+int mals_ingest_device(mals_ingest g, int32_t* device_out);
+int mals_ingest_device_tag_items(mals_ingest g, const int64_t** device_idx_out, int64_t* n_out);
+int mals_ingest_get_tag_items(mals_ingest g, int64_t* host_idx_out);   /* the same array, copied to the host */
 /* last finish: HIP-event milliseconds of the pipeline, host milliseconds spent (re)allocating its
  * workspace (52 bytes per record, kept for later finishes; hipMalloc of tens of GB is slow), algorithmic
  * bytes read+written by all passes, radix passes run */
 int mals_ingest_stats(mals_ingest g, double* finish_ms, double* workspace_ms, double* bytes_moved, int32_t* radix_passes);
+/* last finish: user-id ranges and item ranges it was cut into (0, 0: one pipeline) */
+int mals_ingest_partitions(mals_ingest g, int32_t* user_ranges, int32_t* item_ranges);
 
 /* ---- the TEXT half of the same row: bytes of the input files -> records, on the device -----------------
  * Replaces the line loop of InputFilesReader.readInputFiles (IFR = online-local/src/net/myrrix/online/generation/
@@ -401,7 +436,11 @@ int mals_ingest_stats(mals_ingest g, double* finish_ms, double* workspace_ms, do
 /* KNOWN_ITEMS: also build knownItemIDs (off by default); TEXT_BLOCK_BYTES: bytes handed to the device at a time
  * (default 256 MiB); RESERVE_RECORDS: allocate the record arrays for this many records now (they grow by copying
  * otherwise) */
-enum { MALS_INGEST_OPT_KNOWN_ITEMS = 1, MALS_INGEST_OPT_TEXT_BLOCK_BYTES = 2, MALS_INGEST_OPT_RESERVE_RECORDS = 3 };
+/* PARTITION_RECORDS: most records ONE sort pipeline is given (52 bytes of workspace each); an ingest with more is finished
+ * user-id range by user-id range (csrc/ingest_big_host.h: same result, bit for bit).  0 = the default: one pipeline up to
+ * 2^31 - 256 records, ranges of 2^29 beyond -- which is how C5's 5e9 lines fit one 288 GB device next to their 120 GB of
+ * records.  (Tests set a few hundred to run the oracle suites through the partitioned path.) */
+enum { MALS_INGEST_OPT_KNOWN_ITEMS = 1, MALS_INGEST_OPT_TEXT_BLOCK_BYTES = 2, MALS_INGEST_OPT_RESERVE_RECORDS = 3, MALS_INGEST_OPT_PARTITION_RECORDS = 4 };
 enum { MALS_ITEM_TAG_IDS = 0, MALS_USER_TAG_IDS = 1 };
 int mals_ingest_set_option(mals_ingest g, int32_t option, int64_t value);
 int mals_ingest_append_text(mals_ingest g, const void* bytes, int64_t n_bytes, int mem_kind, int32_t end_of_file);
@@ -579,6 +618,17 @@ int mals_group_end_matrix(mals_group g, int side);
 /* How many entries the next n_rows rows of the chunked upload in progress hold (from the row_ptr given to begin): what a
  * binding checks its arrays against BEFORE mals_group_append_rows reads them. */
 int mals_group_pending_entries(mals_group g, int side, int64_t n_rows, int64_t* n_entries_out);
+/* InputFilesReader.readInputFiles -> the GROUP, without the detour through the host: after mals_ingest_finish both CSRs
+ * are cut at the group's cost-balanced bounds (mals_plan_shards on the ingest's row pointers) and every local member takes
+ * its slice of R and of R^T device to device -- borrowed in place when the member sits on the ingest's device, copied with
+ * hipMemcpyPeerAsync into arrays the group owns otherwise -- together with its slice of knownItemIDs (when the ingest built
+ * them) and the userTagIDs item mask.  Factor rows of both sides are declared from the ingest's counts (n_users, n_items)
+ * unless already declared at least that large.  In a one-process-per-GPU group every rank calls this with its OWN ingest of
+ * the same input (collective like mals_group_set_matrix).  flags = 0: the ingest must outlive the group's use of the
+ * borrowed slices; MALS_INSTALL_COPY: members on the ingest's device copy their slices too (8 bytes per entry and side more
+ * on that device) and the ingest -- its records and its 52 bytes per record of workspace -- can be destroyed right away. */
+enum { MALS_INSTALL_COPY = 1 };
+int mals_ingest_install_group(mals_ingest g, mals_group grp, int32_t flags);
 /* slice bounds of a side after its matrix was set: bounds_out[world+1] */
 int mals_group_bounds(mals_group g, int side, int64_t* bounds_out);
 

@@ -91,6 +91,11 @@ JNIEXPORT jint JNICALL JNI_FN(nativeReadInputDir)(JNIEnv* env, jclass cls, jlong
 /* dense index -> id of one side (side 0 = users / X, 1 = items / Y): ids must hold the side's count */
 JNIEXPORT jint JNICALL JNI_FN(nativeIngestIds)(JNIEnv* env, jclass cls, jlong g, jint side, jlongArray ids) {
   (void)cls;
+  /* the native side writes the side's count of ids: the array must hold them (a short one would corrupt the Java heap) */
+  int64_t n_users = 0, n_items = 0;
+  const int rc0 = mals_ingest_counts(as_ingest(g), NULL, &n_users, &n_items, NULL);
+  if (rc0 != MALS_OK) return rc0;
+  if (!ids || (side != 0 && side != 1) || (int64_t)(*env)->GetArrayLength(env, ids) < (side == 0 ? n_users : n_items)) return MALS_INVALID_ARG;
   jlong* p = (*env)->GetLongArrayElements(env, ids, NULL);
   if (!p) return MALS_OOM;
   const int rc = mals_ingest_get_ids(as_ingest(g), (int)side, (int64_t*)p);
@@ -101,6 +106,12 @@ JNIEXPORT jint JNICALL JNI_FN(nativeIngestIds)(JNIEnv* env, jclass cls, jlong g,
 /* itemTagIDs (which = 0) / userTagIDs (1), IFR:152-165: pass an array of n_item_tag_ids / n_user_tag_ids longs */
 JNIEXPORT jint JNICALL JNI_FN(nativeIngestTagIds)(JNIEnv* env, jclass cls, jlong g, jint which, jlongArray ids) {
   (void)cls;
+  mals_ingest_text_info_t ti;
+  ti.struct_size = (int32_t)sizeof ti;
+  const int rc0 = mals_ingest_text_info(as_ingest(g), &ti);
+  if (rc0 != MALS_OK) return rc0;
+  const int64_t need = which == 0 ? ti.n_item_tag_ids : ti.n_user_tag_ids;
+  if (!ids || (which != 0 && which != 1) || need < 0 || (int64_t)(*env)->GetArrayLength(env, ids) < need) return MALS_INVALID_ARG;
   jlong* p = (*env)->GetLongArrayElements(env, ids, NULL);
   if (!p) return MALS_OOM;
   const int rc = mals_ingest_get_tag_ids(as_ingest(g), (int32_t)which, (int64_t*)p);
@@ -126,6 +137,13 @@ JNIEXPORT jint JNICALL JNI_FN(nativeIngestSetSizes)(JNIEnv* env, jclass cls, jlo
 JNIEXPORT jint JNICALL JNI_FN(nativeIngestCsr)(JNIEnv* env, jclass cls, jlong g, jint side, jlongArray row_ptr, jintArray col_idx,
                                               jfloatArray val) {
   (void)cls;
+  int64_t n_users = 0, n_items = 0, nnz = 0;
+  const int rc0 = mals_ingest_counts(as_ingest(g), NULL, &n_users, &n_items, &nnz);
+  if (rc0 != MALS_OK) return rc0;
+  if (!row_ptr || !col_idx || !val || (side != 0 && side != 1) ||
+      (int64_t)(*env)->GetArrayLength(env, row_ptr) < (side == 0 ? n_users : n_items) + 1 ||
+      (int64_t)(*env)->GetArrayLength(env, col_idx) < nnz || (int64_t)(*env)->GetArrayLength(env, val) < nnz)
+    return MALS_INVALID_ARG;
   jlong* rp = (*env)->GetLongArrayElements(env, row_ptr, NULL);
   jint* ci = (*env)->GetIntArrayElements(env, col_idx, NULL);
   jfloat* v = (*env)->GetFloatArrayElements(env, val, NULL);
@@ -141,6 +159,15 @@ JNIEXPORT jint JNICALL JNI_FN(nativeIngestCsr)(JNIEnv* env, jclass cls, jlong g,
 /* knownItemIDs as CSR over the dense user indices (IFR:172-191): ptr has users + 1 longs, itemIdx the known entries */
 JNIEXPORT jint JNICALL JNI_FN(nativeIngestKnownItems)(JNIEnv* env, jclass cls, jlong g, jlongArray ptr, jintArray item_idx) {
   (void)cls;
+  int64_t n_users = 0;
+  mals_ingest_text_info_t ti;
+  ti.struct_size = (int32_t)sizeof ti;
+  int rc0 = mals_ingest_counts(as_ingest(g), NULL, &n_users, NULL, NULL);
+  if (rc0 == MALS_OK) rc0 = mals_ingest_text_info(as_ingest(g), &ti);
+  if (rc0 != MALS_OK) return rc0;
+  if (!ptr || !item_idx || ti.n_known_items < 0 || (int64_t)(*env)->GetArrayLength(env, ptr) < n_users + 1 ||
+      (int64_t)(*env)->GetArrayLength(env, item_idx) < ti.n_known_items)
+    return MALS_INVALID_ARG;
   jlong* p = (*env)->GetLongArrayElements(env, ptr, NULL);
   jint* ii = (*env)->GetIntArrayElements(env, item_idx, NULL);
   int rc = MALS_OOM;
@@ -176,11 +203,13 @@ JNIEXPORT jint JNICALL JNI_FN(nativeSetKnownItems)(JNIEnv* env, jclass cls, jlon
   (void)cls;
   if (!row_ptr) return mals_set_known_items(as_handle(handle), 0, NULL, NULL, MALS_MEM_HOST);
   const jsize n = (*env)->GetArrayLength(env, row_ptr);
-  if (n < 1) return MALS_INVALID_ARG;
+  if (n < 1 || !item_idx) return MALS_INVALID_ARG;
   jlong* rp = (*env)->GetLongArrayElements(env, row_ptr, NULL);
   jint* ii = (*env)->GetIntArrayElements(env, item_idx, NULL);
   int rc = MALS_OOM;
-  if (rp && ii) rc = mals_set_known_items(as_handle(handle), (int64_t)n - 1, (const int64_t*)rp, (const int32_t*)ii, MALS_MEM_HOST);
+  /* the offsets index item_idx: they must stay inside it */
+  if (rp && ii && (rp[0] != 0 || rp[n - 1] < 0 || rp[n - 1] > (jlong)(*env)->GetArrayLength(env, item_idx))) rc = MALS_INVALID_ARG;
+  else if (rp && ii) rc = mals_set_known_items(as_handle(handle), (int64_t)n - 1, (const int64_t*)rp, (const int32_t*)ii, MALS_MEM_HOST);
   if (ii) (*env)->ReleaseIntArrayElements(env, item_idx, ii, JNI_ABORT);
   if (rp) (*env)->ReleaseLongArrayElements(env, row_ptr, rp, JNI_ABORT);
   return rc;
@@ -231,9 +260,18 @@ JNIEXPORT jint JNICALL JNI_FN(nativeRecommendToMany)(JNIEnv* env, jclass cls, jl
   jfloat* sc = (*env)->GetFloatArrayElements(env, scores, NULL);
   jint* cn = counts ? (*env)->GetIntArrayElements(env, counts, NULL) : NULL;
   int rc = MALS_OOM;
-  if (v && it && sc && (vp || !vector_ptr) && (ep || !exclude_ptr) && (ei || !exclude_idx) && (cn || !counts))
+  if (v && it && sc && (vp || !vector_ptr) && (ep || !exclude_ptr) && (ei || !exclude_idx) && (cn || !counts)) {
+    /* what the offsets promise must be inside the arrays they index */
+    mals_handle hh = as_handle(handle);
+    const int64_t n_vec = vp ? (int64_t)vp[n_queries] : (int64_t)n_queries;
+    const int64_t features = (int64_t)mals_features(hh);
+    if (n_vec < 0 || features <= 0 || (int64_t)(*env)->GetArrayLength(env, vectors) < n_vec * features ||
+        (ep && (ep[n_queries] < 0 || (int64_t)(*env)->GetArrayLength(env, exclude_idx) < (int64_t)ep[n_queries])))
+      rc = MALS_INVALID_ARG;
+    else
     rc = mals_recommend_to_many(as_handle(handle), (const float*)v, (const int64_t*)vp, (int32_t)n_queries, (int32_t)how_many, (const int64_t*)ep,
                                 (const int64_t*)ei, (int64_t*)it, (float*)sc, (int32_t*)cn);
+  }
   const jint mode = rc == MALS_OK ? 0 : JNI_ABORT;
   if (cn) (*env)->ReleaseIntArrayElements(env, counts, cn, mode);
   if (sc) (*env)->ReleaseFloatArrayElements(env, scores, sc, mode);

@@ -14,10 +14,11 @@ FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
 SOLVE_AUTO, SOLVE_DIRECT, SOLVE_DUAL = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 GROUP_RCCL, GROUP_PEER_COPY = 0, 1
-INGEST_OPT_KNOWN_ITEMS, INGEST_OPT_TEXT_BLOCK_BYTES, INGEST_OPT_RESERVE_RECORDS = 1, 2, 3
+INGEST_OPT_KNOWN_ITEMS, INGEST_OPT_TEXT_BLOCK_BYTES, INGEST_OPT_RESERVE_RECORDS, INGEST_OPT_PARTITION_RECORDS = 1, 2, 3, 4
 ITEM_TAG_IDS, USER_TAG_IDS = 0, 1
+INSTALL_COPY = 1
 
 STATUS_NAMES = {OK: "OK", SINGULAR: "SINGULAR", INVALID_ARG: "INVALID_ARG", HIP_ERROR: "HIP_ERROR",
                 COMM_ERROR: "COMM_ERROR", CANCELLED: "CANCELLED", OOM: "OOM",
@@ -147,6 +148,15 @@ SYMBOLS = {
     "mals_recommend_vectors": (ctypes.c_int, [_H, _P, _I32, _I32, _P, _P, _P, _P, _P]),
     "mals_set_known_items": (ctypes.c_int, [_H, _I64, _P, _P, ctypes.c_int]),
     "mals_recommend_to_many": (ctypes.c_int, [_H, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "mals_features": (ctypes.c_int, [_H]),
+    "mals_recommend_front_stats": (ctypes.c_int, [_H, _P]),
+    "mals_recommend_set_depth": (ctypes.c_int, [_H, _I32]),
+    "mals_set_tag_items": (ctypes.c_int, [_H, _I64, _P, ctypes.c_int]),
+    "mals_get_tag_item_count": (ctypes.c_int, [_H, ctypes.POINTER(_I64)]),
+    "mals_ingest_device": (ctypes.c_int, [_H, ctypes.POINTER(_I32)]),
+    "mals_ingest_device_tag_items": (ctypes.c_int, [_H, ctypes.POINTER(_P), ctypes.POINTER(_I64)]),
+    "mals_ingest_get_tag_items": (ctypes.c_int, [_H, _P]),
+    "mals_ingest_install_group": (ctypes.c_int, [_H, _H, _I32]),
     "mals_ingest_create": (ctypes.c_int, [_I32, ctypes.c_float, ctypes.POINTER(_H)]),
     "mals_ingest_destroy": (ctypes.c_int, [_H]),
     "mals_ingest_last_error": (ctypes.c_char_p, [_H]),
@@ -160,6 +170,7 @@ SYMBOLS = {
     "mals_ingest_stats": (ctypes.c_int, [_H, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I32)]),
     "mals_ingest_set_option": (ctypes.c_int, [_H, _I32, _I64]),
+    "mals_ingest_partitions": (ctypes.c_int, [_H, ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     "mals_ingest_append_text": (ctypes.c_int, [_H, _P, _I64, ctypes.c_int, _I32]),
     "mals_ingest_read_file": (ctypes.c_int, [_H, ctypes.c_char_p]),
     "mals_ingest_read_dir": (ctypes.c_int, [_H, ctypes.c_char_p, ctypes.POINTER(_I32)]),

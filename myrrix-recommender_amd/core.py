@@ -365,6 +365,26 @@ class ALSCore:
         ii = _host(item_idx, np.int32)
         self._chk(self._L.mals_set_known_items(self._h, len(rp) - 1, rp.ctypes.data_as(ctypes.c_void_p), ii.ctypes.data_as(ctypes.c_void_p), MEM_HOST))
 
+    def set_tag_items(self, item_idx):
+        """userTagIDs as dense item indices: rows of Y that no recommend call returns (RecommendIterator.java:72); None or
+        empty clears."""
+        ii = _host(item_idx if item_idx is not None else [], np.int64)
+        self._chk(self._L.mals_set_tag_items(self._h, len(ii), ii.ctypes.data_as(ctypes.c_void_p) if len(ii) else None, MEM_HOST))
+
+    def tag_item_count(self):
+        n = ctypes.c_int64(0)
+        self._chk(self._L.mals_get_tag_item_count(self._h, ctypes.byref(n)))
+        return n.value
+
+    def recommend_front_stats(self):
+        """{calls, queries, passes, exclusive} of the serving front since the handle was created."""
+        o = np.zeros(4, dtype=np.int64)
+        self._chk(self._L.mals_recommend_front_stats(self._h, o.ctypes.data_as(ctypes.c_void_p)))
+        return {"calls": int(o[0]), "queries": int(o[1]), "passes": int(o[2]), "exclusive": int(o[3])}
+
+    def recommend_set_depth(self, passes_in_flight):
+        self._chk(self._L.mals_recommend_set_depth(self._h, int(passes_in_flight)))
+
     def recommend_to_many(self, queries, how_many, exclude=None):
         """recommendToMany (ServerRecommender.java:366-441): queries = list of (n_j x features) arrays, one per query; the
         score of an item is the mean of its dots with the query's vectors (RecommendIterator.java:93-104)."""

@@ -19,6 +19,10 @@
 
 using namespace mals;
 
+constexpr int64_t MALS_INGEST_MAX_RECORDS = (int64_t)1 << 36;       // (the record arrays alone are 1.6 TB there)
+constexpr int64_t MALS_INGEST_ONE_SHOT_MAX = (int64_t)0x7fffff00;   // what one sort pipeline holds (32-bit positions)
+constexpr int64_t MALS_INGEST_DEFAULT_PART = (int64_t)1 << 29;      // records per user range beyond that (ingest_big_host.h)
+
 struct mals_ingest_s {
   int device = 0;
   float zero_threshold = 1.0e-4f;
@@ -81,6 +85,9 @@ struct mals_ingest_s {
   int64_t n_known = 0;
   int64_t* known_ptr = nullptr;  // knownItemIDs as a CSR over the dense user / item indices
   int32_t* known_idx = nullptr;
+  int64_t* tag_item_idx = nullptr;  // dense item index of every userTagID (ascending ids), -1: the tag owns no row of R^T
+  int64_t part_cap = 0;       // MALS_INGEST_OPT_PARTITION_RECORDS (0: default) -- ingest_big_host.h
+  int32_t last_partitions = 0, last_item_ranges = 0;
 };
 
 namespace {
@@ -196,6 +203,7 @@ void free_results(mals_ingest g) {
   }
   dfree(g->known_ptr);
   dfree(g->known_idx);
+  dfree(g->tag_item_idx);
   g->n_known = 0;
   g->finished = false;
   g->n_users = g->n_items = g->nnz = 0;
@@ -245,7 +253,7 @@ int mals_ingest_append(mals_ingest g, int64_t n, const int64_t* user_ids, const 
   if (!g) return MALS_INVALID_ARG;
   if (n < 0 || (n > 0 && (!user_ids || !item_ids || !values))) return fail(g, MALS_INVALID_ARG, "bad record arrays");
   if (mem_kind != MALS_MEM_HOST && mem_kind != MALS_MEM_DEVICE) return fail(g, MALS_INVALID_ARG, "mem_kind must be MALS_MEM_HOST or MALS_MEM_DEVICE");
-  if (g->n + n >= (int64_t)0x7fffff00) return fail(g, MALS_INVALID_ARG, "at most 2^31 records per ingest");
+  if (g->n + n >= MALS_INGEST_MAX_RECORDS) return fail(g, MALS_INVALID_ARG, "at most 2^36 records per ingest");
   if (n == 0) return MALS_OK;
   ICHK(g, hipSetDevice(g->device));
   if (g->finished) free_results(g);
@@ -309,14 +317,23 @@ struct FinishTmp {  // small per-finish device temporaries (sized by the number 
   }
 };
 
+// the records a sort pipeline works on: all of the ingest's, or one user range of them (ingest_big_host.h)
+struct Records {
+  const int64_t* user;
+  const int64_t* item;
+  const float* value;
+  int64_t n;
+};
+
 // 1. records sorted by item id (stable: stream order inside an item); dense item rank of every position
 template <typename K>
-static int stage_items(mals_ingest g, Scratch& s, FinishTmp& t, int64_t n, bool user32, int* ra_out, unsigned* n_i_all) {
+static int stage_items(mals_ingest g, Scratch& s, FinishTmp& t, const Records& rec, bool user32, int* ra_out, unsigned* n_i_all) {
+  const int64_t n = rec.n;
   K* const kb[2] = {reinterpret_cast<K*>(s.keys[0]), reinterpret_cast<K*>(s.keys[1])};
   if (user32)
-    hipLaunchKernelGGL((item_stage_kernel<K, true>), dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_item, g->d_user, g->d_value, n, kb[0], s.pay64[0]);
+    hipLaunchKernelGGL((item_stage_kernel<K, true>), dim3(blocks_for(n)), dim3(256), 0, g->stream, rec.item, rec.user, rec.value, n, kb[0], s.pay64[0]);
   else
-    hipLaunchKernelGGL((item_stage_kernel<K, false>), dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_item, g->d_user, g->d_value, n, kb[0], s.pay64[0]);
+    hipLaunchKernelGGL((item_stage_kernel<K, false>), dim3(blocks_for(n)), dim3(256), 0, g->stream, rec.item, rec.user, rec.value, n, kb[0], s.pay64[0]);
   ICHK(g, hipGetLastError());
   g->bytes_moved += (12.0 + (user32 ? 8.0 : 0.0) + sizeof(K) + 8.0) * (double)n;
   int ra = 0;
@@ -336,11 +353,12 @@ static int stage_items(mals_ingest g, Scratch& s, FinishTmp& t, int64_t n, bool 
 //    composite key in two stable stages, with the item rank and the value riding along; 3. pair keys
 //    (user rank << 32 | item rank) and values in that order.  *r_out = the key buffer that holds the pair keys.
 template <typename K>
-static int stage_users(mals_ingest g, Scratch& s, FinishTmp& t, int64_t n, int ra, float* sorted_val, int* r_out, unsigned* n_u_all) {
+static int stage_users(mals_ingest g, Scratch& s, FinishTmp& t, const Records& rec, int ra, float* sorted_val, int* r_out, unsigned* n_u_all) {
+  const int64_t n = rec.n;
   constexpr bool USER32 = sizeof(K) == 4;
   K* const kb[2] = {reinterpret_cast<K*>(s.keys[0]), reinterpret_cast<K*>(s.keys[1])};
   // (reads pay64[ra][i] and writes pay64[0][i]: the same thread, the same index -- safe when ra == 0)
-  hipLaunchKernelGGL((user_stage_kernel<K, USER32>), dim3(blocks_for(n)), dim3(256), 0, g->stream, g->d_user, s.pay64[ra], t.ri, n, kb[0], s.pay64[0]);
+  hipLaunchKernelGGL((user_stage_kernel<K, USER32>), dim3(blocks_for(n)), dim3(256), 0, g->stream, rec.user, s.pay64[ra], t.ri, n, kb[0], s.pay64[0]);
   ICHK(g, hipGetLastError());
   g->bytes_moved += (8.0 + 4.0 + (USER32 ? 0.0 : 8.0) + sizeof(K) + 8.0) * (double)n;
   int rb = 0;
@@ -358,8 +376,81 @@ static int stage_users(mals_ingest g, Scratch& s, FinishTmp& t, int64_t n, int r
   return MALS_OK;
 }
 
+// the arena of one sort pipeline over n records (52 bytes per record + digit counts), carved into the views the stages use;
+// scan_extra: the longest scan the caller runs beside the pipeline's own
+static int setup_workspace(mals_ingest g, Scratch& s, FinishTmp& t, int64_t n, int64_t scan_extra) {
+  const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
+  const int64_t scan_len = std::max<int64_t>(std::max<int64_t>(n, 256 * n_blocks), scan_extra);
+  const int64_t tiles = (scan_len + SC_TILE - 1) / SC_TILE + 1;
+  const size_t k8 = sizeof(uint64_t) * (size_t)n, k4 = sizeof(unsigned) * (size_t)n;
+  const size_t want[mals_ingest_s::N_WS] = {k8, k8, k4, k4, k8, k8, k4, k4, k4, sizeof(unsigned) * (size_t)(256 * n_blocks),
+                                            sizeof(unsigned) * (size_t)tiles, sizeof(unsigned long long) * 8 * 256 + 256};
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int b = 0; b < mals_ingest_s::N_WS; ++b) {
+    if (want[b] > g->ws_bytes[b]) {
+      dfree(g->ws[b]);
+      g->ws_bytes[b] = 0;
+      ICHK(g, hipMalloc(&g->ws[b], want[b]));
+      g->ws_bytes[b] = want[b];
+    }
+  }
+  g->last_workspace_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  s.keys[0] = (uint64_t*)g->ws[0];
+  s.keys[1] = (uint64_t*)g->ws[1];
+  s.pay[0] = (unsigned*)g->ws[2];
+  s.pay[1] = (unsigned*)g->ws[3];
+  s.pay64[0] = (uint64_t*)g->ws[4];
+  s.pay64[1] = (uint64_t*)g->ws[5];
+  t.head = (unsigned*)g->ws[6];
+  t.scan = (unsigned*)g->ws[7];
+  t.ri = (unsigned*)g->ws[8];
+  s.counts = (unsigned*)g->ws[9];
+  s.tile_sums = (unsigned*)g->ws[10];
+  s.digit_tot = (unsigned long long*)g->ws[11];
+  s.total = (unsigned*)((char*)g->ws[11] + sizeof(unsigned long long) * 8 * 256);
+  // dead after the composite sort: the 64-bit payload buffers carry the replay outputs
+  t.keep = (unsigned*)s.pay64[0];
+  t.pair_val = (float*)((char*)s.pay64[0] + k4);
+  t.coo_row = (int32_t*)s.pay64[1];
+  t.present = g->want_known ? (unsigned*)((char*)s.pay64[1] + k4) : nullptr;  // coo_row needs 4 bytes per entry at most
+  return MALS_OK;
+}
+
+#include "ingest_big_host.h"
+
+// 8. tag id sets (IFR:159-165): sorted, unique; 9. userTagIDs as rows of R^T.  sort_cap: what the arena's sort buffers hold
+static int finish_tags(mals_ingest g, Scratch& s, FinishTmp& t, int64_t sort_cap) {
+  const int64_t n_items = g->n_items;
+  for (int which = 0; which < 2; ++which) {
+    const int64_t nt = (int64_t)g->n_tags_raw[which];
+    if (nt == 0) continue;  // nt <= n: every tag comes from a record
+    if (nt > sort_cap) return fail(g, MALS_INVALID_ARG, "ingest: more tag lines than a partition holds records");
+    hipLaunchKernelGGL(ids_to_keys_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, g->d_tags[which], nt, s.keys[0], s.pay[0]);
+    ICHK(g, hipGetLastError());
+    int rt = 0;
+    if (int rc = radix_sort<uint64_t, unsigned>(g, s, s.keys, s.pay, nt, &rt)) return rc;
+    hipLaunchKernelGGL(heads_kernel<uint64_t>, dim3(blocks_for(nt)), dim3(256), 0, g->stream, s.keys[rt], nt, t.head);
+    ICHK(g, hipGetLastError());
+    unsigned n_unique = 0;
+    if (int rc = scan_u32(g, s, t.head, t.scan, nt, &n_unique)) return rc;
+    ICHK(g, hipMalloc(&g->tag_ids[which], sizeof(int64_t) * (size_t)n_unique));
+    g->n_tag_ids[which] = n_unique;
+    hipLaunchKernelGGL(unique_ids_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, s.keys[rt], t.head, t.scan, nt, g->tag_ids[which]);
+    ICHK(g, hipGetLastError());
+  }
+  // 9. userTagIDs as rows of R^T: what top-N must never return (RecommendIterator.java:72)
+  if (g->n_tag_ids[1] > 0) {
+    ICHK(g, hipMalloc(&g->tag_item_idx, sizeof(int64_t) * (size_t)g->n_tag_ids[1]));
+    hipLaunchKernelGGL(index_of_ids_kernel, dim3(blocks_for(g->n_tag_ids[1])), dim3(256), 0, g->stream, g->tag_ids[1], g->n_tag_ids[1], g->ids[1],
+                       (int64_t)n_items, g->tag_item_idx);
+    ICHK(g, hipGetLastError());
+  }
+  return MALS_OK;
+}
+
 static int finish_impl(mals_ingest g, hipEvent_t e0) {
   const int64_t n = g->n;
+  g->last_partitions = g->last_item_ranges = 0;
   if (n == 0) {
     ICHK(g, hipEventRecord(e0, g->stream));
     if (int rc = alloc_results(g, 0, 0, 0)) return rc;
@@ -372,45 +463,13 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
     }
     return MALS_OK;
   }
+  // more records than one sort pipeline holds (or than the caller wants it to hold): user range by user range
+  if (n > MALS_INGEST_ONE_SHOT_MAX || (g->part_cap > 0 && n > g->part_cap))
+    return finish_big(g, e0, g->part_cap > 0 ? g->part_cap : MALS_INGEST_DEFAULT_PART);
   FinishTmp t;
   Scratch s;
   unsigned n_u_all = 0, n_i_all = 0, n_users = 0, n_items = 0, nnz = 0;
-  const int64_t n_blocks = (n + RS_BLOCK_TILE - 1) / RS_BLOCK_TILE;
-  const int64_t scan_len = std::max<int64_t>(n, 256 * n_blocks);
-  const int64_t tiles = (scan_len + SC_TILE - 1) / SC_TILE;
-  {  // workspace: 52 bytes per record + the digit counts
-    const size_t k8 = sizeof(uint64_t) * (size_t)n, k4 = sizeof(unsigned) * (size_t)n;
-    const size_t want[mals_ingest_s::N_WS] = {k8, k8, k4, k4, k8, k8, k4, k4, k4, sizeof(unsigned) * (size_t)(256 * n_blocks),
-                                              sizeof(unsigned) * (size_t)tiles, sizeof(unsigned long long) * 8 * 256 + 256};
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int b = 0; b < mals_ingest_s::N_WS; ++b) {
-      if (want[b] > g->ws_bytes[b]) {
-        dfree(g->ws[b]);
-        g->ws_bytes[b] = 0;
-        ICHK(g, hipMalloc(&g->ws[b], want[b]));
-        g->ws_bytes[b] = want[b];
-      }
-    }
-    g->last_workspace_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    s.keys[0] = (uint64_t*)g->ws[0];
-    s.keys[1] = (uint64_t*)g->ws[1];
-    s.pay[0] = (unsigned*)g->ws[2];
-    s.pay[1] = (unsigned*)g->ws[3];
-    s.pay64[0] = (uint64_t*)g->ws[4];
-    s.pay64[1] = (uint64_t*)g->ws[5];
-    t.head = (unsigned*)g->ws[6];
-    t.scan = (unsigned*)g->ws[7];
-    t.ri = (unsigned*)g->ws[8];
-    s.counts = (unsigned*)g->ws[9];
-    s.tile_sums = (unsigned*)g->ws[10];
-    s.digit_tot = (unsigned long long*)g->ws[11];
-    s.total = (unsigned*)((char*)g->ws[11] + sizeof(unsigned long long) * 8 * 256);
-    // dead after the composite sort: the 64-bit payload buffers carry the replay outputs
-    t.keep = (unsigned*)s.pay64[0];
-    t.pair_val = (float*)((char*)s.pay64[0] + k4);
-    t.coo_row = (int32_t*)s.pay64[1];
-    t.present = g->want_known ? (unsigned*)((char*)s.pay64[1] + k4) : nullptr;  // coo_row needs 4 bytes per entry at most
-  }
+  if (int rc = setup_workspace(g, s, t, n, 0)) return rc;
   ICHK(g, hipEventRecord(e0, g->stream));  // the pipeline proper starts here
   // 0. do the ids fit 32 bits?  Then the sorts run on 32-bit keys, and the user ids ride through the first sort so that
   //    nothing has to be gathered by record index
@@ -424,10 +483,11 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
   const bool user32 = high[0] == 0 && narrow, item32 = high[1] == 0 && narrow;
   g->bytes_moved += 16.0 * (double)n;
   int ra = 0;
-  if (int rc = item32 ? stage_items<uint32_t>(g, s, t, n, user32, &ra, &n_i_all) : stage_items<uint64_t>(g, s, t, n, user32, &ra, &n_i_all)) return rc;
+  const Records rec = {g->d_user, g->d_item, g->d_value, n};
+  if (int rc = item32 ? stage_items<uint32_t>(g, s, t, rec, user32, &ra, &n_i_all) : stage_items<uint64_t>(g, s, t, rec, user32, &ra, &n_i_all)) return rc;
   float* sorted_val = reinterpret_cast<float*>(s.pay[0]);
   int r = 0;
-  if (int rc = user32 ? stage_users<uint32_t>(g, s, t, n, ra, sorted_val, &r, &n_u_all) : stage_users<uint64_t>(g, s, t, n, ra, sorted_val, &r, &n_u_all))
+  if (int rc = user32 ? stage_users<uint32_t>(g, s, t, rec, ra, sorted_val, &r, &n_u_all) : stage_users<uint64_t>(g, s, t, rec, ra, sorted_val, &r, &n_u_all))
     return rc;
   // 4. replay every pair's records in order
   ICHK(g, hipMalloc(&t.alive_u, sizeof(unsigned) * (size_t)n_u_all));
@@ -491,23 +551,7 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
                      (int64_t)n_items, g->ptr[1]);
   ICHK(g, hipGetLastError());
   g->bytes_moved += 4.0 * (double)nnz + 8.0 * (double)n_items;
-  // 8. tag id sets (IFR:159-165): sorted, unique
-  for (int which = 0; which < 2; ++which) {
-    const int64_t nt = (int64_t)g->n_tags_raw[which];
-    if (nt == 0) continue;  // nt <= n: every tag comes from a record
-    hipLaunchKernelGGL(ids_to_keys_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, g->d_tags[which], nt, s.keys[0], s.pay[0]);
-    ICHK(g, hipGetLastError());
-    int rt = 0;
-    if (int rc = radix_sort<uint64_t, unsigned>(g, s, s.keys, s.pay, nt, &rt)) return rc;
-    hipLaunchKernelGGL(heads_kernel<uint64_t>, dim3(blocks_for(nt)), dim3(256), 0, g->stream, s.keys[rt], nt, t.head);
-    ICHK(g, hipGetLastError());
-    unsigned n_unique = 0;
-    if (int rc = scan_u32(g, s, t.head, t.scan, nt, &n_unique)) return rc;
-    ICHK(g, hipMalloc(&g->tag_ids[which], sizeof(int64_t) * (size_t)n_unique));
-    g->n_tag_ids[which] = n_unique;
-    hipLaunchKernelGGL(unique_ids_kernel, dim3(blocks_for(nt)), dim3(256), 0, g->stream, s.keys[rt], t.head, t.scan, nt, g->tag_ids[which]);
-    ICHK(g, hipGetLastError());
-  }
+  if (int rc = finish_tags(g, s, t, n)) return rc;
   ICHK(g, hipStreamSynchronize(g->stream));
   return MALS_OK;
 }
@@ -595,8 +639,46 @@ int mals_ingest_install(mals_ingest g, mals_handle h) {
     return fail(g, rc, mals_last_error(h));
   // knownItemIDs, if they were asked for: what mals_recommend skips (ServerRecommender.java:394-425), entries that
   // removeSmall pruned from R included
+  // (mals_set_matrix(side X) has dropped whatever known items an earlier install left on the handle)
   if (g->known_ptr)
     if (int rc = mals_set_known_items(h, g->n_users, g->known_ptr, g->known_idx, MALS_MEM_DEVICE)) return fail(g, rc, mals_last_error(h));
+  // userTagIDs: rows of Y top-N never returns (RecommendIterator.java:72).  Needs the item factor rows: declare them here if
+  // the caller has not (a caller-bound or larger replica is left alone).
+  void* fy = nullptr;
+  int64_t fy_rows = 0;
+  (void)mals_factor_device_ptr(h, MALS_SIDE_Y, &fy, &fy_rows);
+  if (g->n_tag_ids[1] > 0 && (!fy || fy_rows < g->n_items))
+    if (int rc = mals_set_factor_rows(h, MALS_SIDE_Y, g->n_items)) return fail(g, rc, mals_last_error(h));
+  if (int rc = mals_set_tag_items(h, g->n_tag_ids[1], g->tag_item_idx, MALS_MEM_DEVICE)) return fail(g, rc, mals_last_error(h));
+  return MALS_OK;
+}
+
+int mals_ingest_device(mals_ingest g, int32_t* device_out) {
+  if (!g || !device_out) return MALS_INVALID_ARG;
+  *device_out = g->device;
+  return MALS_OK;
+}
+
+int mals_ingest_get_tag_items(mals_ingest g, int64_t* host_idx_out) {
+  if (!g || !host_idx_out) return MALS_INVALID_ARG;
+  if (!g->finished) return fail(g, MALS_INVALID_ARG, "mals_ingest_finish has not run");
+  ICHK(g, hipSetDevice(g->device));
+  if (g->n_tag_ids[1]) ICHK(g, hipMemcpy(host_idx_out, g->tag_item_idx, sizeof(int64_t) * (size_t)g->n_tag_ids[1], hipMemcpyDeviceToHost));
+  return MALS_OK;
+}
+
+int mals_ingest_device_tag_items(mals_ingest g, const int64_t** device_idx_out, int64_t* n_out) {
+  if (!g) return MALS_INVALID_ARG;
+  if (!g->finished) return fail(g, MALS_INVALID_ARG, "mals_ingest_finish has not run");
+  if (device_idx_out) *device_idx_out = g->tag_item_idx;
+  if (n_out) *n_out = g->n_tag_ids[1];
+  return MALS_OK;
+}
+
+int mals_ingest_partitions(mals_ingest g, int32_t* user_ranges, int32_t* item_ranges) {
+  if (!g) return MALS_INVALID_ARG;
+  if (user_ranges) *user_ranges = g->last_partitions;
+  if (item_ranges) *item_ranges = g->last_item_ranges;
   return MALS_OK;
 }
 

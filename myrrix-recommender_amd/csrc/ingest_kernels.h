@@ -387,6 +387,19 @@ __global__ void compact_ids_kernel(const int64_t* __restrict__ id_table, const u
   MALS_GRID_STRIDE(i, n_ids)
     if (alive[i]) ids_out[alive_scan[i]] = id_table[i];
 }
+// out[i] = the position of ids[i] in the ascending table, -1 if it is not there
+__global__ void index_of_ids_kernel(const int64_t* __restrict__ ids, int64_t n, const int64_t* __restrict__ table, int64_t n_table,
+                                    int64_t* __restrict__ out) {
+  MALS_GRID_STRIDE(i, n) {
+    const int64_t want = ids[i];
+    int64_t lo = 0, hi = n_table;
+    while (lo < hi) {
+      const int64_t mid = lo + (hi - lo) / 2;
+      if (table[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    out[i] = (lo < n_table && table[lo] == want) ? lo : -1;
+  }
+}
 // compact the kept pairs into COO sorted by (row, col); count entries per row
 __global__ void compact_pairs_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ keep,
                                      const unsigned* __restrict__ keep_scan, const float* __restrict__ pair_val, int64_t n,

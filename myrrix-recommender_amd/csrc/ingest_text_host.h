@@ -169,6 +169,7 @@ int process_text_region(mals_ingest g, size_t region) {
       if (k == text::ST_BAD) ++bad;
     }
   }
+  if (g->finished) free_results(g);   // any accepted text (also lines that yield no record) makes the last finish stale
   g->bad_lines += c.bad;
   g->abort_armed = g->bad_lines > 100;
   g->lines += (int64_t)L;
@@ -177,8 +178,7 @@ int process_text_region(mals_ingest g, size_t region) {
   g->slow_lines += c.deferred;
   // 5. records, in file order
   if (c.records) {
-    if (g->n + (int64_t)c.records >= (int64_t)0x7fffff00) return text_fail(g, MALS_INVALID_ARG, "at most 2^31 records per ingest");
-    if (g->finished) free_results(g);
+    if (g->n + (int64_t)c.records >= MALS_INGEST_MAX_RECORDS) return text_fail(g, MALS_INVALID_ARG, "at most 2^36 records per ingest");
     if (int rc = ensure_record_capacity(g, c.records)) return rc;
     ICHK(g, hipEventRecord(e0, g->stream));
     hipLaunchKernelGGL(compact_records_kernel, dim3((unsigned)ct), dim3(256), 0, g->stream, g->t_status, g->t_flag, (int64_t)L, g->t_user,
@@ -322,10 +322,14 @@ int mals_ingest_set_option(mals_ingest g, int32_t option, int64_t value) {
       g->want_known = value != 0;
       return MALS_OK;
     case MALS_INGEST_OPT_RESERVE_RECORDS: {
-      if (value < 0 || value >= (int64_t)0x7fffff00) return fail(g, MALS_INVALID_ARG, "at most 2^31 records per ingest");
+      if (value < 0 || value >= MALS_INGEST_MAX_RECORDS) return fail(g, MALS_INVALID_ARG, "at most 2^36 records per ingest");
       ICHK(g, hipSetDevice(g->device));
       return ensure_record_capacity(g, std::max<int64_t>(0, value - g->n));
     }
+    case MALS_INGEST_OPT_PARTITION_RECORDS:
+      if (value != 0 && (value < 64 || value > MALS_INGEST_ONE_SHOT_MAX)) return fail(g, MALS_INVALID_ARG, "partition records: 0 (default) or 64 .. 2^31 - 256");
+      g->part_cap = value;
+      return MALS_OK;
     case MALS_INGEST_OPT_TEXT_BLOCK_BYTES:
       if (value < 1 || value > (int64_t)1 << 31) return fail(g, MALS_INVALID_ARG, "text block: 1 byte .. 2 GiB");
       g->text_block_bytes = (size_t)value;

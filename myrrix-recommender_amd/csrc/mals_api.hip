@@ -20,8 +20,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -198,6 +201,10 @@ struct mals_handle_s {
   std::vector<PendingEvent> pending;
   unsigned long long* d_trace = nullptr;  // MALS_DEBUG_TRACE
   void* tn_ws = nullptr;  // top-N workspace (topn_host.h), grow-only
+  void* tn_front = nullptr;  // the serving front of mals_recommend*: queue, leader, passes in flight (topn_host.h)
+  // userTagIDs as one bit per item (mals_set_tag_items): never recommended (RecommendIterator.java:72)
+  uint32_t* tag_bits = nullptr;
+  int64_t tag_bits_items = 0, n_tag_items = 0;
   // knownItemIDs (mals_set_known_items): what mals_recommend skips instead of the rows of R when present
   const int64_t* known_ptr = nullptr;
   const int32_t* known_idx = nullptr;
@@ -244,6 +251,14 @@ template <typename P>
 void free_dev(P*& p) {
   if (p) (void)hipFree(p);
   p = nullptr;
+}
+
+void clear_known_items(mals_handle h) {
+  free_dev(h->known_ptr_own);
+  free_dev(h->known_idx_own);
+  h->known_ptr = nullptr;
+  h->known_idx = nullptr;
+  h->known_rows = 0;
 }
 
 void free_matrix(SideState& s) {
@@ -1379,6 +1394,8 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   }
 #endif
   t_create_error.clear();
+  h->tn_front = new TopnFront();
+  if (const char* e = std::getenv("MALS_TOPN_FRONT_DEPTH")) topn_front(h)->depth = std::max(1, std::min(TOPN_SLOTS, std::atoi(e)));
   *out = h;
   return MALS_OK;
 }
@@ -1386,6 +1403,9 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
 int mals_destroy(mals_handle h) {
   if (!h) return MALS_INVALID_ARG;
   (void)hipSetDevice(h->cfg.device);
+  delete topn_front(h);
+  h->tn_front = nullptr;
+  free_dev(h->tag_bits);
   (void)hipStreamSynchronize(h->stream);
   if (h->d_trace) {  // dump the last launch's per-phase cycle stamps (profiling aid)
     std::vector<unsigned long long> t(64 * 64 * 6);
@@ -1452,6 +1472,8 @@ int mals_destroy(mals_handle h) {
   return MALS_OK;
 }
 
+int mals_features(mals_handle h) { return h ? h->cfg.features : 0; }
+
 const char* mals_last_error(mals_handle h) { return h ? h->err.c_str() : "null handle"; }
 
 int mals_set_stream(mals_handle h, void* hip_stream) {
@@ -1509,6 +1531,7 @@ int mals_set_matrix(mals_handle h, int side, int64_t row_offset, int64_t n_rows_
   SideState& s = h->side[side];
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_matrix(s);
+  if (side == MALS_SIDE_X) clear_known_items(h);  // they were a CSR over the OLD local rows (and maybe borrowed arrays)
   s.row_offset = row_offset;
   s.n_local = n_rows_local;
   s.nnz = nnz;
@@ -1558,6 +1581,7 @@ int mals_begin_matrix(mals_handle h, int side, int64_t row_offset, int64_t n_row
   SideState& s = h->side[side];
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_matrix(s);
+  if (side == MALS_SIDE_X) clear_known_items(h);
   s.row_offset = row_offset;
   s.n_local = n_rows_local;
   s.nnz = nnz;
@@ -2429,31 +2453,57 @@ int mals_reconstruction_error(mals_handle h, double* sum_out, int64_t* count_out
   return MALS_OK;
 }
 
+// (a failed argument check of a recommend call: the message under the front's mutex -- other request threads may be
+// inside the same handle)
+static int topn_fail(mals_handle h, int code, const char* msg) {
+  std::lock_guard<std::mutex> lk(topn_front(h)->mu);
+  h->err = msg;
+  return code;
+}
+
 int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, int32_t how_many, int32_t consider_known_items,
                    int64_t* item_idx_out, float* score_out, int32_t* n_out) {
   if (!h) return MALS_INVALID_ARG;
   SideState& x = h->side[MALS_SIDE_X];
   SideState& y = h->side[MALS_SIDE_Y];
-  if (!x.F || !y.F || y.n_total == 0) return fail(h, MALS_INVALID_ARG, "factor replicas not available");
+  if (!x.F || !y.F || y.n_total == 0) return topn_fail(h, MALS_INVALID_ARG, "factor replicas not available");
   if (n_queries < 0 || how_many <= 0 || how_many > 4096 || (n_queries > 0 && (!user_idx || !item_idx_out || !score_out)))
-    return fail(h, MALS_INVALID_ARG, "bad recommend arguments (how_many in 1..4096)");
+    return topn_fail(h, MALS_INVALID_ARG, "bad recommend arguments (how_many in 1..4096)");
   if (!consider_known_items && !x.has_matrix && !h->known_ptr)
-    return fail(h, MALS_INVALID_ARG, "the user-side matrix (or mals_set_known_items) is needed to skip known items");
+    return topn_fail(h, MALS_INVALID_ARG, "the user-side matrix (or mals_set_known_items) is needed to skip known items");
+  if (!consider_known_items && h->known_ptr && h->known_rows != x.n_local)
+    return topn_fail(h, MALS_INVALID_ARG, "the installed known items do not match the local user rows");
   for (int q = 0; q < n_queries; ++q) {
-    if (user_idx[q] < 0 || user_idx[q] >= x.n_total) return fail(h, MALS_INVALID_ARG, "user index outside the factor replica");
+    if (user_idx[q] < 0 || user_idx[q] >= x.n_total) return topn_fail(h, MALS_INVALID_ARG, "user index outside the factor replica");
     if (!consider_known_items && (user_idx[q] < x.row_offset || user_idx[q] >= x.row_offset + x.n_local))
-      return fail(h, MALS_INVALID_ARG, "known items of this user are not on this handle (row outside the local shard)");
+      return topn_fail(h, MALS_INVALID_ARG, "known items of this user are not on this handle (row outside the local shard)");
   }
-  if (int rc = use_device(h)) return rc;
+  if (n_queries == 0) return MALS_OK;
+  if (h->tag_bits && h->tag_bits_items != y.n_total)
+    return topn_fail(h, MALS_INVALID_ARG, "the tag items were set for another item count: call mals_set_tag_items again");
+  if (hipSetDevice(h->cfg.device) != hipSuccess) return topn_fail(h, MALS_HIP_ERROR, "hipSetDevice failed");
+  TopnTicket t;
   TopnRequest rq;
-  rq.n_queries = n_queries;
-  rq.how_many = how_many;
-  rq.user_idx = user_idx;
-  rq.skip_known = !consider_known_items;
-  rq.item_idx_out = item_idx_out;
-  rq.score_out = score_out;
-  rq.n_out = n_out;
-  return topn_run(h, rq);
+  if (n_queries < TOPN_FRONT_BULK && how_many <= TOPN_FILTER_MAX_N) {
+    t.user_idx = user_idx;
+    t.n = n_queries;
+    t.how_many = how_many;
+    t.skip_known = !consider_known_items;
+    t.item_out = item_idx_out;
+    t.score_out = score_out;
+    t.n_out = n_out;
+  } else {
+    rq.n_queries = n_queries;
+    rq.how_many = how_many;
+    rq.user_idx = user_idx;
+    rq.skip_known = !consider_known_items;
+    rq.item_idx_out = item_idx_out;
+    rq.score_out = score_out;
+    rq.n_out = n_out;
+    t.bulk = &rq;
+    t.how_many = how_many;
+  }
+  return topn_front_submit(h, t);
 }
 
 int mals_set_known_items(mals_handle h, int64_t n_rows, const int64_t* row_ptr, const int32_t* item_idx, int mem_kind) {
@@ -2461,11 +2511,7 @@ int mals_set_known_items(mals_handle h, int64_t n_rows, const int64_t* row_ptr, 
   if (mem_kind != MALS_MEM_HOST && mem_kind != MALS_MEM_DEVICE) return fail(h, MALS_INVALID_ARG, "mem_kind must be MALS_MEM_HOST or MALS_MEM_DEVICE");
   if (int rc = use_device(h)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  free_dev(h->known_ptr_own);
-  free_dev(h->known_idx_own);
-  h->known_ptr = nullptr;
-  h->known_idx = nullptr;
-  h->known_rows = 0;
+  clear_known_items(h);
   if (!row_ptr) return MALS_OK;  // back to the rows of R
   SideState& x = h->side[MALS_SIDE_X];
   if (n_rows != x.n_local) return fail(h, MALS_INVALID_ARG, "known items: one row per local user row of side X");
@@ -2486,25 +2532,77 @@ int mals_set_known_items(mals_handle h, int64_t n_rows, const int64_t* row_ptr, 
   return MALS_OK;
 }
 
+int mals_set_tag_items(mals_handle h, int64_t n, const int64_t* item_idx, int mem_kind) {
+  if (!h) return MALS_INVALID_ARG;
+  if (mem_kind != MALS_MEM_HOST && mem_kind != MALS_MEM_DEVICE) return fail(h, MALS_INVALID_ARG, "mem_kind must be MALS_MEM_HOST or MALS_MEM_DEVICE");
+  if (n < 0 || (n > 0 && !item_idx)) return fail(h, MALS_INVALID_ARG, "bad tag item list");
+  if (int rc = use_device(h)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_dev(h->tag_bits);
+  h->tag_bits_items = h->n_tag_items = 0;
+  if (n == 0) return MALS_OK;
+  const int64_t n_items = h->side[MALS_SIDE_Y].n_total;
+  if (n_items <= 0) return fail(h, MALS_INVALID_ARG, "tag items: the item factor replica comes first (mals_set_factor_rows)");
+  const size_t words = ((size_t)((n_items + 31) / 32) + 1) & ~(size_t)1;   // even: the counter behind them is 8-byte aligned
+  uint32_t* bits = nullptr;
+  HIPCHK(h, hipMalloc(&bits, sizeof(uint32_t) * words + sizeof(unsigned long long)));
+  unsigned long long* d_n = reinterpret_cast<unsigned long long*>(bits + words);
+  HIPCHK(h, hipMemsetAsync(bits, 0, sizeof(uint32_t) * words + sizeof(unsigned long long), h->stream));
+  int64_t* d_idx = nullptr;
+  const int64_t* src = item_idx;
+  if (mem_kind == MALS_MEM_HOST) {
+    HIPCHK(h, hipMalloc(&d_idx, sizeof(int64_t) * (size_t)n));
+    HIPCHK(h, hipMemcpyAsync(d_idx, item_idx, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    src = d_idx;
+  }
+  hipLaunchKernelGGL(topn_tag_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, n, n_items, bits, d_n);
+  unsigned long long n_set = 0;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&n_set, d_n, sizeof(n_set), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  free_dev(d_idx);
+  if (e != hipSuccess) {
+    free_dev(bits);
+    return fail(h, MALS_HIP_ERROR, std::string("mals_set_tag_items: ") + hipGetErrorString(e));
+  }
+  if (n_set == 0) {  // none of them owns a row of Y: nothing to strike
+    free_dev(bits);
+    return MALS_OK;
+  }
+  h->tag_bits = bits;
+  h->tag_bits_items = n_items;
+  h->n_tag_items = (int64_t)n_set;
+  return MALS_OK;
+}
+
+int mals_get_tag_item_count(mals_handle h, int64_t* n_out) {
+  if (!h || !n_out) return MALS_INVALID_ARG;
+  *n_out = h->n_tag_items;
+  return MALS_OK;
+}
+
 int mals_recommend_to_many(mals_handle h, const float* vectors, const int64_t* vector_ptr, int32_t n_queries, int32_t how_many,
                            const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
                            int32_t* n_out) {
   if (!h) return MALS_INVALID_ARG;
   SideState& y = h->side[MALS_SIDE_Y];
-  if (!y.F || y.n_total == 0) return fail(h, MALS_INVALID_ARG, "item factor replica not available");
+  if (!y.F || y.n_total == 0) return topn_fail(h, MALS_INVALID_ARG, "item factor replica not available");
   if (n_queries < 0 || how_many <= 0 || how_many > 4096 || (n_queries > 0 && (!vectors || !item_idx_out || !score_out)))
-    return fail(h, MALS_INVALID_ARG, "bad recommend arguments (how_many in 1..4096)");
+    return topn_fail(h, MALS_INVALID_ARG, "bad recommend arguments (how_many in 1..4096)");
   if ((exclude_ptr == nullptr) != (exclude_idx == nullptr) && exclude_ptr && exclude_ptr[n_queries] > 0)
-    return fail(h, MALS_INVALID_ARG, "exclude_ptr and exclude_idx go together");
+    return topn_fail(h, MALS_INVALID_ARG, "exclude_ptr and exclude_idx go together");
   if (vector_ptr) {
-    if (vector_ptr[0] != 0) return fail(h, MALS_INVALID_ARG, "vector_ptr[0] must be 0");
+    if (vector_ptr[0] != 0) return topn_fail(h, MALS_INVALID_ARG, "vector_ptr[0] must be 0");
     for (int q = 0; q < n_queries; ++q) {
       const int64_t n = vector_ptr[q + 1] - vector_ptr[q];
-      if (n < 1) return fail(h, MALS_INVALID_ARG, "features must not be empty");  // RecommendIterator.java:52
-      if (n > (1 << 20)) return fail(h, MALS_INVALID_ARG, "too many vectors in one query");
+      if (n < 1) return topn_fail(h, MALS_INVALID_ARG, "features must not be empty");  // RecommendIterator.java:52
+      if (n > (1 << 20)) return topn_fail(h, MALS_INVALID_ARG, "too many vectors in one query");
     }
   }
-  if (int rc = use_device(h)) return rc;
+  if (n_queries == 0) return MALS_OK;
+  if (h->tag_bits && h->tag_bits_items != y.n_total)
+    return topn_fail(h, MALS_INVALID_ARG, "the tag items were set for another item count: call mals_set_tag_items again");
+  if (hipSetDevice(h->cfg.device) != hipSuccess) return topn_fail(h, MALS_HIP_ERROR, "hipSetDevice failed");
   TopnRequest rq;
   rq.n_queries = n_queries;
   rq.how_many = how_many;
@@ -2515,13 +2613,37 @@ int mals_recommend_to_many(mals_handle h, const float* vectors, const int64_t* v
   rq.item_idx_out = item_idx_out;
   rq.score_out = score_out;
   rq.n_out = n_out;
-  return topn_run(h, rq);
+  TopnTicket t;
+  t.bulk = &rq;
+  t.how_many = how_many;
+  return topn_front_submit(h, t);
 }
 
 int mals_recommend_vectors(mals_handle h, const float* query_vectors, int32_t n_queries, int32_t how_many,
                            const int64_t* exclude_ptr, const int64_t* exclude_idx, int64_t* item_idx_out, float* score_out,
                            int32_t* n_out) {
   return mals_recommend_to_many(h, query_vectors, nullptr, n_queries, how_many, exclude_ptr, exclude_idx, item_idx_out, score_out, n_out);
+}
+
+int mals_recommend_front_stats(mals_handle h, int64_t* out4) {
+  if (!h || !out4) return MALS_INVALID_ARG;
+  TopnFront* f = topn_front(h);
+  std::lock_guard<std::mutex> lk(f->mu);
+  out4[0] = (int64_t)f->calls;
+  out4[1] = (int64_t)f->queries;
+  out4[2] = (int64_t)f->passes;
+  out4[3] = (int64_t)f->bulk_calls;
+  return MALS_OK;
+}
+
+int mals_recommend_set_depth(mals_handle h, int32_t passes_in_flight) {
+  if (!h || passes_in_flight < 1 || passes_in_flight > TOPN_SLOTS) return MALS_INVALID_ARG;
+  TopnFront* f = topn_front(h);
+  std::lock_guard<std::mutex> lk(f->mu);
+  if (f->n_busy > 0 || f->leader) { h->err = "mals_recommend_set_depth: calls are in flight"; return MALS_INVALID_ARG; }
+  f->depth = passes_in_flight;
+  f->next_slot = f->oldest = 0;
+  return MALS_OK;
 }
 
 int mals_symmetric_eigen(const double* A, int32_t n, double* evals_out, double* V_out) {

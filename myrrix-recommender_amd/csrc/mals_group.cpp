@@ -121,6 +121,13 @@ struct Member {
   float* d_ymax = nullptr;   // max |element| of the rows of this member's partial Gramian (bit pattern = non-negative float)
   float* F[2] = {nullptr, nullptr};
   int64_t* d_row_ptr[2] = {nullptr, nullptr};  // rebased row pointers of borrowed device matrices
+  // mals_ingest_install_group: the member's slices when the ingest lives on ANOTHER device (peer copies), and its slice of
+  // knownItemIDs (rebased offsets always; the indices only when copied)
+  int32_t* own_col[2] = {nullptr, nullptr};
+  float* own_val[2] = {nullptr, nullptr};
+  int64_t* own_known_ptr = nullptr;
+  int32_t* own_known_idx = nullptr;
+  int64_t* own_tag_idx = nullptr;
   // chunked upload
   int64_t up_rows = 0;
 };
@@ -230,8 +237,14 @@ void destroy_member(Member& mb) {
   if (mb.comm) (void)hipStreamSynchronize(mb.comm);
   if (mb.nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(mb.nccl);
   if (mb.h) (void)mals_destroy(mb.h);
-  for (int sd = 0; sd < 2; ++sd)
+  for (int sd = 0; sd < 2; ++sd) {
     if (mb.d_row_ptr[sd]) (void)hipFree(mb.d_row_ptr[sd]);
+    if (mb.own_col[sd]) (void)hipFree(mb.own_col[sd]);
+    if (mb.own_val[sd]) (void)hipFree(mb.own_val[sd]);
+  }
+  if (mb.own_known_ptr) (void)hipFree(mb.own_known_ptr);
+  if (mb.own_known_idx) (void)hipFree(mb.own_known_idx);
+  if (mb.own_tag_idx) (void)hipFree(mb.own_tag_idx);
   if (mb.d_gp) (void)hipFree(mb.d_gp);
   if (mb.d_stat) (void)hipFree(mb.d_stat);
   if (mb.d_ymax) (void)hipFree(mb.d_ymax);
@@ -783,6 +796,107 @@ int mals_group_set_matrix(mals_group g, int side, int64_t n_rows, int64_t nnz, c
     if (rc) return mfail(g, mb, rc);
   }
   return finish_matrix(g, side);
+}
+
+// InputFilesReader.readInputFiles -> DelegateGenerationManager.java:406-410, for a group: see include/myrrix_als.h
+int mals_ingest_install_group(mals_ingest in, mals_group g, int32_t flags) {
+  if (!g) return MALS_INVALID_ARG;
+  if (!in) return gfail(g, MALS_INVALID_ARG, "null ingest handle");
+  int64_t n_rows[2] = {0, 0}, nnz = 0;
+  if (int rc = mals_ingest_counts(in, nullptr, &n_rows[0], &n_rows[1], &nnz)) return gfail(g, rc, mals_ingest_last_error(in));
+  int32_t in_dev = 0;
+  if (int rc = mals_ingest_device(in, &in_dev)) return gfail(g, rc, "mals_ingest_device failed");
+  if (flags & ~MALS_INSTALL_COPY) return gfail(g, MALS_INVALID_ARG, "unknown install flag");
+  const bool force_copy = (flags & MALS_INSTALL_COPY) != 0;   // members on the ingest's own device copy too: the ingest may go
+  auto free_p = [](auto*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  };
+  // replicas first: validate_columns of the matrix upload checks the column indices against the opposite replica
+  for (int sd = 0; sd < 2; ++sd)
+    if (g->n_total[sd] < n_rows[sd])
+      if (int rc = mals_group_set_factor_rows(g, sd, n_rows[sd])) return rc;
+  for (int sd = 0; sd < 2; ++sd) {
+    const int64_t* d_ptr = nullptr;
+    const int32_t* d_col = nullptr;
+    const float* d_val = nullptr;
+    if (int rc = mals_ingest_device_csr(in, sd, &d_ptr, &d_col, &d_val)) return gfail(g, rc, mals_ingest_last_error(in));
+    // the row pointers cross to the host once (8 bytes per row): the plan is made there, like for every other upload
+    std::vector<int64_t> rp((size_t)n_rows[sd] + 1);
+    GHIP(g, hipSetDevice(in_dev));
+    GHIP(g, hipMemcpy(rp.data(), d_ptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost));
+    if (rp[0] != 0 || rp[(size_t)n_rows[sd]] != nnz) return gfail(g, MALS_INVALID_ARG, "the ingest's row pointers do not match its entry count");
+    if (int rc = plan_side(g, sd, rp.data(), n_rows[sd])) return rc;
+    for (Member& mb : g->m) {
+      const int64_t r0 = g->bounds[sd][(size_t)mb.rank], r1 = g->bounds[sd][(size_t)mb.rank + 1];
+      const int64_t e0 = rp[(size_t)r0], e1 = rp[(size_t)r1];
+      std::vector<int64_t> local((size_t)(r1 - r0) + 1);
+      for (int64_t r = r0; r <= r1; ++r) local[(size_t)(r - r0)] = rp[(size_t)r] - e0;
+      GHIP(g, hipSetDevice(mb.device));
+      free_p(mb.d_row_ptr[sd]);
+      free_p(mb.own_col[sd]);
+      free_p(mb.own_val[sd]);
+      GHIP(g, hipMalloc(&mb.d_row_ptr[sd], sizeof(int64_t) * local.size()));
+      GHIP(g, hipMemcpy(mb.d_row_ptr[sd], local.data(), sizeof(int64_t) * local.size(), hipMemcpyHostToDevice));
+      const int32_t* col = d_col + e0;
+      const float* val = d_val + e0;
+      if ((mb.device != in_dev || force_copy) && e1 > e0) {
+        GHIP(g, hipMalloc(&mb.own_col[sd], sizeof(int32_t) * (size_t)(e1 - e0)));
+        GHIP(g, hipMalloc(&mb.own_val[sd], sizeof(float) * (size_t)(e1 - e0)));
+        GHIP(g, hipMemcpyPeerAsync(mb.own_col[sd], mb.device, col, in_dev, sizeof(int32_t) * (size_t)(e1 - e0), mb.compute));
+        GHIP(g, hipMemcpyPeerAsync(mb.own_val[sd], mb.device, val, in_dev, sizeof(float) * (size_t)(e1 - e0), mb.compute));
+        GHIP(g, hipStreamSynchronize(mb.compute));
+        col = mb.own_col[sd];
+        val = mb.own_val[sd];
+      }
+      if (int rc = mals_set_matrix(mb.h, sd, r0, r1 - r0, e1 - e0, mb.d_row_ptr[sd], col, val, MALS_MEM_DEVICE)) return mfail(g, mb, rc);
+    }
+    if (int rc = finish_matrix(g, sd)) return rc;
+  }
+  // knownItemIDs: every member the rows of its own users (mals_recommend by user index is answered by the member that
+  // holds the user's row); userTagIDs: every member the whole mask
+  const int64_t *k_ptr = nullptr, *t_idx = nullptr;
+  const int32_t* k_idx = nullptr;
+  int64_t n_known = 0, n_tags = 0;
+  (void)mals_ingest_device_known_items(in, &k_ptr, &k_idx, &n_known);   // fails when the ingest did not build them: k_ptr stays null
+  if (int rc = mals_ingest_device_tag_items(in, &t_idx, &n_tags)) return gfail(g, rc, mals_ingest_last_error(in));
+  std::vector<int64_t> kp;
+  if (k_ptr) {
+    kp.resize((size_t)n_rows[0] + 1);
+    GHIP(g, hipSetDevice(in_dev));
+    GHIP(g, hipMemcpy(kp.data(), k_ptr, sizeof(int64_t) * kp.size(), hipMemcpyDeviceToHost));
+  }
+  for (Member& mb : g->m) {
+    GHIP(g, hipSetDevice(mb.device));
+    free_p(mb.own_known_ptr);
+    free_p(mb.own_known_idx);
+    free_p(mb.own_tag_idx);
+    if (k_ptr) {
+      const int64_t r0 = g->bounds[0][(size_t)mb.rank], r1 = g->bounds[0][(size_t)mb.rank + 1];
+      const int64_t e0 = kp[(size_t)r0], e1 = kp[(size_t)r1];
+      std::vector<int64_t> local((size_t)(r1 - r0) + 1);
+      for (int64_t r = r0; r <= r1; ++r) local[(size_t)(r - r0)] = kp[(size_t)r] - e0;
+      GHIP(g, hipMalloc(&mb.own_known_ptr, sizeof(int64_t) * local.size()));
+      GHIP(g, hipMemcpy(mb.own_known_ptr, local.data(), sizeof(int64_t) * local.size(), hipMemcpyHostToDevice));
+      const int32_t* idx = k_idx + e0;
+      if ((mb.device != in_dev || force_copy) && e1 > e0) {
+        GHIP(g, hipMalloc(&mb.own_known_idx, sizeof(int32_t) * (size_t)(e1 - e0)));
+        GHIP(g, hipMemcpyPeerAsync(mb.own_known_idx, mb.device, idx, in_dev, sizeof(int32_t) * (size_t)(e1 - e0), mb.compute));
+        GHIP(g, hipStreamSynchronize(mb.compute));
+        idx = mb.own_known_idx;
+      }
+      if (int rc = mals_set_known_items(mb.h, r1 - r0, mb.own_known_ptr, idx, MALS_MEM_DEVICE)) return mfail(g, mb, rc);
+    }
+    const int64_t* tags = t_idx;
+    if (n_tags > 0 && (mb.device != in_dev || force_copy)) {
+      GHIP(g, hipMalloc(&mb.own_tag_idx, sizeof(int64_t) * (size_t)n_tags));
+      GHIP(g, hipMemcpyPeerAsync(mb.own_tag_idx, mb.device, t_idx, in_dev, sizeof(int64_t) * (size_t)n_tags, mb.compute));
+      GHIP(g, hipStreamSynchronize(mb.compute));
+      tags = mb.own_tag_idx;
+    }
+    if (int rc = mals_set_tag_items(mb.h, n_tags, tags, MALS_MEM_DEVICE)) return mfail(g, mb, rc);
+  }
+  return MALS_OK;
 }
 
 int mals_group_begin_matrix(mals_group g, int side, int64_t n_rows, const int64_t* row_ptr) {

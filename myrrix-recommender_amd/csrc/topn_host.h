@@ -81,6 +81,11 @@ int topn_grow(mals_handle h, hipStream_t stream, P*& p, size_t& cap, size_t want
   return MALS_OK;
 }
 
+struct TopnOut {
+  int64_t* items;
+  float* scores;
+  int32_t* n;
+};
 // what one call asks for (host pointers)
 struct TopnRequest {
   int n_queries = 0, how_many = 0;
@@ -93,7 +98,16 @@ struct TopnRequest {
   int64_t* item_idx_out = nullptr;
   float* score_out = nullptr;
   int32_t* n_out = nullptr;
+  // a coalesced pass of the serving front (below): queries of several callers -- every query has its own output block and
+  // its own "skip the known items" flag
+  const TopnOut* out_q = nullptr;
+  const uint8_t* skip_known_q = nullptr;
 };
+
+inline TopnOut topn_out(const TopnRequest& rq, size_t qq) {
+  if (rq.out_q) return rq.out_q[qq];
+  return {rq.item_idx_out + qq * (size_t)rq.how_many, rq.score_out + qq * (size_t)rq.how_many, rq.n_out ? rq.n_out + qq : nullptr};
+}
 
 struct TopnPass {
   int q0 = 0, nq = 0;
@@ -162,9 +176,10 @@ int topn_upload_pass(mals_handle h, TopnSlot& sl, hipStream_t stream, const Topn
     std::memcpy(in + o_uidx, rq.user_idx + ps.q0, sizeof(int64_t) * (size_t)ps.nq);
     sl.d_vecs = x.F;
     sl.d_vrow = reinterpret_cast<const int64_t*>(sl.d_in + o_uidx);
-    if (rq.skip_known) {
+    if (rq.skip_known || rq.skip_known_q) {
       int64_t* rows = reinterpret_cast<int64_t*>(in + o_rows);
-      for (int q = 0; q < ps.nq; ++q) rows[q] = rq.user_idx[ps.q0 + q] - x.row_offset;
+      for (int q = 0; q < ps.nq; ++q)
+        rows[q] = (!rq.skip_known_q || rq.skip_known_q[ps.q0 + q]) ? rq.user_idx[ps.q0 + q] - x.row_offset : -1;
       ps.have_rows = true;
     }
   } else {
@@ -217,6 +232,9 @@ int topn_pass_dense(mals_handle h, TopnWorkspace* w, TopnSlot& sl, const TopnReq
   if (ps.have_excl)
     hipLaunchKernelGGL(topn_exclude_kernel, dim3(64, (unsigned)nq), dim3(256), 0, h->stream, sl.d_excl_ptr, sl.d_excl_idx, nq, n_items, 1, n_items,
                        w->d_scores);
+  if (h->tag_bits)
+    hipLaunchKernelGGL(topn_mask_tags_kernel, dim3((unsigned)(((n_items + 31) / 32 + 255) / 256)), dim3(256), 0, h->stream, h->tag_bits, nq, n_items,
+                       w->d_scores);
   unsigned slabs = 1;
   if (int rc = topn_select_threshold(h, w->d_scores, n_items, nq, how_many, w->d_state, w->d_hist, &slabs)) return rc;
   hipLaunchKernelGGL(topn_collect_kernel, dim3(slabs, (unsigned)nq), dim3(256), 0, h->stream, w->d_scores, n_items, w->d_state, how_many, cap_ties,
@@ -249,8 +267,8 @@ int topn_pass_dense(mals_handle h, TopnWorkspace* w, TopnSlot& sl, const TopnReq
       for (uint32_t p = 0; p < above; ++p) cand.push_back({o[2 * p + 1], (int64_t)o[2 * p]});
       for (uint32_t p = 0; p < ties_stored; ++p) cand.push_back({o[2 * (how_many + p) + 1], (int64_t)o[2 * (how_many + p)]});
     }
-    const size_t qq = (size_t)(ps.q0 + q);
-    topn_emit(cand, how_many, rq.item_idx_out + qq * how_many, rq.score_out + qq * how_many, rq.n_out ? rq.n_out + qq : nullptr);
+    const TopnOut o_q = topn_out(rq, (size_t)(ps.q0 + q));
+    topn_emit(cand, how_many, o_q.items, o_q.scores, o_q.n);
   }
   return MALS_OK;
 }
@@ -380,14 +398,14 @@ int topn_pass_filter_launch(mals_handle h, TopnSlot& sl, const TopnRequest& rq, 
   int n_groups = 0, n_fw = 0;
   if (int rc = topn_launch_stream<0>(h, sl, p.S, nt, y.F, n_items, k, nq, p.tile_stride, &n_groups)) return rc;
   hipLaunchKernelGGL(topn_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, st, sl.d_bmax, sl.d_bidx, n_groups, how_many, k_ptr, k_idx, d_rows,
-                     d_eptr, d_eidx, n_items, p.tile_stride, sl.d_tau);
+                     d_eptr, d_eidx, n_items, p.tile_stride, h->tag_bits, sl.d_tau);
   // 3. filter, 4. exact scores of the hits (known items dropped), 5. the N best -- written straight into the slot's pinned
   // block (device-visible host memory: no copy kernel, no copy call)
   if (int rc = topn_launch_stream<1>(h, sl, p.S, nt, y.F, n_items, k, nq, 1, &n_fw)) return rc;
   hipLaunchKernelGGL(topn_scatter_kernel, dim3((unsigned)n_fw), dim3(256), 0, st, sl.d_wcount, sl.d_whits, TOPN_WAVE_CAP, n_fw, p.cap,
                      sl.d_count, sl.d_cand, d_overflow);
   hipLaunchKernelGGL(topn_rescore_kernel, dim3(8, (unsigned)nq), dim3(64), sizeof(float) * 64 * (size_t)(k + 1), st, y.F, k, sl.d_vecs, sl.d_vrow, sl.d_vptr, sl.d_count, p.cap,
-                     sl.d_cand, k_ptr, k_idx, d_rows, d_eptr, d_eidx, sl.d_pairs);
+                     sl.d_cand, k_ptr, k_idx, d_rows, d_eptr, d_eidx, h->tag_bits, sl.d_pairs);
   uint8_t* o = sl.h_stage;
   const size_t o_cnt = sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many, o_tau = o_cnt + sizeof(unsigned) * TOPN_FILTER_QUERIES,
                o_ovf = o_tau + sizeof(float) * TOPN_FILTER_QUERIES;
@@ -438,41 +456,32 @@ int topn_pass_filter_finish(mals_handle h, TopnSlot& sl, const TopnRequest& rq, 
     }
   for (int q = 0; q < ps.nq; ++q) {
     if (failed[(size_t)q]) continue;
-    const size_t qq = (size_t)(ps.q0 + q);
+    const TopnOut o_q = topn_out(rq, (size_t)(ps.q0 + q));
     int n = 0;
     for (int j = 0; j < how_many; ++j) {
       const uint64_t pr = outp[(size_t)q * how_many + j];
       if (pr != 0) {
-        rq.item_idx_out[qq * how_many + j] = (int64_t)(0xffffffffu - (uint32_t)pr);
-        rq.score_out[qq * how_many + j] = key_score((uint32_t)(pr >> 32));
+        o_q.items[j] = (int64_t)(0xffffffffu - (uint32_t)pr);
+        o_q.scores[j] = key_score((uint32_t)(pr >> 32));
         ++n;
       } else {
-        rq.item_idx_out[qq * how_many + j] = -1;
-        rq.score_out[qq * how_many + j] = -std::numeric_limits<float>::infinity();
+        o_q.items[j] = -1;
+        o_q.scores[j] = -std::numeric_limits<float>::infinity();
       }
     }
-    if (rq.n_out) rq.n_out[qq] = n;
+    if (o_q.n) *o_q.n = n;
   }
   return MALS_OK;
 }
 
-int topn_run(mals_handle h, const TopnRequest& rq) {
-  if (!h->tn_ws) h->tn_ws = new TopnWorkspace();
-  TopnWorkspace* w = static_cast<TopnWorkspace*>(h->tn_ws);
+bool topn_dense_only(mals_handle h, int how_many) {
   const int64_t n_items = h->side[MALS_SIDE_Y].n_total;
-  const bool dense_only = n_items < 131072 || n_items >= 0xffffffffll || rq.how_many > TOPN_FILTER_MAX_N ||
-                          n_items / 16 < 64 * (int64_t)rq.how_many || std::getenv("MALS_TOPN_FULL");
-  if (dense_only) {
-    for (int q0 = 0; q0 < rq.n_queries; q0 += TOPN_MAX_QUERIES) {
-      TopnPass ps;
-      ps.q0 = q0;
-      ps.nq = std::min(TOPN_MAX_QUERIES, rq.n_queries - q0);
-      if (int rc = topn_upload_pass(h, w->slot[0], h->stream, rq, ps)) return rc;
-      if (int rc = topn_pass_dense(h, w, w->slot[0], rq, ps)) return rc;
-    }
-    return MALS_OK;
-  }
-  const TopnFilterPlan p = topn_plan(h, rq.how_many);
+  return n_items < 131072 || n_items >= 0xffffffffll || how_many > TOPN_FILTER_MAX_N || n_items / 16 < 64 * (int64_t)how_many ||
+         std::getenv("MALS_TOPN_FULL");
+}
+
+// streams, events and pinned result blocks of the slots; every slot stream ordered after the work already on the handle's
+int topn_prepare_slots(mals_handle h, TopnWorkspace* w, const TopnFilterPlan& p) {
   for (TopnSlot& sl : w->slot) {
     if (!sl.stream) HIPCHK(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
     if (!sl.ev) HIPCHK(h, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
@@ -486,6 +495,55 @@ int topn_run(mals_handle h, const TopnRequest& rq) {
     }
   }
   if (!w->ev_begin) HIPCHK(h, hipEventCreateWithFlags(&w->ev_begin, hipEventDisableTiming));
+  return MALS_OK;
+}
+
+// decode the pass in slot s; the queries the filter could not answer (rare) go through the dense path, run by run (the
+// slot's input block is free again: its pass has finished)
+int topn_finish_slot(mals_handle h, TopnWorkspace* w, int s, const TopnRequest& rq, const TopnPass& done, const TopnFilterPlan& p,
+                     std::vector<uint8_t>& failed) {
+  bool any_failed = false;
+  if (int rc = topn_pass_filter_finish(h, w->slot[s], rq, done, p, failed, &any_failed)) return rc;
+  if (any_failed && std::getenv("MALS_TOPN_DEBUG")) {
+    int nf = 0;
+    for (uint8_t f : failed) nf += f;
+    std::fprintf(stderr, "[mals top-N] pass at query %d (%d queries): %d to the dense path\n", done.q0, done.nq, nf);
+  }
+  if (any_failed) {
+    for (int q = 0; q < done.nq;) {
+      if (!failed[(size_t)q]) {
+        ++q;
+        continue;
+      }
+      int e = q;
+      while (e < done.nq && failed[(size_t)e] && e - q < TOPN_MAX_QUERIES) ++e;
+      TopnPass ps;
+      ps.q0 = done.q0 + q;
+      ps.nq = e - q;
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (int rc = topn_upload_pass(h, w->slot[s], h->stream, rq, ps)) return rc;
+      if (int rc = topn_pass_dense(h, w, w->slot[s], rq, ps)) return rc;
+      q = e;
+    }
+  }
+  return MALS_OK;
+}
+
+int topn_run(mals_handle h, const TopnRequest& rq) {
+  if (!h->tn_ws) h->tn_ws = new TopnWorkspace();
+  TopnWorkspace* w = static_cast<TopnWorkspace*>(h->tn_ws);
+  if (topn_dense_only(h, rq.how_many)) {
+    for (int q0 = 0; q0 < rq.n_queries; q0 += TOPN_MAX_QUERIES) {
+      TopnPass ps;
+      ps.q0 = q0;
+      ps.nq = std::min(TOPN_MAX_QUERIES, rq.n_queries - q0);
+      if (int rc = topn_upload_pass(h, w->slot[0], h->stream, rq, ps)) return rc;
+      if (int rc = topn_pass_dense(h, w, w->slot[0], rq, ps)) return rc;
+    }
+    return MALS_OK;
+  }
+  const TopnFilterPlan p = topn_plan(h, rq.how_many);
+  if (int rc = topn_prepare_slots(h, w, p)) return rc;
   // whatever the caller's stream still has to do (an iteration, a factor upload) comes first
   HIPCHK(h, hipEventRecord(w->ev_begin, h->stream));
   for (TopnSlot& sl : w->slot) HIPCHK(h, hipStreamWaitEvent(sl.stream, w->ev_begin, 0));
@@ -501,32 +559,7 @@ int topn_run(mals_handle h, const TopnRequest& rq) {
   auto finish = [&](int s) -> int {
     if (!busy[s]) return MALS_OK;
     busy[s] = false;
-    bool any_failed = false;
-    const TopnPass done = inflight[s];
-    if (int rc = topn_pass_filter_finish(h, w->slot[s], rq, done, p, failed, &any_failed)) return rc;
-    if (any_failed && std::getenv("MALS_TOPN_DEBUG")) {
-      int nf = 0;
-      for (uint8_t f : failed) nf += f;
-      std::fprintf(stderr, "[mals top-N] pass at query %d (%d queries): %d to the dense path\n", done.q0, done.nq, nf);
-    }
-    if (any_failed) {  // rare: answer those queries exactly the slow way, run by run (the slot's input block is free again: its pass has finished)
-      for (int q = 0; q < done.nq;) {
-        if (!failed[(size_t)q]) {
-          ++q;
-          continue;
-        }
-        int e = q;
-        while (e < done.nq && failed[(size_t)e] && e - q < TOPN_MAX_QUERIES) ++e;
-        TopnPass ps;
-        ps.q0 = done.q0 + q;
-        ps.nq = e - q;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (int rc = topn_upload_pass(h, w->slot[s], h->stream, rq, ps)) return rc;
-        if (int rc = topn_pass_dense(h, w, w->slot[s], rq, ps)) return rc;
-        q = e;
-      }
-    }
-    return MALS_OK;
+    return topn_finish_slot(h, w, s, rq, inflight[s], p, failed);
   };
   int s = 0;
   int rc_all = MALS_OK;
@@ -552,4 +585,209 @@ int topn_run(mals_handle h, const TopnRequest& rq) {
     }
   }
   return rc_all;
+}
+
+// ---- the serving front: many request threads, one handle ---------------------------------------------------------------
+// The reference's top-N is entered by every request thread of the servlet container at once (ServerRecommender.java:359-441
+// -> multithreadedTopN :443-508), one user per call.  Here a call is cheap only as part of a PASS (one read of Y answers up
+// to 240 queries), so concurrent calls are folded into passes: a call becomes a ticket in the handle's queue; the first
+// thread that finds no leader becomes the leader, packs whatever is queued into the next pass, enqueues it on a slot,
+// decodes finished passes and wakes their callers.  When its own ticket is answered it hands leadership to a caller that is
+// still waiting.  While a pass is on the device the tickets of the calls that arrive pile up and form the next one (group
+// commit); `depth` passes are in flight at most (2: one streaming Y, one being prepared behind it; more would only split the
+// same callers over more reads of Y).  Calls that are passes of their own already (>= TOPN_FRONT_BULK queries, caller's
+// vectors, how_many the filter does not take) run exclusively, in queue order, through topn_run.
+constexpr int TOPN_FRONT_BULK = 64;
+
+struct TopnTicket {
+  // a small by-user call ...
+  const int64_t* user_idx = nullptr;
+  int n = 0, how_many = 0;
+  bool skip_known = false;
+  int64_t* item_out = nullptr;
+  float* score_out = nullptr;
+  int32_t* n_out = nullptr;
+  // ... or a whole request of its own
+  const TopnRequest* bulk = nullptr;
+  int rc = MALS_OK;
+  std::string err;
+  bool done = false;
+  bool is_leader = false;
+  std::condition_variable cv;
+};
+
+struct TopnFrontPass {
+  std::vector<TopnTicket*> tickets;
+  std::vector<int64_t> users;
+  std::vector<uint8_t> skip;
+  std::vector<TopnOut> outs;
+  TopnRequest rq;
+  TopnPass ps;
+  TopnFilterPlan plan;
+};
+
+struct TopnFront {
+  std::mutex mu;
+  std::deque<TopnTicket*> queue;
+  bool leader = false;
+  TopnFrontPass inflight[TOPN_SLOTS];
+  bool busy[TOPN_SLOTS] = {};
+  int n_busy = 0, next_slot = 0, oldest = 0;
+  int depth = 2;
+  std::vector<uint8_t> failed;
+  // counters (mals_recommend_front_stats)
+  uint64_t calls = 0, queries = 0, passes = 0, bulk_calls = 0;
+};
+
+TopnFront* topn_front(mals_handle h) { return static_cast<TopnFront*>(h->tn_front); }
+
+// leader only, mutex NOT held: the pass in `fp` (already filled) onto slot s
+int topn_front_enqueue(mals_handle h, TopnWorkspace* w, int s, TopnFrontPass& fp) {
+  if (int rc = topn_prepare_slots(h, w, fp.plan)) return rc;
+  HIPCHK(h, hipEventRecord(w->ev_begin, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(w->slot[s].stream, w->ev_begin, 0));
+  if (int rc = topn_upload_pass(h, w->slot[s], w->slot[s].stream, fp.rq, fp.ps)) return rc;
+  return topn_pass_filter_enqueue(h, w->slot[s], fp.rq, fp.ps, fp.plan);
+}
+
+void topn_front_complete(TopnFrontPass& fp, int rc, const std::string& err) {  // mutex held
+  for (TopnTicket* t : fp.tickets) {
+    t->rc = rc;
+    if (rc != MALS_OK) t->err = err;
+    t->done = true;
+    if (!t->is_leader) t->cv.notify_one();
+  }
+  fp.tickets.clear();
+}
+
+// The calling thread leads until its own ticket is answered.
+void topn_front_lead(mals_handle h, TopnFront* f, std::unique_lock<std::mutex>& lk, TopnTicket* me) {
+  if (!h->tn_ws) h->tn_ws = new TopnWorkspace();
+  TopnWorkspace* w = static_cast<TopnWorkspace*>(h->tn_ws);
+  const int k_tiles = topn_max_tiles((h->cfg.features + 31) / 32);
+  auto finish_oldest = [&]() {
+    const int s = f->oldest;
+    TopnFrontPass& fp = f->inflight[s];
+    lk.unlock();
+    const int rc = topn_finish_slot(h, w, s, fp.rq, fp.ps, fp.plan, f->failed);
+    const std::string err = rc != MALS_OK ? h->err : std::string();
+    lk.lock();
+    f->busy[s] = false;
+    --f->n_busy;
+    f->oldest = (s + 1) % f->depth;
+    topn_front_complete(fp, rc, err);
+  };
+  while (!me->done) {
+    TopnTicket* head = f->queue.empty() ? nullptr : f->queue.front();
+    if (head && (head->bulk || topn_dense_only(h, head->how_many))) {
+      // a request that is passes of its own (or a catalogue the dense path answers): alone on the workspace
+      while (f->n_busy > 0) finish_oldest();
+      if (me->done && head != me) break;   // (own answer arrived while draining: let the successor run it)
+      f->queue.pop_front();
+      TopnFrontPass one;
+      one.tickets.push_back(head);
+      if (head->bulk) {
+        one.rq = *head->bulk;
+        ++f->bulk_calls;
+      } else {
+        one.rq.n_queries = head->n;
+        one.rq.how_many = head->how_many;
+        one.rq.user_idx = head->user_idx;
+        one.rq.skip_known = head->skip_known;
+        one.rq.item_idx_out = head->item_out;
+        one.rq.score_out = head->score_out;
+        one.rq.n_out = head->n_out;
+      }
+      lk.unlock();
+      const int rc = topn_run(h, one.rq);
+      const std::string err = rc != MALS_OK ? h->err : std::string();
+      lk.lock();
+      topn_front_complete(one, rc, err);
+      continue;
+    }
+    if (head && f->n_busy < f->depth) {
+      // the next pass: whole tickets, one how_many, up to the pass's query capacity
+      const int s = f->next_slot;
+      TopnFrontPass& fp = f->inflight[s];
+      const int cap = 16 * k_tiles;
+      fp.tickets.clear(); fp.users.clear(); fp.skip.clear(); fp.outs.clear();
+      const int how_many = head->how_many;
+      while (!f->queue.empty()) {
+        TopnTicket* t = f->queue.front();
+        if (t->bulk || t->how_many != how_many || (int)fp.users.size() + t->n > cap) break;
+        f->queue.pop_front();
+        fp.tickets.push_back(t);
+        for (int q = 0; q < t->n; ++q) {
+          fp.users.push_back(t->user_idx[q]);
+          fp.skip.push_back(t->skip_known ? 1 : 0);
+          fp.outs.push_back({t->item_out + (size_t)q * how_many, t->score_out + (size_t)q * how_many, t->n_out ? t->n_out + q : nullptr});
+        }
+      }
+      fp.rq = TopnRequest();
+      fp.rq.n_queries = (int)fp.users.size();
+      fp.rq.how_many = how_many;
+      fp.rq.user_idx = fp.users.data();
+      fp.rq.skip_known_q = fp.skip.data();
+      fp.rq.out_q = fp.outs.data();
+      fp.ps = TopnPass();
+      fp.ps.q0 = 0;
+      fp.ps.nq = fp.rq.n_queries;
+      fp.plan = topn_plan(h, how_many);
+      f->busy[s] = true;
+      ++f->n_busy;
+      f->next_slot = (s + 1) % f->depth;
+      ++f->passes;
+      lk.unlock();
+      const int rc = topn_front_enqueue(h, w, s, fp);
+      const std::string err = rc != MALS_OK ? h->err : std::string();
+      lk.lock();
+      if (rc != MALS_OK) {  // nothing of the pass may still run when its callers return
+        lk.unlock();
+        if (w->slot[s].stream) (void)hipStreamSynchronize(w->slot[s].stream);
+        lk.lock();
+        f->busy[s] = false;
+        --f->n_busy;
+        // (slots complete in order: an enqueue failure of the newest pass leaves `oldest` where it was unless it was alone)
+        if (f->n_busy == 0) f->oldest = f->next_slot;
+        else f->next_slot = s;
+        topn_front_complete(fp, rc, err);
+      }
+      continue;
+    }
+    if (f->n_busy > 0) {
+      finish_oldest();
+      continue;
+    }
+    break;  // (not reached: a leader's own ticket is queued, in flight or done)
+  }
+}
+
+// every mals_recommend* call ends here
+int topn_front_submit(mals_handle h, TopnTicket& me) {
+  TopnFront* f = topn_front(h);
+  std::unique_lock<std::mutex> lk(f->mu);
+  ++f->calls;
+  f->queries += (uint64_t)(me.bulk ? me.bulk->n_queries : me.n);
+  f->queue.push_back(&me);
+  while (!me.done) {
+    if (!f->leader) {
+      f->leader = true;
+      me.is_leader = true;
+      topn_front_lead(h, f, lk, &me);
+      me.is_leader = false;
+      f->leader = false;
+      // successor: a caller whose answer is still out -- in the oldest pass in flight, else at the head of the queue
+      TopnTicket* next = nullptr;
+      if (f->n_busy > 0) {
+        for (TopnTicket* t : f->inflight[f->oldest].tickets)
+          if (!t->done) { next = t; break; }
+      }
+      if (!next && !f->queue.empty()) next = f->queue.front();
+      if (next) next->cv.notify_one();
+    } else {
+      me.cv.wait(lk);
+    }
+  }
+  if (me.rc != MALS_OK) h->err = me.err;
+  return me.rc;
 }

@@ -423,6 +423,33 @@ __global__ void topn_mask_kernel(const int64_t* __restrict__ row_ptr, const int3
     if (slot >= 0) scores[(int64_t)q * n_out + slot] = -__builtin_huge_valf();
   }
 }
+// userTagIDs (RecommendIterator.java:72: "if (userTagIDs.contains(itemID)) return null"): items that are tag pseudo-items
+// are never recommended to anybody.  The handle keeps them as one bit per item (mals_set_tag_items).
+__device__ __forceinline__ bool topn_tagged(const uint32_t* __restrict__ tag_bits, int64_t item) {
+  return tag_bits != nullptr && ((tag_bits[item >> 5] >> (item & 31)) & 1u) != 0u;
+}
+__global__ void topn_tag_bits_kernel(const int64_t* __restrict__ item_idx, int64_t n, int64_t n_items, uint32_t* __restrict__ bits,
+                                     unsigned long long* __restrict__ n_set) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t it = item_idx[i];
+  if (it < 0 || it >= n_items) return;   // a tag that owns no row of Y (its entries were all removed)
+  const uint32_t bit = 1u << (it & 31);
+  if ((atomicOr(&bits[it >> 5], bit) & bit) == 0u) atomicAdd(n_set, 1ull);
+}
+// dense path: the tagged items of every query's score row
+__global__ void topn_mask_tags_kernel(const uint32_t* __restrict__ tag_bits, int n_queries, int64_t n_items, float* __restrict__ scores) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 32-item word per thread
+  if (w >= (n_items + 31) / 32) return;
+  uint32_t bits = tag_bits[w];
+  while (bits) {
+    const int b = __ffs((int)bits) - 1;
+    bits &= bits - 1;
+    const int64_t it = w * 32 + b;
+    if (it < n_items)
+      for (int q = 0; q < n_queries; ++q) scores[(int64_t)q * n_items + it] = -__builtin_huge_valf();
+  }
+}
 // caller-supplied exclusion lists (anonymous users: the items they were built from, SR:561-606)
 __global__ void topn_exclude_kernel(const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx, int n_queries,
                                     int64_t n_items, int tile_stride, int64_t n_out, float* __restrict__ scores) {
@@ -446,7 +473,7 @@ __global__ __launch_bounds__(1024) void topn_threshold_kernel(float* __restrict_
                                                               int how_many, const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ col,
                                                               const int64_t* __restrict__ query_row, const int64_t* __restrict__ excl_ptr,
                                                               const int64_t* __restrict__ excl_idx, int64_t n_items, int tile_stride,
-                                                              float* __restrict__ tau) {
+                                                              const uint32_t* __restrict__ tag_bits, float* __restrict__ tau) {
   __shared__ unsigned h[256], sfx[256];
   __shared__ uint32_t s_prefix, s_rem;
   const int q = blockIdx.x;
@@ -471,7 +498,12 @@ __global__ __launch_bounds__(1024) void topn_threshold_kernel(float* __restrict_
   __threadfence_block();
   __syncthreads();
   float best = -__builtin_huge_valf();
-  for (int64_t i = threadIdx.x; i < n_row; i += 1024) best = fmaxf(best, row[i]);
+  // (a bucket won by a tag item is dropped like one won by a known item; an empty bucket's idx is never read as an item:
+  // its maximum is -inf already)
+  for (int64_t i = threadIdx.x; i < n_row; i += 1024) {
+    const float v = row[i];
+    if (v > -__builtin_huge_valf() && !topn_tagged(tag_bits, (int64_t)idx[i])) best = fmaxf(best, v);
+  }
   const uint32_t key = score_key(best);
   if (threadIdx.x == 0) {
     s_prefix = 0;
@@ -534,7 +566,7 @@ __global__ __launch_bounds__(64) void topn_rescore_kernel(const float* __restric
                                                           const uint32_t* __restrict__ cand, const int64_t* __restrict__ row_ptr,
                                                           const int32_t* __restrict__ col, const int64_t* __restrict__ query_row,
                                                           const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx,
-                                                          uint64_t* __restrict__ pairs) {
+                                                          const uint32_t* __restrict__ tag_bits, uint64_t* __restrict__ pairs) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   float* ys = reinterpret_cast<float*>(smem);  // [64][k + 1]
   __shared__ uint32_t sk[1024];
@@ -559,7 +591,7 @@ __global__ __launch_bounds__(64) void topn_rescore_kernel(const float* __restric
     const unsigned p = base + lane;
     const bool valid = p < n;
     const uint32_t it = valid ? cand[(int64_t)q * cap + p] : 0u;
-    bool struck = false;
+    bool struck = valid && topn_tagged(tag_bits, (int64_t)it);
     for (int64_t c0 = 0; c0 < n_list; c0 += 1024) {
       __syncthreads();
       for (int i = lane; i < 1024 && c0 + i < n_list; i += 64) {

@@ -135,6 +135,28 @@ class Ingest:
         self._chk(self._L.mals_ingest_install(self._g, core._h))
         core._keep[("ingest",)] = self
 
+    def install_group(self, group, copy=False):
+        """mals_ingest_install_group: both matrices cut at the group's bounds, every member its slices device to device,
+        knownItemIDs and the userTagIDs mask included.  copy=False: slices are borrowed where the member shares the device
+        (this object is kept alive by the group wrapper); copy=True (MALS_INSTALL_COPY): every member owns its slices and
+        this object may be closed."""
+        self._chk(self._L.mals_ingest_install_group(self._g, group._g, _lib.INSTALL_COPY if copy else 0))
+        if not copy:
+            group._keep_ingest = self
+
+    def tag_items(self):
+        """dense item index per userTagID (ascending ids), -1 = the tag owns no row of R^T"""
+        n = len(self.tag_ids(_lib.USER_TAG_IDS))
+        out = np.empty(n, dtype=np.int64)
+        self._chk(self._L.mals_ingest_get_tag_items(self._g, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def partitions(self):
+        """(user-id ranges, item ranges) the last finish was cut into; (0, 0): one sort pipeline held everything"""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._chk(self._L.mals_ingest_partitions(self._g, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def stats(self):
         ms, ws, by, p = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
         self._chk(self._L.mals_ingest_stats(self._g, ctypes.byref(ms), ctypes.byref(ws), ctypes.byref(by), ctypes.byref(p)))

@@ -54,14 +54,17 @@ def scores_to_many(Y, vectors):
     return (total / float(len(vectors))).astype(np.float32)
 
 
-def recommend(Y, x, how_many, known=None):
+def recommend(Y, x, how_many, known=None, tags=None):
     """Returns (item indices, scores), best first, ties by ascending index.  x: one vector, or an array of several
-    (recommendToMany)."""
+    (recommendToMany).  tags: userTagIDs as item indices -- RecommendIterator.java:72 returns null for them before it
+    looks at anything else."""
     x = np.asarray(x, np.float32)
     s = scores(Y, x) if x.ndim == 1 else scores_to_many(Y, x)
     ok = np.ones(len(s), bool)
+    if tags is not None and len(tags):
+        ok[np.asarray(tags, np.int64)] = False            # RecommendIterator.java:72
     if known is not None and len(known):
-        ok[np.asarray(known, np.int64)] = False
+        ok[np.asarray(known, np.int64)] = False           # RecommendIterator.java:75-82
     idx = np.flatnonzero(ok)
     order = np.lexsort((idx, -s[idx].astype(np.float64)))[:how_many]
     return idx[order], s[idx][order]

@@ -35,3 +35,9 @@ def pytest_terminal_summary(terminalreporter):
     w = getattr(mod, "WORST_ROW", None) if mod else None
     if w and w["where"] is not None:
         terminalreporter.write_line("parity sweeps: worst single row vs the oracle %.3e (%s), bar %.0e" % (w["value"], w["where"], getattr(mod, "ROW_TOL", 0.0)))
+    full = sys.modules.get("test_gpu_full_size") or sys.modules.get("tests.test_gpu_full_size")
+    for cfg, side, n, entries, worst, length, frob, per_class in (getattr(full, "WORST", None) or []):
+        terminalreporter.write_line("full size %s, %s half: %d rows (%d entries) vs the oracle, worst row %.3e (a row of %d entries), "
+                                    "relative Frobenius %.3e, bar %.0e per row; rows per length class %s"
+                                    % (cfg, side, n, entries, worst, length, frob, getattr(full, "ROW_TOL", 0.0),
+                                       ", ".join("%d-%s: %d" % (lo, "inf" if hi >= (1 << 40) else hi, c) for (lo, hi), c in per_class.items())))

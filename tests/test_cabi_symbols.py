@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared_functions():
         assert hasattr(L, name), name
-    assert _lib.load().mals_abi_version() == 4
+    assert _lib.load().mals_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_struct_layouts_match_header():
