@@ -288,7 +288,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--segment-nnz", type=int, default=0)
-    ap.add_argument("--gramian-mode", default="auto", choices=["auto", "fp32", "split_f16"],
+    ap.add_argument("--gramian-mode", default="auto", choices=["auto", "fp32", "split_f16", "split3_f16"],
                     help="mals_config.gramian_mode (A/B only; the headline number uses the library default)")
     ap.add_argument("--solve-mode", default="auto", choices=["auto", "direct", "dual"],
                     help="mals_config.solve_mode (A/B only; the headline number uses the library default)")
@@ -370,7 +370,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     chunk_rows = 0
-    gmode = {"auto": 0, "fp32": 1, "split_f16": 2}[args.gramian_mode]
+    gmode = {"auto": 0, "fp32": 1, "split_f16": 2, "split3_f16": 3}[args.gramian_mode]
     smode = {"auto": 0, "direct": 1, "dual": 2}[args.solve_mode]
     use_group = (world > 1 or force) and args.exchange == "group"
     if rank_shape:
@@ -662,6 +662,15 @@ def main():
             leg["kernel"] = "rows kernel (als_persistent_kernel, MODE 0, fp32 gather)"
             leg["slower_than_split_f16_by"] = leg["ms_per_step"] / ms_per_step - 1.0
             out["roofline_fp32"] = leg
+            # ... and the arithmetic in between: THREE f16 terms per operand (every fp32 operand exactly, six products per tile on
+            # v_mfma_f32_16x16x32_f16) -- fp32-operand accuracy on the f16 pipe; features 49..64 only
+            if 49 <= k <= 64:
+                leg = unplanted_leg(torch, pkg, sharded, synth, n_users, n_items, nnz_req, k, args, 3, smode, local_rank, device, prob=prob,
+                                    label="the headline workload with --gramian-mode split3_f16 (three f16 terms per operand, 24+ bits, six MFMAs per tile)")
+                leg.pop("_all_rows_launches", None)
+                leg["kernel"] = "rows kernel (als_persistent_kernel_h<4,0,.,3>, MODE 0)"
+                leg["slower_than_split_f16_by"] = leg["ms_per_step"] / ms_per_step - 1.0
+                out["roofline_split24"] = leg
         if world == 1 and not args.no_cpu_baseline and not rank_shape and not big:
             X = als.factors(pkg.SIDE_X)
             Y = als.factors(pkg.SIDE_Y)

@@ -60,7 +60,7 @@ enum { MALS_FLAG_RECONSTRUCT_R = 1, MALS_FLAG_LOSS_IGNORES_UNSPECIFIED = 2 };
 
 enum { MALS_MEM_HOST = 0, MALS_MEM_DEVICE = 1 };
 
-enum { MALS_GRAMIAN_AUTO = 0, MALS_GRAMIAN_FP32 = 1, MALS_GRAMIAN_SPLIT_F16 = 2 };
+enum { MALS_GRAMIAN_AUTO = 0, MALS_GRAMIAN_FP32 = 1, MALS_GRAMIAN_SPLIT_F16 = 2, MALS_GRAMIAN_SPLIT3_F16 = 3 };
 
 enum { MALS_SOLVE_AUTO = 0, MALS_SOLVE_DIRECT = 1, MALS_SOLVE_DUAL = 2 };
 
@@ -86,6 +86,10 @@ typedef struct mals_config {
                                    updates of the factorization use the same operands) -- 2.5x less
                                    matrix-pipe time, rounding error on a par with FP32 (measured
                                    2-4e-7 vs the fp64 reference for both);
+                                   MALS_GRAMIAN_SPLIT3_F16 (features 49..64 only; a measured alternative,
+                                   DESIGN.md section 6): THREE f16 terms per operand -- every fp32 operand
+                                   exactly -- and the six products at or above 2^-24 of the leading one:
+                                   fp32-operand arithmetic on the f16 pipe, twice SPLIT_F16's matrix time;
                                    MALS_GRAMIAN_AUTO (default): FP32 for features <= 16 (where the
                                    products are not the bottleneck), SPLIT_F16 above            */
   int32_t solve_mode;           /* how a row with FEWER ENTRIES THAN FEATURES is solved (ALS:447-494 is the

@@ -12,7 +12,7 @@ OK, SINGULAR, INVALID_ARG, HIP_ERROR, COMM_ERROR, CANCELLED, OOM, ILL_CONDITIONE
 SIDE_X, SIDE_Y = 0, 1
 FLAG_RECONSTRUCT_R, FLAG_LOSS_IGNORES_UNSPECIFIED = 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
-GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16 = 0, 1, 2
+GRAMIAN_AUTO, GRAMIAN_FP32, GRAMIAN_SPLIT_F16, GRAMIAN_SPLIT3_F16 = 0, 1, 2, 3
 SOLVE_AUTO, SOLVE_DIRECT, SOLVE_DUAL = 0, 1, 2
 ABI_VERSION = 5
 GROUP_RCCL, GROUP_PEER_COPY = 0, 1

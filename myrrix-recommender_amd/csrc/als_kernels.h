@@ -865,9 +865,11 @@ __device__ __forceinline__ void issue_pair_loads_h(const SolveParams& p, int (&c
 }
 
 // raw rows of one entry pair -> scaled, split f16 operands; RHS partial sums (fp32, raw rows)
-template <int T, int E, bool FULL, int PART, int E2>
+// NTERM = 3 (MALS_GRAMIAN_SPLIT3_F16): z = zh + zm + zl, three f16 numbers -- 33 significand bits, every fp32 z exactly -- and
+// the six products at or above 2^-24 of the leading one (gram_super_step).
+template <int T, int E, bool FULL, int PART, int E2, int NTERM = 2>
 __device__ __forceinline__ void convert_pair_h(const SolveParams& p, const Chunk& ch, int lane, const float (&raw)[T][E], ZOp<E> (&zh)[T],
-                                               ZOp<E> (&zl)[T], float (&bpart)[T]) {
+                                               ZOp<E> (&zl)[T], float (&bpart)[T], ZOp<E> (&zm)[NTERM == 3 ? T : 1]) {
   constexpr int m0 = E * PART + 2 * E2;  // entry 4 m0 + g of the chunk: lane m0 of this group's row (chunk_issue<true>)
   const float s0 = row_bcast<m0>(ch.w), s1 = row_bcast<m0 + 1>(ch.w);
   const float c0 = row_bcast<m0>(ch.cb), c1 = row_bcast<m0 + 1>(ch.cb);
@@ -881,7 +883,15 @@ __device__ __forceinline__ void convert_pair_h(const SolveParams& p, const Chunk
     const int hp = pk_rn16(z0, z1);
     const f16x2 hh = __builtin_bit_cast(f16x2, hp);
     zh[v].r[E2] = hp;
-    zl[v].r[E2] = pk_rn16(fmaf((float)hh[0], -1.f, z0), fmaf((float)hh[1], -1.f, z1));
+    if constexpr (NTERM == 3) {
+      const float r0 = fmaf((float)hh[0], -1.f, z0), r1 = fmaf((float)hh[1], -1.f, z1);   // exact: the bits rounding dropped
+      const int mp = pk_rn16(r0, r1);
+      const f16x2 mh = __builtin_bit_cast(f16x2, mp);
+      zm[v].r[E2] = mp;
+      zl[v].r[E2] = pk_rn16(fmaf((float)mh[0], -1.f, r0), fmaf((float)mh[1], -1.f, r1));
+    } else {
+      zl[v].r[E2] = pk_rn16(fmaf((float)hh[0], -1.f, z0), fmaf((float)hh[1], -1.f, z1));
+    }
     bpart[v] = fmaf(c0, y0, bpart[v]);
     bpart[v] = fmaf(c1, y1, bpart[v]);
   }
@@ -891,30 +901,30 @@ __device__ __forceinline__ void convert_pair_h(const SolveParams& p, const Chunk
 // gathers of whatever comes next (columns in next_col at next_off): the registers are in flight
 // again as soon as they have been read.  The fences keep that order: left alone, the scheduler
 // issues the refills first and copies the old rows aside, at twice the registers.
-template <int T, int E, bool FULL, int PART>
+template <int T, int E, bool FULL, int PART, int NTERM = 2>
 __device__ __forceinline__ void convert_refill_h(const SolveParams& p, const Chunk& ch, int next_col, int next_off, int lane,
-                                                 float (&raw)[T][E], ZOp<E> (&zh)[T], ZOp<E> (&zl)[T], float (&bpart)[T]) {
+                                                 float (&raw)[T][E], ZOp<E> (&zh)[T], ZOp<E> (&zl)[T], float (&bpart)[T], ZOp<E> (&zm)[NTERM == 3 ? T : 1]) {
 #define MALS_SB __builtin_amdgcn_sched_barrier(0)
   int col[2];
   fetch_pair_cols_h<0>(next_col, next_off, col);
   MALS_SB;
-  convert_pair_h<T, E, FULL, PART, 0>(p, ch, lane, raw, zh, zl, bpart);
+  convert_pair_h<T, E, FULL, PART, 0, NTERM>(p, ch, lane, raw, zh, zl, bpart, zm);
   MALS_SB;
   issue_pair_loads_h<T, E, FULL, 0>(p, col, lane, raw);
   fetch_pair_cols_h<1>(next_col, next_off, col);
   MALS_SB;
-  convert_pair_h<T, E, FULL, PART, 1>(p, ch, lane, raw, zh, zl, bpart);
+  convert_pair_h<T, E, FULL, PART, 1, NTERM>(p, ch, lane, raw, zh, zl, bpart, zm);
   MALS_SB;
   issue_pair_loads_h<T, E, FULL, 1>(p, col, lane, raw);
   if constexpr (E == 8) {
     fetch_pair_cols_h<2>(next_col, next_off, col);
     MALS_SB;
-    convert_pair_h<T, E, FULL, PART, 2>(p, ch, lane, raw, zh, zl, bpart);
+    convert_pair_h<T, E, FULL, PART, 2, NTERM>(p, ch, lane, raw, zh, zl, bpart, zm);
     MALS_SB;
     issue_pair_loads_h<T, E, FULL, 2>(p, col, lane, raw);
     fetch_pair_cols_h<3>(next_col, next_off, col);
     MALS_SB;
-    convert_pair_h<T, E, FULL, PART, 3>(p, ch, lane, raw, zh, zl, bpart);
+    convert_pair_h<T, E, FULL, PART, 3, NTERM>(p, ch, lane, raw, zh, zl, bpart, zm);
     MALS_SB;
     issue_pair_loads_h<T, E, FULL, 3>(p, col, lane, raw);
   }
@@ -938,6 +948,22 @@ __device__ __forceinline__ void gram_super_step(const ZOp<E> (&zh)[T], const ZOp
     for (int j = i; j < T; ++j) acc[tidx(T, i, j)] = mfma_h<E>(zl[i], zh[j], acc[tidx(T, i, j)]);
 }
 
+// three terms: hh + (hm + mh) + (mm + hl + lh); what is dropped (ml, lm, ll) is below 2^-35 of the leading product
+template <int T, int E>
+__device__ __forceinline__ void gram_super_step3(const ZOp<E> (&zh)[T], const ZOp<E> (&zm)[T], const ZOp<E> (&zl)[T], f32x4 (&acc)[tri(T)]) {
+#define MALS_GS3(A, B)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < T; ++i) _Pragma("unroll") for (int j = i; j < T; ++j)              \
+      acc[tidx(T, i, j)] = mfma_h<E>(A[i], B[j], acc[tidx(T, i, j)])
+  // smallest terms first: they are added to the accumulator before the large ones swamp their low bits
+  MALS_GS3(zl, zh);
+  MALS_GS3(zh, zl);
+  MALS_GS3(zm, zm);
+  MALS_GS3(zm, zh);
+  MALS_GS3(zh, zm);
+  MALS_GS3(zh, zh);
+#undef MALS_GS3
+}
+
 // The gathers of a whole super-step (start of a wave's first row only).
 template <int T, int E, bool FULL>
 __device__ __forceinline__ void prime_row_h(const SolveParams& p, int col_src, int lane, float (&raw)[T][E]) {
@@ -951,26 +977,27 @@ __device__ __forceinline__ void prime_row_h(const SolveParams& p, int col_src, i
 }
 
 // One super-step of the row pipeline: PART-th group of 4E entries of chunk ch.
-template <int T, int E, bool FULL, int PART>
+template <int T, int E, bool FULL, int PART, int NTERM = 2>
 __device__ __forceinline__ void super_step_h(const SolveParams& p, const Chunk& ch, const Chunk& chn, int next_col, bool last, int lane,
                                              float (&raw)[T][E], f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
   constexpr int NP = 16 / E;  // super-steps per 64-entry chunk
   const int rb = (lane & 48) << 2;  // byte address of lane 0 of this group's row
-  ZOp<E> zh[T], zl[T];
+  ZOp<E> zh[T], zl[T], zm[NTERM == 3 ? T : 1];
   // what the raw registers are refilled with: the next part of this chunk, part 0 of the next chunk,
   // or (after the row's last super-step) the first super-step of the next row
   const int same_row_col = PART == NP - 1 ? chn.col : ch.col;
   const int same_row_off = PART == NP - 1 ? rb : rb + 4 * E * (PART + 1);
-  convert_refill_h<T, E, FULL, PART>(p, ch, last ? next_col : same_row_col, last ? rb : same_row_off, lane, raw, zh, zl, bpart);
+  convert_refill_h<T, E, FULL, PART, NTERM>(p, ch, last ? next_col : same_row_col, last ? rb : same_row_off, lane, raw, zh, zl, bpart, zm);
   __builtin_amdgcn_sched_barrier(0);
-  gram_super_step<T, E>(zh, zl, acc);
+  if constexpr (NTERM == 3) gram_super_step3<T, E>(zh, zm, zl, acc);
+  else gram_super_step<T, E>(zh, zl, acc);
   __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc (zero on entry) += S^2 * sum_n w_n y_n y_n^T,  bpart += sum_n cb_n y_n  for a row with len > 0.
 // On entry ch = chunk 0 (weights done) and raw = super-step 0 in flight; on exit raw = super-step 0
 // of the NEXT row (columns in the first lanes of next_col) in flight.
-template <int T, int E, bool FULL>
+template <int T, int E, bool FULL, int NTERM = 2>
 __device__ __forceinline__ void gather_row_h(const SolveParams& p, int64_t begin, int len, int lane, float zscale, Chunk& ch,
                                              int next_col, float (&raw)[T][E], f32x4 (&acc)[tri(T)], float (&bpart)[T]) {
   constexpr int NS = 4 * E, NP = 16 / E;
@@ -979,16 +1006,16 @@ __device__ __forceinline__ void gather_row_h(const SolveParams& p, int64_t begin
     // next chunk (clamped inside the row, so always safe to issue); lands during this chunk
     Chunk chn = chunk_issue<true>(p, begin, len, 64 * (q + 1), lane);
     const int ss = NP * q;
-    super_step_h<T, E, FULL, 0>(p, ch, chn, next_col, ss + 1 >= n_ss, lane, raw, acc, bpart);
+    super_step_h<T, E, FULL, 0, NTERM>(p, ch, chn, next_col, ss + 1 >= n_ss, lane, raw, acc, bpart);
     if (ss + 1 < n_ss) {
       if (NP == 2) chunk_weights_h(p, chn, zscale);
-      super_step_h<T, E, FULL, 1>(p, ch, chn, next_col, ss + 2 >= n_ss, lane, raw, acc, bpart);
+      super_step_h<T, E, FULL, 1, NTERM>(p, ch, chn, next_col, ss + 2 >= n_ss, lane, raw, acc, bpart);
     }
     if constexpr (NP == 4) {
-      if (ss + 2 < n_ss) super_step_h<T, E, FULL, 2>(p, ch, chn, next_col, ss + 3 >= n_ss, lane, raw, acc, bpart);
+      if (ss + 2 < n_ss) super_step_h<T, E, FULL, 2, NTERM>(p, ch, chn, next_col, ss + 3 >= n_ss, lane, raw, acc, bpart);
       if (ss + 3 < n_ss) {
         chunk_weights_h(p, chn, zscale);
-        super_step_h<T, E, FULL, 3>(p, ch, chn, next_col, ss + 4 >= n_ss, lane, raw, acc, bpart);
+        super_step_h<T, E, FULL, 3, NTERM>(p, ch, chn, next_col, ss + 4 >= n_ss, lane, raw, acc, bpart);
       }
     }
     ch = chn;
@@ -1317,7 +1344,7 @@ __global__ __launch_bounds__(256, MALS_WAVES(T, MODE)) void als_persistent_kerne
 // a row on, super-step 0 of the next row, which therefore flies during the whole factorization.
 // That needs the next row's first chunk (col, value) on chip a row ahead (nch) and the work items three ahead.  Rows are sorted by length, so the empty rows
 // (nothing to gather: W = G, b = 0) form the tail of a wave's list and are handled after the loop.
-template <int T, int MODE, bool FULL>
+template <int T, int MODE, bool FULL, int NTERM = 2>
 __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_kernel_h(SolveParams p) {
   __shared__ f32x4 sG[MODE == 0 ? tri(T) * 64 : 1];
   const int lane = threadIdx.x & 63;
@@ -1362,7 +1389,7 @@ __global__ __launch_bounds__(256, MALS_WAVES_H(T, MODE)) void als_persistent_ker
       unsigned long long t0 = 0, t1 = 0, t2 = 0;
       if (tr) t0 = __builtin_readcyclecounter();
 #endif
-      gather_row_h<T, E, FULL>(p, cur.begin, cur.len, lane, zscale, ch, nch.col, raw, acc, bpart);
+      gather_row_h<T, E, FULL, NTERM>(p, cur.begin, cur.len, lane, zscale, ch, nch.col, raw, acc, bpart);
 #ifdef MALS_PROFILING
       if (tr) t1 = __builtin_readcyclecounter();
 #endif

@@ -27,6 +27,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -109,6 +110,7 @@ struct mals_handle_s {
   mals_config cfg;
   int T = 0;
   bool split_f16 = false;  // cfg.gramian_mode resolved
+  bool split3 = false;     // MALS_GRAMIAN_SPLIT3_F16: three f16 terms per operand (features 49..64)
   int dual_blocks = 0;     // cfg.solve_mode resolved: rows up to 16*dual_blocks entries go to the dual lists (0 = none)
   // dual path state (dual_kernels.h): rotated copy of the gathered factor matrix, Q / Q^T / eigenvalues
   float* d_Mr = nullptr;
@@ -785,6 +787,12 @@ int launch_solve_TF(mals_handle h, SideState& s, const SolveParams& p, int chunk
   if constexpr (T == 8 && FULL) {
     if (h->split_f16 && h->lds_gather && p.Gperm) return launch_lists_lds(h, s, p, chunk, which);
   }
+  if constexpr (T == 4) {
+    if (h->split3)
+      return launch_lists(h, s, p, chunk, which, als_persistent_kernel_h<T, 0, FULL, 3>, als_persistent_kernel_h<T, 1, FULL, 3>,
+                          als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>,
+                          als_prereduce_kernel<T>);
+  }
   if (h->split_f16)
     return launch_lists(h, s, p, chunk, which, als_persistent_kernel_h<T, 0, FULL>, als_persistent_kernel_h<T, 1, FULL>,
                         als_persistent_kernel<T, D, 0, FULL>, als_persistent_kernel<T, D, 1, FULL>, als_finish_kernel<T>,
@@ -1340,6 +1348,13 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
     case MALS_GRAMIAN_AUTO: h->split_f16 = h->T >= 2; break;  // k <= 16: one tile, the fp32 products are not the bottleneck (k = 30: split is 8 % faster, measured)
     case MALS_GRAMIAN_FP32: h->split_f16 = false; break;
     case MALS_GRAMIAN_SPLIT_F16: h->split_f16 = true; break;
+    case MALS_GRAMIAN_SPLIT3_F16:
+      if (h->T != 4) {
+        delete h;
+        return create_fail(MALS_INVALID_ARG, "mals_create: MALS_GRAMIAN_SPLIT3_F16 is built for 49..64 features");
+      }
+      h->split_f16 = h->split3 = true;
+      break;
     default: delete h; return create_fail(MALS_INVALID_ARG, "mals_create: unknown gramian_mode");
   }
   // a negative alpha (accepted by the reference, ALS:506-509) has no real sqrt(alpha |r|): fp32 gather
@@ -1396,6 +1411,7 @@ int mals_create(const mals_config* cfg, mals_handle* out) {
   t_create_error.clear();
   h->tn_front = new TopnFront();
   if (const char* e = std::getenv("MALS_TOPN_FRONT_DEPTH")) topn_front(h)->depth = std::max(1, std::min(TOPN_SLOTS, std::atoi(e)));
+  if (const char* e = std::getenv("MALS_TOPN_FRONT_SPIN_US")) topn_front(h)->spin_us = std::max(0, std::atoi(e));
   *out = h;
   return MALS_OK;
 }

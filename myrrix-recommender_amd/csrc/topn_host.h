@@ -282,7 +282,7 @@ constexpr int TOPN_WAVE_CAP = 2048;  // hits a wave of the filter kernel can rec
 // topn_stream_kernel: QT = query tiles per wave, 4 QT per workgroup.  MODE 0: *n_out = workgroups of the sample (16
 // buckets each); MODE 1: *n_out = waves of the filter (one hit list each).
 template <int S, int QT, int MODE>
-int topn_launch_stream_QT(mals_handle h, TopnSlot& sl, const float* Y, int64_t n_items, int k, int nq, int tile_stride, int* n_out) {
+int topn_launch_stream_QT(mals_handle h, TopnSlot& sl, const float* Y, int64_t n_items, int k, int nq, int tile_stride, int cap, int* n_out) {
   const int64_t tiles = (n_items + 16 * (int64_t)tile_stride - 1) / (16 * (int64_t)tile_stride);
   const int64_t stages = (tiles + 3) / 4;
   // resident workgroups per CU: what the instantiation's registers and LDS (two buffers of 4 (S + 1) KB) allow, asked once
@@ -319,7 +319,7 @@ int topn_launch_stream_QT(mals_handle h, TopnSlot& sl, const float* Y, int64_t n
 #define MALS_TOPN_GO(LM)                                                                                                              \
   hipLaunchKernelGGL((topn_stream_kernel<S, QT, MODE, LM>), dim3(grid), dim3(256), 0, sl.stream, Y, n_items, k,                           \
                      static_cast<const bf16x8*>(sl.d_img), nq, tile_stride, sl.d_bmax, sl.d_bidx, sl.d_tau, TOPN_WAVE_CAP, sl.d_wcount,   \
-                     sl.d_whits)
+                     sl.d_whits, cap, sl.d_count, sl.d_cand, sl.d_count + (size_t)TOPN_FILTER_QUERIES * TOPN_COUNT_STRIDE)
   if (lm == 1) MALS_TOPN_GO(1);
   else if (lm == 2) MALS_TOPN_GO(2);
   else if (lm == 3) MALS_TOPN_GO(3);
@@ -329,9 +329,9 @@ int topn_launch_stream_QT(mals_handle h, TopnSlot& sl, const float* Y, int64_t n
   return MALS_OK;
 }
 template <int MODE>
-int topn_launch_stream(mals_handle h, TopnSlot& sl, int S, int nt, const float* Y, int64_t n_items, int k, int nq, int tile_stride, int* n_out) {
+int topn_launch_stream(mals_handle h, TopnSlot& sl, int S, int nt, const float* Y, int64_t n_items, int k, int nq, int tile_stride, int cap, int* n_out) {
   const int qt = (nt + 3) / 4;
-#define MALS_TOPN_STREAM(SS, QQ) return topn_launch_stream_QT<SS, QQ, MODE>(h, sl, Y, n_items, k, nq, tile_stride, n_out)
+#define MALS_TOPN_STREAM(SS, QQ) return topn_launch_stream_QT<SS, QQ, MODE>(h, sl, Y, n_items, k, nq, tile_stride, cap, n_out)
   switch (S) {
     case 1:
       if (qt <= 1) MALS_TOPN_STREAM(1, 1);
@@ -396,14 +396,13 @@ int topn_pass_filter_launch(mals_handle h, TopnSlot& sl, const TopnRequest& rq, 
                      static_cast<bf16x8*>(sl.d_img), sl.d_count, d_overflow);
   // 1. sample: bucket maxima of the lower bounds of every tile_stride-th tile; 2. threshold (buckets won by known items dropped)
   int n_groups = 0, n_fw = 0;
-  if (int rc = topn_launch_stream<0>(h, sl, p.S, nt, y.F, n_items, k, nq, p.tile_stride, &n_groups)) return rc;
+  if (int rc = topn_launch_stream<0>(h, sl, p.S, nt, y.F, n_items, k, nq, p.tile_stride, p.cap, &n_groups)) return rc;
   hipLaunchKernelGGL(topn_threshold_kernel, dim3((unsigned)nq), dim3(1024), 0, st, sl.d_bmax, sl.d_bidx, n_groups, how_many, k_ptr, k_idx, d_rows,
                      d_eptr, d_eidx, n_items, p.tile_stride, h->tag_bits, sl.d_tau);
   // 3. filter, 4. exact scores of the hits (known items dropped), 5. the N best -- written straight into the slot's pinned
   // block (device-visible host memory: no copy kernel, no copy call)
-  if (int rc = topn_launch_stream<1>(h, sl, p.S, nt, y.F, n_items, k, nq, 1, &n_fw)) return rc;
-  hipLaunchKernelGGL(topn_scatter_kernel, dim3((unsigned)n_fw), dim3(256), 0, st, sl.d_wcount, sl.d_whits, TOPN_WAVE_CAP, n_fw, p.cap,
-                     sl.d_count, sl.d_cand, d_overflow);
+  // (the filter's waves scatter their own hits into the per-query candidate lists: no kernel in between)
+  if (int rc = topn_launch_stream<1>(h, sl, p.S, nt, y.F, n_items, k, nq, 1, p.cap, &n_fw)) return rc;
   hipLaunchKernelGGL(topn_rescore_kernel, dim3(8, (unsigned)nq), dim3(64), sizeof(float) * 64 * (size_t)(k + 1), st, y.F, k, sl.d_vecs, sl.d_vrow, sl.d_vptr, sl.d_count, p.cap,
                      sl.d_cand, k_ptr, k_idx, d_rows, d_eptr, d_eidx, h->tag_bits, sl.d_pairs);
   uint8_t* o = sl.h_stage;
@@ -611,10 +610,47 @@ struct TopnTicket {
   const TopnRequest* bulk = nullptr;
   int rc = MALS_OK;
   std::string err;
-  bool done = false;
+  bool done = false;          // under the front's mutex
   bool is_leader = false;
+  // How a waiting caller hears from the leader: `sig` (TOPN_SIG_DONE: the answer is in the caller's arrays; TOPN_SIG_LEAD:
+  // take over as leader).  A caller first polls it (an answer takes 100-200 us: most arrive while it polls, and then the
+  // leader's "wake-up" is one store, not a futex call per caller -- 33 of those per pass were half of a pass's host time at
+  // 128 callers), then blocks on its own condition variable.  Everything the leader touches of a ticket it touches under
+  // the ticket's mutex, and a caller takes that mutex once before it returns: the ticket lives on the caller's stack.
+  std::atomic<int> sig{0};
+  std::atomic<bool> blocked{false};
+  std::mutex mu;
   std::condition_variable cv;
 };
+enum { TOPN_SIG_DONE = 1, TOPN_SIG_LEAD = 2 };
+
+void topn_signal(TopnTicket* t, int bits) {
+  std::lock_guard<std::mutex> lk(t->mu);
+  t->sig.fetch_or(bits, std::memory_order_seq_cst);
+  if (t->blocked.load(std::memory_order_seq_cst)) t->cv.notify_one();
+}
+
+// returns the signal bits seen (never 0)
+int topn_wait_signal(TopnTicket* t, int spin_us) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int it = 0;; ++it) {
+    const int sg = t->sig.load(std::memory_order_acquire);
+    if (sg) return sg;
+    if ((it & 15) == 15) {
+      if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > (double)spin_us) break;
+      std::this_thread::yield();
+    } else {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+      __builtin_ia32_pause();
+#endif
+    }
+  }
+  std::unique_lock<std::mutex> lk(t->mu);
+  t->blocked.store(true, std::memory_order_seq_cst);
+  while (!t->sig.load(std::memory_order_seq_cst)) t->cv.wait(lk);
+  t->blocked.store(false, std::memory_order_seq_cst);
+  return t->sig.load(std::memory_order_seq_cst);
+}
 
 struct TopnFrontPass {
   std::vector<TopnTicket*> tickets;
@@ -634,6 +670,7 @@ struct TopnFront {
   bool busy[TOPN_SLOTS] = {};
   int n_busy = 0, next_slot = 0, oldest = 0;
   int depth = 2;
+  int spin_us = 300;   // how long a waiting caller polls before it blocks (MALS_TOPN_FRONT_SPIN_US at mals_create)
   std::vector<uint8_t> failed;
   // counters (mals_recommend_front_stats)
   uint64_t calls = 0, queries = 0, passes = 0, bulk_calls = 0;
@@ -655,7 +692,7 @@ void topn_front_complete(TopnFrontPass& fp, int rc, const std::string& err) {  /
     t->rc = rc;
     if (rc != MALS_OK) t->err = err;
     t->done = true;
-    if (!t->is_leader) t->cv.notify_one();
+    if (!t->is_leader) topn_signal(t, TOPN_SIG_DONE);   // (after this the ticket may be gone)
   }
   fp.tickets.clear();
 }
@@ -769,7 +806,8 @@ int topn_front_submit(mals_handle h, TopnTicket& me) {
   ++f->calls;
   f->queries += (uint64_t)(me.bulk ? me.bulk->n_queries : me.n);
   f->queue.push_back(&me);
-  while (!me.done) {
+  for (;;) {
+    if (me.done) break;
     if (!f->leader) {
       f->leader = true;
       me.is_leader = true;
@@ -783,11 +821,19 @@ int topn_front_submit(mals_handle h, TopnTicket& me) {
           if (!t->done) { next = t; break; }
       }
       if (!next && !f->queue.empty()) next = f->queue.front();
-      if (next) next->cv.notify_one();
-    } else {
-      me.cv.wait(lk);
+      if (next) topn_signal(next, TOPN_SIG_LEAD);
+      continue;
     }
+    // somebody leads: wait for the answer, or for the call to lead
+    const int spin_us = f->spin_us;
+    lk.unlock();
+    const int sg = topn_wait_signal(&me, spin_us);
+    if (sg & TOPN_SIG_LEAD) me.sig.fetch_and(~TOPN_SIG_LEAD, std::memory_order_seq_cst);
+    lk.lock();
   }
-  if (me.rc != MALS_OK) h->err = me.err;
-  return me.rc;
+  const int rc = me.rc;
+  if (rc != MALS_OK) h->err = me.err;
+  lk.unlock();
+  { std::lock_guard<std::mutex> own(me.mu); }   // the leader has let go of the ticket
+  return rc;
 }

@@ -188,14 +188,15 @@ __global__ __launch_bounds__(256) void topn_prepare_kernel(const float* __restri
 // MODE 1: filter -- all tiles; acc = approx + margin_i - tau_q; (item i, query q) is a hit iff acc is not below zero.
 //         Hits go to a list PRIVATE to the wave (wave_hits[wave][..], wave_count[wave] counts them, also past wave_cap):
 //         positions come from a ballot, not from an atomic -- a returning atomic in this loop waits on the same counter as
-//         the prefetched rows.  topn_scatter_kernel sorts the hits into per-query candidate lists afterwards.
+//         the prefetched rows.  When a wave has run out of item tiles it sorts its own hits into the per-query candidate lists.
 // The filter's grid is persistent (as many workgroups as fit the chip at once).
 template <int S, int QT, int MODE, int LM>
 __global__ __launch_bounds__(256, 2) void topn_stream_kernel(const float* __restrict__ Y, int64_t n_items, int k,
                                                           const bf16x8* __restrict__ img, int n_queries, int tile_stride,
                                                           float* __restrict__ bmax, uint32_t* __restrict__ bidx,
                                                           const float* __restrict__ tau, int wave_cap, unsigned* __restrict__ wave_count,
-                                                          uint2* __restrict__ wave_hits) {
+                                                          uint2* __restrict__ wave_hits, int cap, unsigned* __restrict__ count,
+                                                          uint32_t* __restrict__ cand, unsigned* __restrict__ overflow) {
   constexpr int CH = 8 * S;  // features per lane
   constexpr int E = S + 1;   // A operands per item tile: S contraction steps + the margin step
   __shared__ __attribute__((aligned(16))) bf16x8 sa2[2][4 * E * 64];  // two stages x [item tile of the stage][operand][lane]
@@ -387,25 +388,21 @@ __global__ __launch_bounds__(256, 2) void topn_stream_kernel(const float* __rest
       }
     }
   }
-  if (MODE == 1 && lane == 0) wave_count[wave] = n_hits;
-}
-
-// the waves' hit lists -> per-query candidate lists (count[q] counts them, also past cap).  One thread per hit slot;
-// here a returning atomic costs nothing else its latency.
-__global__ __launch_bounds__(256) void topn_scatter_kernel(const unsigned* __restrict__ wave_count, const uint2* __restrict__ wave_hits,
-                                                           int wave_cap, int n_waves, int cap, unsigned* __restrict__ count,
-                                                           uint32_t* __restrict__ cand, unsigned* __restrict__ overflow) {
-  const int w = blockIdx.x;
-  if (w >= n_waves) return;
-  const unsigned n = wave_count[w];
-  if (n > (unsigned)wave_cap) {
-    if (threadIdx.x == 0) atomicAdd(overflow, 1u);
-    return;
-  }
-  for (unsigned i = threadIdx.x; i < n; i += 256) {
-    const uint2 hq = wave_hits[(int64_t)w * wave_cap + i];
-    const unsigned p = atomicAdd(&count[(size_t)hq.y * TOPN_COUNT_STRIDE], 1u);
-    if ((int)p < cap) cand[(int64_t)hq.y * cap + p] = hq.x;
+  if (MODE == 1) {
+    if (lane == 0) wave_count[wave] = n_hits;
+    // The wave's own hit list -> the per-query candidate lists (count[q] counts them, also past cap).  Until round 6 a kernel
+    // of its own (one launch and its gap per pass: 7 us); here every wave does it for its ~100 hits when it has run out of
+    // item tiles: the returning atomics wait on nothing the wave still needs, and the other waves of the CU stream on.
+    if (n_hits > (unsigned)wave_cap) {
+      if (lane == 0) atomicAdd(overflow, 1u);   // whose hits are missing is not known: the whole pass falls back
+    } else if (n_hits) {
+      __threadfence();   // the list was written by this wave's own lanes: stores before the loads of other lanes
+      for (unsigned i = lane; i < n_hits; i += 64) {
+        const uint2 hq = my_hits[i];
+        const unsigned pos = atomicAdd(&count[(size_t)hq.y * TOPN_COUNT_STRIDE], 1u);
+        if ((int)pos < cap) cand[(int64_t)hq.y * cap + pos] = hq.x;
+      }
+    }
   }
 }
 

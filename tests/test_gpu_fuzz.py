@@ -95,6 +95,11 @@ def draw_case(seed):
                segment_nnz=int(rng.choice([0, 0, 64, 128])), chunk_rows=int(rng.choice([0, 0, 97, 256])),
                gramian_mode=int(rng.choice([0, 0, _lib.GRAMIAN_FP32, _lib.GRAMIAN_SPLIT_F16])),
                solve_mode=int(rng.choice([0, 0, _lib.SOLVE_DIRECT, _lib.SOLVE_DUAL])))
+    # MALS_FUZZ_GRAMIAN_MODE=3: the whole sweep under one arithmetic (the three-term split is built for 49..64 features: the
+    # other feature counts keep their drawn mode) -- profiles/r6_parity_evidence.txt
+    forced = os.environ.get("MALS_FUZZ_GRAMIAN_MODE")
+    if forced is not None and (int(forced) != _lib.GRAMIAN_SPLIT3_F16 or 49 <= k <= 64):
+        cfg["gramian_mode"] = int(forced)
     return k, n_users, n_items, n_stale, r_csr, c_csr, Y0, cfg
 
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import myrrix_recommender_amd as pkg
-from myrrix_recommender_amd import ingest
+from myrrix_recommender_amd import _lib, ingest
 from oracle import ingest_oracle as io
 
 pytestmark = pytest.mark.gpu
@@ -13,11 +13,16 @@ pytestmark = pytest.mark.gpu
 NaN = np.float32("nan")
 
 
-def check(u, i, v, thr=1.0e-4):
+def check(u, i, v, thr=1.0e-4, part=None):
+    """part: MALS_INGEST_OPT_PARTITION_RECORDS -- the finish then runs user-id range by user-id range (ingest_big_host.h)"""
     (uid, rp, col, val), (iid, cp, ccol, cval) = io.expected_matrices(u, i, v, thr)
     with ingest.Ingest(0, thr) as g:
+        if part:
+            g.set_option(_lib.INGEST_OPT_PARTITION_RECORDS, part)
         g.append(u, i, v)
         g.finish()
+        if part and len(u) > part:
+            assert g.partitions()[0] >= 2, g.partitions()
         c = g.counts()
         assert c == {"records": len(u), "users": len(uid), "items": len(iid), "nnz": len(col)}
         assert np.array_equal(g.ids(pkg.SIDE_X), uid) and np.array_equal(g.ids(pkg.SIDE_Y), iid)

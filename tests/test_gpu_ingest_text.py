@@ -40,10 +40,13 @@ def build_corpus(seed, n_lines, p_odd, bad_budget=90, terminators=("\n",), first
     return bytes(out)
 
 
-def check(streams, thr=1.0e-4, block_bytes=None, pieces=None, known=True):
-    """streams: list of bytes (files in order).  pieces: how each file is cut for append_text (None = whole)."""
+def check(streams, thr=1.0e-4, block_bytes=None, pieces=None, known=True, part=None):
+    """streams: list of bytes (files in order).  pieces: how each file is cut for append_text (None = whole).  part:
+    MALS_INGEST_OPT_PARTITION_RECORDS (the finish then runs user-id range by user-id range, ingest_big_host.h)."""
     want = to.expected(streams, thr)
     with ingest.Ingest(0, thr) as g:
+        if part:
+            g.set_option(_lib.INGEST_OPT_PARTITION_RECORDS, part)
         if known:
             g.set_option(_lib.INGEST_OPT_KNOWN_ITEMS, 1)
         if block_bytes:

@@ -431,6 +431,35 @@ def test_gramian_modes_match_oracle(mode, k, flags, alpha, vscale):
     assert worst < 10 * REL_TOL, (mode, k, flags, worst)
 
 
+@pytest.mark.parametrize("k,flags,alpha,vscale", [(64, 0, 1.0, 1.0), (50, 0, 40.0, 1.0), (49, 0, 1.0, 1000.0), (60, 0, 1.0, 1e-3),
+                                                  (64, pkg.FLAG_RECONSTRUCT_R, 1.0, 1.0), (56, pkg.FLAG_LOSS_IGNORES_UNSPECIFIED, 1.0, 1.0)])
+def test_three_term_split_matches_oracle_no_worse_than_two_terms(k, flags, alpha, vscale):
+    """MALS_GRAMIAN_SPLIT3_F16 (features 49..64): every fp32 operand exactly as three f16 terms, six products per tile.  Same
+    bar as the other modes; and its error against the fp64 oracle is not above the two-term split's."""
+    n_users, n_items = 900, 300
+    r_csr, c_csr, Y0 = synth.numpy_problem(n_users, n_items, 70000, k, seed=300 + k)
+    r_csr = (r_csr[0], r_csr[1], (r_csr[2] * vscale).astype(np.float32))
+    keep = np.flatnonzero(np.diff(r_csr[0]) >= (k if flags & 2 else 0))
+    rp = np.concatenate([[0], np.cumsum(np.diff(r_csr[0])[keep])]).astype(np.int64)
+    ent = np.concatenate([np.arange(r_csr[0][i], r_csr[0][i + 1]) for i in keep])
+    r_csr = (rp, r_csr[1][ent], r_csr[2][ent])
+    Xo = oracle.half_iteration(*r_csr, Y0, alpha=alpha, flags=flags)
+    err = {}
+    for mode in (_lib.GRAMIAN_SPLIT_F16, _lib.GRAMIAN_SPLIT3_F16):
+        with pkg.ALSCore(k, alpha=alpha, flags=flags, gramian_mode=mode, solve_mode=_lib.SOLVE_DIRECT) as core:
+            core.set_factor_rows(pkg.SIDE_X, len(keep))
+            core.set_factor_rows(pkg.SIDE_Y, n_items)
+            core.set_matrix(pkg.SIDE_X, *r_csr)
+            core.set_factors(pkg.SIDE_Y, Y0)
+            core.half_iteration(pkg.SIDE_X)
+            X = core.get_factors(pkg.SIDE_X)
+        err[mode] = rel(X, Xo)
+        assert err[mode] < REL_TOL, (mode, k, flags, err[mode])
+    assert err[_lib.GRAMIAN_SPLIT3_F16] <= 1.5 * err[_lib.GRAMIAN_SPLIT_F16] + 1e-8, err
+    with pytest.raises(pkg.MalsError):
+        pkg.ALSCore(100, gramian_mode=_lib.GRAMIAN_SPLIT3_F16)
+
+
 def test_split_f16_mode_limits_and_degenerate_scales():
     with pytest.raises(pkg.MalsError):
         pkg.ALSCore(64, gramian_mode=7)

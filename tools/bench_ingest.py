@@ -26,6 +26,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--from-text", action="store_true")
     ap.add_argument("--text-chunk", type=int, default=1 << 25, help="lines formatted per torch pass")
+    ap.add_argument("--stream-text", action="store_true",
+                    help="--from-text for inputs whose text does not fit beside the ingest (C5: 5e9 lines = 88 GB): every piece of text is "
+                         "generated in HBM, handed to mals_ingest_append_text and dropped; times are the library's HIP-event times of its "
+                         "kernels (text_info, stats), so the generator between the pieces is not in them; one run, no repeats")
+    ap.add_argument("--partition-records", type=int, default=0, help="MALS_INGEST_OPT_PARTITION_RECORDS (0: the library's default)")
     a = ap.parse_args()
     if a.from_text:
         return from_text(a)
@@ -107,25 +112,53 @@ def from_text(a):
     gen = torch.Generator(device="cuda").manual_seed(1234567890)
     n = a.records
     texts, n_bytes, sample = [], 0, None
-    for lo in range(0, n, a.text_chunk):
-        m = min(a.text_chunk, n - lo)
-        u = torch.randint(0, a.users, (m,), device="cuda", generator=gen)
-        i = (torch.rand(m, device="cuda", generator=gen).pow_(3.0) * a.items).long().clamp_(max=a.items - 1)
-        v = torch.randint(1, 6, (m,), device="cuda", generator=gen).float()
-        if a.removes > 0:
-            v[torch.rand(m, device="cuda", generator=gen) < a.removes] = float("nan")
-        t = format_lines(torch, u, i, v)
-        if sample is None:
-            sample = (u[:200000].cpu().numpy(), i[:200000].cpu().numpy(), v[:200000].cpu().numpy())
-        texts.append(t)
-        n_bytes += t.numel()
-        del u, i, v
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()
+
+    def pieces():
+        nonlocal sample
+        for lo in range(0, n, a.text_chunk):
+            m = min(a.text_chunk, n - lo)
+            u = torch.randint(0, a.users, (m,), device="cuda", generator=gen)
+            i = (torch.rand(m, device="cuda", generator=gen).pow_(3.0) * a.items).long().clamp_(max=a.items - 1)
+            v = torch.randint(1, 6, (m,), device="cuda", generator=gen).float()
+            if a.removes > 0:
+                v[torch.rand(m, device="cuda", generator=gen) < a.removes] = float("nan")
+            t = format_lines(torch, u, i, v)
+            if sample is None:
+                sample = (u[:200000].cpu().numpy(), i[:200000].cpu().numpy(), v[:200000].cpu().numpy())
+            del u, i, v
+            yield t, lo + m >= n
     best = None
-    for rep in range(a.repeat):
+    if a.stream_text:
         with ingest.Ingest(0) as g:
             g.set_option(_lib.INGEST_OPT_RESERVE_RECORDS, n)
+            if a.partition_records:
+                g.set_option(_lib.INGEST_OPT_PARTITION_RECORDS, a.partition_records)
+            t0 = time.perf_counter()
+            for t, last in pieces():
+                n_bytes += t.numel()
+                g.append_text(t, last)
+                del t
+            info = g.text_info()
+            wall_text = (time.perf_counter() - t0) * 1e3     # (includes the generator: not a rate of anything)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            g.finish()
+            st, c = g.stats(), g.counts()
+            best = {"total_ms": info["stage_ms"] + info["parse_ms"] + st["finish_ms"], "parse_ms": info["parse_ms"], "stage_ms": info["stage_ms"],
+                    "append_text_wall_ms": wall_text, "finish": st, "info": info, "counts": c, "partitions": g.partitions()}
+            hbm = torch.cuda.mem_get_info()
+            best["hbm_GB_in_use_after_finish"] = round((hbm[1] - hbm[0]) / 1e9, 1)
+    else:
+        for t, last in pieces():
+            texts.append(t)
+            n_bytes += t.numel()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    for rep in range(0 if a.stream_text else a.repeat):
+        with ingest.Ingest(0) as g:
+            g.set_option(_lib.INGEST_OPT_RESERVE_RECORDS, n)
+            if a.partition_records:
+                g.set_option(_lib.INGEST_OPT_PARTITION_RECORDS, a.partition_records)
             t0 = time.perf_counter()
             for k, t in enumerate(texts):
                 g.append_text(t, k == len(texts) - 1)        # one file in len(texts) pieces: lines straddle the pieces
@@ -138,7 +171,7 @@ def from_text(a):
             total_ms = info["stage_ms"] + info["parse_ms"] + st["finish_ms"]
             if best is None or total_ms < best["total_ms"]:
                 best = {"total_ms": total_ms, "parse_ms": info["parse_ms"], "stage_ms": info["stage_ms"], "append_text_wall_ms": wall_text, "finish": st, "info": info,
-                        "counts": c}
+                        "counts": c, "partitions": g.partitions()}
     assert best["info"]["lines"] == n and best["info"]["records"] == n and best["info"]["bad_lines"] == 0
     csr_out = 2.0 * best["counts"]["nnz"] * 8 + 8.0 * (best["counts"]["users"] + best["counts"]["items"] + 2) \
         + 8.0 * (best["counts"]["users"] + best["counts"]["items"])
@@ -151,7 +184,9 @@ def from_text(a):
            "block_copy_ms": best["stage_ms"],
            "append_text_wall_ms": best["append_text_wall_ms"], "finish_ms": best["finish"]["finish_ms"], "lines": n, "text_bytes": n_bytes,
            "bytes_per_line": n_bytes / n, "users": best["counts"]["users"], "items": best["counts"]["items"], "nnz": best["counts"]["nnz"],
-           "full_parser_lines": best["info"]["full_parser_lines"], "data": "synthetic, text resident in HBM",
+           "full_parser_lines": best["info"]["full_parser_lines"],
+           "data": "synthetic, text resident in HBM" + (" piece by piece (generated, appended, dropped: --stream-text)" if a.stream_text else ""),
+           "user_ranges": best["partitions"][0], "item_ranges": best["partitions"][1], "hbm_GB_in_use_after_finish": best.get("hbm_GB_in_use_after_finish"),
            "roofline": {"bound": "hbm", "what": "end to end: text bytes in + both CSR matrices and id tables out",
                         "achieved": (n_bytes + csr_out) / best["total_ms"] / 1e6, "peak": 8000.0, "unit": "GB/s",
                         "frac": (n_bytes + csr_out) / best["total_ms"] / 1e6 / 8000.0, "algorithmic_bytes": n_bytes + csr_out},

@@ -81,6 +81,40 @@ def main():
                            "at_one_pass_per_call": out["batches"][str(per_pass)]["Y_stream_frac"],
                            "best_over_queries_per_pass": {"frac": best["Y_stream_frac"], "queries_per_s": best["queries_per_s"],
                                                           "queries_per_pass": [int(kk) for kk, v in out["by_queries_per_pass"].items() if v is best][0]}}
+        # ---- the way the reference is entered: request threads, one user per call (ServerRecommender.java:359-441) ----------
+        # native threads (tools/topn_callers.cpp) on ONE handle; the library folds the concurrent calls into passes
+        import ctypes
+        harness = os.path.join(ROOT, "tools", "libtopn_callers.so")
+        if os.path.exists(harness):
+            H = ctypes.CDLL(harness)
+            H.topn_callers_run.restype = ctypes.c_int
+            H.topn_callers_run.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint64,
+                                           ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
+            out["callers"] = {}
+
+            def run_callers(n_threads, calls):
+                lat = np.zeros(n_threads * calls, dtype=np.float64)
+                wall, chk = ctypes.c_double(0.0), ctypes.c_int64(0)
+                before = core.recommend_front_stats()
+                rc = H.topn_callers_run(core._h, n_threads, calls, a.users, a.how_many, 42, lat.ctypes.data_as(ctypes.c_void_p), ctypes.byref(wall),
+                                        ctypes.byref(chk))
+                assert rc == 0, rc
+                st = core.recommend_front_stats()
+                passes = st["passes"] - before["passes"]
+                n = n_threads * calls
+                return {"threads": n_threads, "calls": n, "queries_per_s": n / wall.value, "latency_us": {"p50": float(np.percentile(lat, 50)),
+                        "p99": float(np.percentile(lat, 99)), "mean": float(lat.mean())}, "passes": passes, "queries_per_pass": n / max(passes, 1),
+                        "us_per_pass": wall.value * 1e6 / max(passes, 1), "Y_stream_frac": passes * a.items * k * 4 / wall.value / 8e12}
+            for depth in (1, 2, 3):
+                core.recommend_set_depth(depth)
+                run_callers(8, 50)                                      # warm
+                out["callers"]["depth_%d" % depth] = {str(nt): run_callers(nt, 4000 if nt > 1 else 2000) for nt in (1, 8, 32, 128)}
+            core.recommend_set_depth(2)
+            c32 = out["callers"]["depth_2"]["32"]
+            out["roofline_callers"] = {"bound": "hbm", "achieved": c32["Y_stream_frac"] * 8000.0, "peak": 8000.0, "unit": "GB/s", "frac": c32["Y_stream_frac"],
+                                       "what": "32 native threads of one-user calls on one handle, 2 passes in flight: reads of Y (items * 4k bytes per "
+                                               "coalesced pass) per second of wall time", "queries_per_s": c32["queries_per_s"],
+                                       "latency_us": c32["latency_us"], "queries_per_pass": c32["queries_per_pass"]}
     if not a.no_cpu_baseline:
         from oracle import topn_oracle as to
         t0 = time.perf_counter()
