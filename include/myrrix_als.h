@@ -335,6 +335,9 @@ int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, in
  * out4 = {calls, queries, coalesced passes, exclusive calls} since mals_create. */
 int mals_recommend_front_stats(mals_handle h, int64_t* out4);
 int mals_recommend_set_depth(mals_handle h, int32_t passes_in_flight);   /* 1..6; not while calls are in flight */
+/* How long a caller whose call is in somebody else's pass polls for its answer before it blocks on a condition variable
+ * (default 0: block at once; a process with cores to spare trades them for wake-up latency). */
+int mals_recommend_set_spin_us(mals_handle h, int32_t spin_us);
 /* userTagIDs (RecommendIterator.java:72 -- "if (userTagIDs.contains(itemID)) return null"; likewise MostSimilarItemIterator
  * .java:77): rows of Y that stand for tags of users (InputFilesReader.java:159-165) are never recommended, to anybody, by
  * any mals_recommend* call.  item_idx: n dense item indices (host or device; entries outside [0, rows of Y) are ignored:
@@ -442,7 +445,7 @@ int mals_ingest_partitions(mals_ingest g, int32_t* user_ranges, int32_t* item_ra
  * otherwise) */
 /* PARTITION_RECORDS: most records ONE sort pipeline is given (52 bytes of workspace each); an ingest with more is finished
  * user-id range by user-id range (csrc/ingest_big_host.h: same result, bit for bit).  0 = the default: one pipeline up to
- * 2^31 - 256 records, ranges of 2^29 beyond -- which is how C5's 5e9 lines fit one 288 GB device next to their 120 GB of
+ * 2^31 - 256 records, ranges of 2^28 beyond -- which is how C5's 5e9 lines fit one 288 GB device next to their 120 GB of
  * records.  (Tests set a few hundred to run the oracle suites through the partitioned path.) */
 enum { MALS_INGEST_OPT_KNOWN_ITEMS = 1, MALS_INGEST_OPT_TEXT_BLOCK_BYTES = 2, MALS_INGEST_OPT_RESERVE_RECORDS = 3, MALS_INGEST_OPT_PARTITION_RECORDS = 4 };
 enum { MALS_ITEM_TAG_IDS = 0, MALS_USER_TAG_IDS = 1 };

@@ -151,6 +151,7 @@ SYMBOLS = {
     "mals_features": (ctypes.c_int, [_H]),
     "mals_recommend_front_stats": (ctypes.c_int, [_H, _P]),
     "mals_recommend_set_depth": (ctypes.c_int, [_H, _I32]),
+    "mals_recommend_set_spin_us": (ctypes.c_int, [_H, _I32]),
     "mals_set_tag_items": (ctypes.c_int, [_H, _I64, _P, ctypes.c_int]),
     "mals_get_tag_item_count": (ctypes.c_int, [_H, ctypes.POINTER(_I64)]),
     "mals_ingest_device": (ctypes.c_int, [_H, ctypes.POINTER(_I32)]),

@@ -385,6 +385,9 @@ class ALSCore:
     def recommend_set_depth(self, passes_in_flight):
         self._chk(self._L.mals_recommend_set_depth(self._h, int(passes_in_flight)))
 
+    def recommend_set_spin_us(self, spin_us):
+        self._chk(self._L.mals_recommend_set_spin_us(self._h, int(spin_us)))
+
     def recommend_to_many(self, queries, how_many, exclude=None):
         """recommendToMany (ServerRecommender.java:366-441): queries = list of (n_j x features) arrays, one per query; the
         score of an item is the mean of its dots with the query's vectors (RecommendIterator.java:93-104)."""

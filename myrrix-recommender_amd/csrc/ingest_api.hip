@@ -21,7 +21,7 @@ using namespace mals;
 
 constexpr int64_t MALS_INGEST_MAX_RECORDS = (int64_t)1 << 36;       // (the record arrays alone are 1.6 TB there)
 constexpr int64_t MALS_INGEST_ONE_SHOT_MAX = (int64_t)0x7fffff00;   // what one sort pipeline holds (32-bit positions)
-constexpr int64_t MALS_INGEST_DEFAULT_PART = (int64_t)1 << 29;      // records per user range beyond that (ingest_big_host.h)
+constexpr int64_t MALS_INGEST_DEFAULT_PART = (int64_t)1 << 28;      // records per user range beyond that (ingest_big_host.h)
 
 struct mals_ingest_s {
   int device = 0;

@@ -50,11 +50,31 @@ __global__ __launch_bounds__(256) void big_part_histogram_kernel(const uint8_t* 
   if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 // tile_counts[t] = records of range p in tile t
-__global__ __launch_bounds__(256) void big_count_part_kernel(const uint8_t* __restrict__ part, int64_t n, uint8_t p, unsigned* __restrict__ tile_counts) {
-  const int64_t b = (int64_t)blockIdx.x * BIG_TILE + threadIdx.x * 8;
+// (a thread's 8 range bytes are ONE 8-byte load -- the array is padded past n --, a thread's 8 columns two 16-byte loads:
+// eight strided 1- or 4-byte loads per thread ran these kernels at 0.2-0.9 TB/s)
+__device__ __forceinline__ unsigned big_match8(const uint8_t* __restrict__ part, int64_t b, int64_t n, uint8_t p, bool (&m)[8]) {
+  const uint64_t w = b < n ? *reinterpret_cast<const uint64_t*>(part + b) : 0ull;
   unsigned c = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) c += (b + j < n && part[b + j] == p) ? 1u : 0u;
+  for (int j = 0; j < 8; ++j) {
+    m[j] = b + j < n && (uint8_t)(w >> (8 * j)) == p;
+    c += m[j] ? 1u : 0u;
+  }
+  return c;
+}
+__device__ __forceinline__ void big_load8(const int32_t* __restrict__ col, int64_t e, int64_t nnz, int32_t (&c)[8]) {
+  if (e + 8 <= nnz) {
+    const int4 lo = *reinterpret_cast<const int4*>(col + e), hi = *reinterpret_cast<const int4*>(col + e + 4);
+    c[0] = lo.x, c[1] = lo.y, c[2] = lo.z, c[3] = lo.w, c[4] = hi.x, c[5] = hi.y, c[6] = hi.z, c[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = e + j < nnz ? col[e + j] : -1;
+  }
+}
+__global__ __launch_bounds__(256) void big_count_part_kernel(const uint8_t* __restrict__ part, int64_t n, uint8_t p, unsigned* __restrict__ tile_counts) {
+  const int64_t b = (int64_t)blockIdx.x * BIG_TILE + threadIdx.x * 8;
+  bool m[8];
+  const unsigned c = big_match8(part, b, n, p, m);
   unsigned total;
   block_exclusive_scan(c, &total);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
@@ -66,12 +86,7 @@ __global__ __launch_bounds__(256) void big_compact_part_kernel(const uint8_t* __
                                                                int64_t* __restrict__ pu, int64_t* __restrict__ pi, float* __restrict__ pv) {
   const int64_t b = (int64_t)blockIdx.x * BIG_TILE + threadIdx.x * 8;
   bool m[8];
-  unsigned c = 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    m[j] = b + j < n && part[b + j] == p;
-    c += m[j] ? 1u : 0u;
-  }
+  const unsigned c = big_match8(part, b, n, p, m);
   unsigned pos = tile_offsets[blockIdx.x] + block_exclusive_scan(c, nullptr);
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -151,8 +166,12 @@ __global__ void big_remap_kernel(int32_t* __restrict__ col, int64_t n, const int
   MALS_GRID_STRIDE(i, n) col[i] = final_map[col[i]];
 }
 // ---- R^T ------------------------------------------------------------------------------------------------------------------
-__global__ void big_item_count_kernel(const int32_t* __restrict__ col, int64_t nnz, unsigned* __restrict__ cnt) {
-  MALS_GRID_STRIDE(i, nnz) atomicAdd(&cnt[col[i]], 1u);
+// entries per item, from every `stride`-th entry: the item ranges of R^T are CUT by this estimate (an exact count of all
+// entries is 5e9 atomics, a fifth of them on a few thousand popular items: 324 ms at 2.5e9 entries, a quarter of the whole
+// finish); what a range really holds is counted exactly when it is selected, and R^T's offsets come out of the sorted ranges
+__global__ void big_item_sample_kernel(const int32_t* __restrict__ col, int64_t nnz, int64_t stride, unsigned* __restrict__ cnt) {
+  const int64_t n_s = (nnz + stride - 1) / stride;
+  MALS_GRID_STRIDE(i, n_s) atomicAdd(&cnt[col[i * stride]], 1u);
 }
 // exclusive scan uint32 -> int64 offsets (out has n + 1 entries): tile sums, one block over them, apply
 __global__ __launch_bounds__(256) void big_scan64_reduce_kernel(const unsigned* __restrict__ in, int64_t n, unsigned long long* __restrict__ tile_sums) {
@@ -198,9 +217,11 @@ __global__ __launch_bounds__(256) void big_scan64_apply_kernel(const unsigned* _
 __global__ __launch_bounds__(256) void big_count_items_kernel(const int32_t* __restrict__ col, int64_t nnz, int32_t a, int32_t b,
                                                               unsigned* __restrict__ tile_counts) {
   const int64_t e = (int64_t)blockIdx.x * BIG_TILE + threadIdx.x * 8;
+  int32_t cc[8];
+  big_load8(col, e, nnz, cc);
   unsigned c = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) c += (e + j < nnz && col[e + j] >= a && col[e + j] < b) ? 1u : 0u;
+  for (int j = 0; j < 8; ++j) c += (cc[j] >= a && cc[j] < b) ? 1u : 0u;
   unsigned total;
   block_exclusive_scan(c, &total);
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
@@ -213,26 +234,28 @@ __device__ __forceinline__ int64_t big_row_of(const int64_t* __restrict__ row_pt
   }
   return lo;
 }
+// tile_row[t] = the row of the first entry of entry tile t (tile_row[n_tiles] = the last row): once per finish, one thread per
+// tile.  (Searched inside big_select_items_kernel by one thread per workgroup it was 50 dependent loads in front of a
+// barrier, per tile and per item range: 20 ms per range at 2.5e9 entries, a third of the finish.)
+__global__ void big_tile_rows_kernel(const int64_t* __restrict__ row_ptr, int64_t n_rows, int64_t nnz, int64_t n_tiles, int32_t* __restrict__ tile_row) {
+  MALS_GRID_STRIDE(t, n_tiles + 1)
+    tile_row[t] = (t == n_tiles || t * BIG_TILE >= nnz) ? (int32_t)(n_rows - 1) : (int32_t)big_row_of(row_ptr, 0, n_rows - 1, t * BIG_TILE);
+}
 // the selected entries, in (user, item) order, as sort keys ((item - a) << 32 | user) with the value bits as payload
 __global__ __launch_bounds__(256) void big_select_items_kernel(const int32_t* __restrict__ col, const float* __restrict__ val, int64_t nnz,
-                                                               const int64_t* __restrict__ row_ptr, int64_t n_rows, int32_t a, int32_t b,
+                                                               const int64_t* __restrict__ row_ptr, const int32_t* __restrict__ tile_row, int32_t a, int32_t b,
                                                                const unsigned* __restrict__ tile_offsets, uint64_t* __restrict__ keys,
                                                                unsigned* __restrict__ pay) {
-  __shared__ int64_t s_lo, s_hi;
   const int64_t e0 = (int64_t)blockIdx.x * BIG_TILE;
-  if (threadIdx.x == 0) {
-    const int64_t last = e0 + BIG_TILE - 1 < nnz - 1 ? e0 + BIG_TILE - 1 : nnz - 1;
-    s_lo = big_row_of(row_ptr, 0, n_rows - 1, e0);
-    s_hi = big_row_of(row_ptr, s_lo, n_rows - 1, last);
-  }
-  __syncthreads();
-  const int64_t r_lo = s_lo, r_hi = s_hi;
+  const int64_t r_lo = tile_row[blockIdx.x], r_hi = tile_row[blockIdx.x + 1];
   const int64_t e = e0 + threadIdx.x * 8;
+  int32_t cc[8];
+  big_load8(col, e, nnz, cc);
   bool m[8];
   unsigned c = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    m[j] = e + j < nnz && col[e + j] >= a && col[e + j] < b;
+    m[j] = cc[j] >= a && cc[j] < b;   // (entries past nnz read as -1: outside every range)
     c += m[j] ? 1u : 0u;
   }
   unsigned pos = tile_offsets[blockIdx.x] + block_exclusive_scan(c, nullptr);
@@ -242,17 +265,21 @@ __global__ __launch_bounds__(256) void big_select_items_kernel(const int32_t* __
     if (m[j]) {
       // (a thread's 8 entries are consecutive: the row only moves forward)
       if (row < 0 || row_ptr[row + 1] <= e + j) row = big_row_of(row_ptr, row < 0 ? r_lo : row, r_hi, e + j);
-      keys[pos] = ((uint64_t)(uint32_t)(col[e + j] - a) << 32) | (uint32_t)row;
+      keys[pos] = ((uint64_t)(uint32_t)(cc[j] - a) << 32) | (uint32_t)row;
       pay[pos] = __float_as_uint(val[e + j]);
       ++pos;
     }
 }
-__global__ void big_transpose_write_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay, int64_t n, int32_t* __restrict__ t_col,
-                                           float* __restrict__ t_val) {
+__global__ void big_transpose_write_kernel(const uint64_t* __restrict__ keys, const unsigned* __restrict__ pay, int64_t n, int32_t* __restrict__ t_row,
+                                           int32_t* __restrict__ t_col, float* __restrict__ t_val) {
   MALS_GRID_STRIDE(i, n) {
-    t_col[i] = (int32_t)(keys[i] & 0xffffffffu);
+    t_row[i] = (int32_t)(keys[i] >> 32);          // the item, counted from the range's first
+    t_col[i] = (int32_t)(keys[i] & 0xffffffffu);  // the user
     t_val[i] = __uint_as_float(pay[i]);
   }
+}
+__global__ void big_add_base_inplace_kernel(int64_t* __restrict__ p, int64_t n, int64_t base) {
+  MALS_GRID_STRIDE(i, n) p[i] += base;
 }
 
 }  // namespace mals
@@ -281,7 +308,9 @@ struct BigState {
   int64_t n_item_glob = 0;
   unsigned *alive_glob = nullptr, *new_i = nullptr, *cnt = nullptr;
   unsigned long long* sums64 = nullptr;
+  int32_t* tile_row = nullptr;
   ~BigState() {
+    dfree(tile_row);
     for (BigPart& p : parts) {
       dfree(p.item_ids); dfree(p.item_alive); dfree(p.user_ids); dfree(p.ptr_local); dfree(p.known_ptr_local);
     }
@@ -364,6 +393,9 @@ static int finish_big(mals_ingest g, hipEvent_t e0, int64_t part_cap) {
   ICHK(g, hipMalloc(&g->col[0], sizeof(int32_t) * (size_t)n));
   ICHK(g, hipMalloc(&g->val[0], sizeof(float) * (size_t)n));
   if (g->want_known) ICHK(g, hipMalloc(&g->known_idx, sizeof(int32_t) * (size_t)n));
+  // ... and R by item likewise, now: a 20 GB hipMalloc in the middle of the pipeline is a second of host time on some boxes
+  ICHK(g, hipMalloc(&g->col[1], sizeof(int32_t) * (size_t)n));
+  ICHK(g, hipMalloc(&g->val[1], sizeof(float) * (size_t)n));
   g->last_workspace_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ws).count();
   ICHK(g, hipEventRecord(e0, g->stream));
 
@@ -546,49 +578,79 @@ static int finish_big(mals_ingest g, hipEvent_t e0, int64_t part_cap) {
   dfree(B.alive_glob); dfree(B.new_i); dfree(B.item_glob);
 
   // ---- 3. R^T ---------------------------------------------------------------------------------------------------------------
-  ICHK(g, hipMalloc(&g->col[1], sizeof(int32_t) * std::max<size_t>((size_t)nnz, 1)));
-  ICHK(g, hipMalloc(&g->val[1], sizeof(float) * std::max<size_t>((size_t)nnz, 1)));
+  // item ranges from a sample of the entries (every 61st), cut at 0.7 of a partition; a range that turns out larger is halved
   ICHK(g, hipMalloc(&B.cnt, sizeof(unsigned) * ((size_t)n_items + 8)));
   const int64_t tiles64 = (n_items + SC_TILE - 1) / SC_TILE + 1;
   ICHK(g, hipMalloc(&B.sums64, sizeof(unsigned long long) * ((size_t)tiles64 + 1)));
   ICHK(g, hipMemsetAsync(B.cnt, 0, sizeof(unsigned) * ((size_t)n_items + 8), g->stream));
-  if (nnz) hipLaunchKernelGGL(big_item_count_kernel, dim3(blocks_for(nnz, 256, 1 << 16)), dim3(256), 0, g->stream, g->col[0], nnz, B.cnt);
+  const int64_t stride = nnz > ((int64_t)1 << 24) ? 61 : 1;
+  if (nnz) hipLaunchKernelGGL(big_item_sample_kernel, dim3(blocks_for((nnz + stride - 1) / stride, 256, 1 << 16)), dim3(256), 0, g->stream, g->col[0], nnz, stride, B.cnt);
   const unsigned t64 = (unsigned)std::max<int64_t>(1, (n_items + SC_TILE - 1) / SC_TILE);
   hipLaunchKernelGGL(big_scan64_reduce_kernel, dim3(t64), dim3(256), 0, g->stream, B.cnt, n_items, B.sums64);
   hipLaunchKernelGGL(big_scan64_sums_kernel, dim3(1), dim3(64), 0, g->stream, B.sums64, (int64_t)t64, B.sums64 + t64);
   hipLaunchKernelGGL(big_scan64_apply_kernel, dim3(t64), dim3(256), 0, g->stream, B.cnt, n_items, B.sums64, B.sums64 + t64, g->ptr[1]);
   ICHK(g, hipGetLastError());
-  g->bytes_moved += 4.0 * (double)nnz + 16.0 * (double)n_items;
-  std::vector<int64_t> cp((size_t)n_items + 1);
+  g->bytes_moved += 4.0 * (double)nnz / (double)stride + 16.0 * (double)n_items;
+  std::vector<int64_t> cp((size_t)n_items + 1);   // estimated offsets, in sampled entries
   ICHK(g, hipMemcpyAsync(cp.data(), g->ptr[1], sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost, g->stream));
   ICHK(g, hipStreamSynchronize(g->stream));
-  if (cp[(size_t)n_items] != nnz) return fail(g, MALS_HIP_ERROR, "ingest: the item counts do not add up to the entries");
+  std::vector<std::pair<int64_t, int64_t>> todo;   // item ranges still to do, the first on top
+  {
+    const int64_t budget = std::max<int64_t>(1, (int64_t)(0.7 * (double)part_cap / (double)stride));
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    for (int64_t a = 0; a < n_items;) {
+      int64_t b = std::upper_bound(cp.begin() + a + 1, cp.end(), cp[(size_t)a] + budget) - cp.begin() - 1;
+      b = std::min(std::max(b, a + 1), n_items);
+      ranges.emplace_back(a, b);
+      a = b;
+    }
+    todo.assign(ranges.rbegin(), ranges.rend());
+  }
   const unsigned e_tiles = big_tiles(nnz);
-  for (int64_t a = 0; a < n_items;) {
-    // the longest run of items from a whose entries fit a partition
-    int64_t b = std::upper_bound(cp.begin() + a + 1, cp.end(), cp[(size_t)a] + part_cap) - cp.begin() - 1;
-    if (b <= a) return fail(g, MALS_INVALID_ARG, "ingest: the entries of one item do not fit a partition (" + std::to_string(cp[(size_t)a + 1] - cp[(size_t)a]) + ")");
-    b = std::min(b, n_items);
-    const int64_t nq = cp[(size_t)b] - cp[(size_t)a];
-    ++g->last_item_ranges;
-    if (nq > 0) {
+  ICHK(g, hipMalloc(&B.tile_row, sizeof(int32_t) * ((size_t)e_tiles + 1)));
+  hipLaunchKernelGGL(big_tile_rows_kernel, dim3(blocks_for((int64_t)e_tiles + 1)), dim3(256), 0, g->stream, g->ptr[0], std::max<int64_t>(n_users, 1), nnz,
+                     (int64_t)e_tiles, B.tile_row);
+  ICHK(g, hipGetLastError());
+  int64_t done_entries = 0;   // R^T's offsets so far: every range starts where the one before it ended
+  ICHK(g, hipMemsetAsync(g->ptr[1], 0, sizeof(int64_t) * ((size_t)n_items + 1), g->stream));
+  while (!todo.empty()) {
+    const int64_t a = todo.back().first, b = todo.back().second;
+    todo.pop_back();
+    int64_t nq = 0;
+    if (nnz > 0) {
       hipLaunchKernelGGL(big_count_items_kernel, dim3(e_tiles), dim3(256), 0, g->stream, g->col[0], nnz, (int32_t)a, (int32_t)b, t.head);
       ICHK(g, hipGetLastError());
       unsigned counted = 0;
       if (int rc = scan_u32(g, s, t.head, t.head, (int64_t)e_tiles, &counted)) return rc;
-      if ((int64_t)counted != nq) return fail(g, MALS_HIP_ERROR, "ingest: item range size mismatch");
-      hipLaunchKernelGGL(big_select_items_kernel, dim3(e_tiles), dim3(256), 0, g->stream, g->col[0], g->val[0], nnz, g->ptr[0], n_users, (int32_t)a, (int32_t)b,
+      nq = counted;
+      g->bytes_moved += 4.0 * (double)nnz;
+    }
+    if (nq > part_cap) {   // the sample underestimated it: two halves (a single item that does not fit is refused)
+      if (b - a < 2) return fail(g, MALS_INVALID_ARG, "ingest: the entries of one item do not fit a partition (" + std::to_string(nq) + ")");
+      const int64_t mid = a + (b - a) / 2;
+      todo.emplace_back(mid, b);
+      todo.emplace_back(a, mid);
+      continue;
+    }
+    ++g->last_item_ranges;
+    if (nq > 0) {
+      hipLaunchKernelGGL(big_select_items_kernel, dim3(e_tiles), dim3(256), 0, g->stream, g->col[0], g->val[0], nnz, g->ptr[0], B.tile_row, (int32_t)a, (int32_t)b,
                          t.head, s.keys[0], s.pay[0]);
       ICHK(g, hipGetLastError());
       int r2 = 0;
       if (int rc = radix_sort<uint64_t, unsigned>(g, s, s.keys, s.pay, nq, &r2, 4, ((uint64_t)(b - a - 1) << 32) | 0xffffffffull)) return rc;
-      hipLaunchKernelGGL(big_transpose_write_kernel, dim3(blocks_for(nq)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], nq, g->col[1] + cp[(size_t)a],
-                         g->val[1] + cp[(size_t)a]);
+      hipLaunchKernelGGL(big_transpose_write_kernel, dim3(blocks_for(nq)), dim3(256), 0, g->stream, s.keys[r2], s.pay[r2], nq, t.coo_row, g->col[1] + done_entries,
+                         g->val[1] + done_entries);
       ICHK(g, hipGetLastError());
-      g->bytes_moved += 8.0 * (double)nnz + 36.0 * (double)nq;
+      g->bytes_moved += 4.0 * (double)nnz + 40.0 * (double)nq;
     }
-    a = b;
+    // offsets of the range's items: local from the sorted item column, then shifted behind the ranges before it
+    hipLaunchKernelGGL(row_ptr_from_sorted_kernel, dim3(blocks_for(nq + 1)), dim3(256), 0, g->stream, t.coo_row, nq, b - a, g->ptr[1] + a);
+    hipLaunchKernelGGL(big_add_base_inplace_kernel, dim3(blocks_for(b - a + 1)), dim3(256), 0, g->stream, g->ptr[1] + a, b - a + 1, done_entries);
+    ICHK(g, hipGetLastError());
+    done_entries += nq;
   }
+  if (done_entries != nnz) return fail(g, MALS_HIP_ERROR, "ingest: the item ranges do not add up to the entries");
   // ---- 4. tag id sets, userTagIDs as rows of R^T ----------------------------------------------------------------------------
   if (int rc = finish_tags(g, s, t, std::max<int64_t>(part_cap, n_sample))) return rc;
   ICHK(g, hipStreamSynchronize(g->stream));

@@ -2652,6 +2652,14 @@ int mals_recommend_front_stats(mals_handle h, int64_t* out4) {
   return MALS_OK;
 }
 
+int mals_recommend_set_spin_us(mals_handle h, int32_t spin_us) {
+  if (!h || spin_us < 0 || spin_us > 1000000) return MALS_INVALID_ARG;
+  TopnFront* f = topn_front(h);
+  std::lock_guard<std::mutex> lk(f->mu);
+  f->spin_us = spin_us;
+  return MALS_OK;
+}
+
 int mals_recommend_set_depth(mals_handle h, int32_t passes_in_flight) {
   if (!h || passes_in_flight < 1 || passes_in_flight > TOPN_SLOTS) return MALS_INVALID_ARG;
   TopnFront* f = topn_front(h);

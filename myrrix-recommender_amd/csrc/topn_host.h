@@ -670,7 +670,8 @@ struct TopnFront {
   bool busy[TOPN_SLOTS] = {};
   int n_busy = 0, next_slot = 0, oldest = 0;
   int depth = 2;
-  int spin_us = 300;   // how long a waiting caller polls before it blocks (MALS_TOPN_FRONT_SPIN_US at mals_create)
+  int spin_us = 0;     // how long a waiting caller polls before it blocks (mals_recommend_set_spin_us; MALS_TOPN_FRONT_SPIN_US at
+                       // mals_create).  0: block at once -- polling callers compete with the HIP runtime's own threads for cores
   std::vector<uint8_t> failed;
   // counters (mals_recommend_front_stats)
   uint64_t calls = 0, queries = 0, passes = 0, bulk_calls = 0;

@@ -396,7 +396,11 @@ __global__ __launch_bounds__(256, 2) void topn_stream_kernel(const float* __rest
     if (n_hits > (unsigned)wave_cap) {
       if (lane == 0) atomicAdd(overflow, 1u);   // whose hits are missing is not known: the whole pass falls back
     } else if (n_hits) {
-      __threadfence();   // the list was written by this wave's own lanes: stores before the loads of other lanes
+      // the list was written by this wave's own lanes: their stores before the other lanes' loads.  WORKGROUP scope: the wave
+      // only waits for its own stores (the lines were never read on this CU: nothing stale to hit).  An agent-scope fence
+      // here writes back and invalidates the XCD's whole L2 once per wave -- 2048 times per pass: measured, a pass of 240
+      // queries went from 86 to 232 us with every streaming kernel beside it losing its cache.
+      __threadfence_block();
       for (unsigned i = lane; i < n_hits; i += 64) {
         const uint2 hq = my_hits[i];
         const unsigned pos = atomicAdd(&count[(size_t)hq.y * TOPN_COUNT_STRIDE], 1u);

@@ -234,6 +234,8 @@ def test_bench_line_on_one_gpu_says_what_it_leaves_out():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1.2 and rf["peak"] == 8000.0
     assert r32["ms_per_step"] > 0 and 0 < r32["frac"] < 1.2 and "fp32" in r32["workload"]
     assert r32["nnz"] == d["config"]["nnz"]                      # the same problem, another arithmetic
+    r24 = d["roofline_split24"]                                  # ... and the three-term f16 split in between (k = 64)
+    assert r24["ms_per_step"] > 0 and 0 < r24["frac"] < 1.2 and "split3_f16" in r24["workload"] and r24["nnz"] == d["config"]["nnz"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "rows/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["cpu_model"]
     assert "work units of 100 rows per thread" in cb["sample"]

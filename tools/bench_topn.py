@@ -110,6 +110,12 @@ def main():
                 run_callers(8, 50)                                      # warm
                 out["callers"]["depth_%d" % depth] = {str(nt): run_callers(nt, 4000 if nt > 1 else 2000) for nt in (1, 8, 32, 128)}
             core.recommend_set_depth(2)
+            # waiting callers that poll for their answer before they block (mals_recommend_set_spin_us)
+            out["callers_by_spin_us"] = {}
+            for spin in (0, 50, 300):
+                core.recommend_set_spin_us(spin)
+                out["callers_by_spin_us"][str(spin)] = {str(nt): run_callers(nt, 4000) for nt in (8, 32, 128)}
+            core.recommend_set_spin_us(0)
             c32 = out["callers"]["depth_2"]["32"]
             out["roofline_callers"] = {"bound": "hbm", "achieved": c32["Y_stream_frac"] * 8000.0, "peak": 8000.0, "unit": "GB/s", "frac": c32["Y_stream_frac"],
                                        "what": "32 native threads of one-user calls on one handle, 2 passes in flight: reads of Y (items * 4k bytes per "
