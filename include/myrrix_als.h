@@ -445,8 +445,9 @@ int mals_ingest_partitions(mals_ingest g, int32_t* user_ranges, int32_t* item_ra
  * otherwise) */
 /* PARTITION_RECORDS: most records ONE sort pipeline is given (52 bytes of workspace each); an ingest with more is finished
  * user-id range by user-id range (csrc/ingest_big_host.h: same result, bit for bit).  0 = the default: one pipeline up to
- * 2^31 - 256 records, ranges of 2^28 beyond -- which is how C5's 5e9 lines fit one 288 GB device next to their 120 GB of
- * records.  (Tests set a few hundred to run the oracle suites through the partitioned path.) */
+ * 2^31 - 256 records; beyond, ranges as large as 70 % of the device's free memory hold at 76 bytes per record (at least
+ * 2^26) -- which is how C5's 5e9 lines fit one 288 GB device next to their 120 GB of records.  (Tests set a few hundred
+ * to run the oracle suites through the partitioned path.) */
 enum { MALS_INGEST_OPT_KNOWN_ITEMS = 1, MALS_INGEST_OPT_TEXT_BLOCK_BYTES = 2, MALS_INGEST_OPT_RESERVE_RECORDS = 3, MALS_INGEST_OPT_PARTITION_RECORDS = 4 };
 enum { MALS_ITEM_TAG_IDS = 0, MALS_USER_TAG_IDS = 1 };
 int mals_ingest_set_option(mals_ingest g, int32_t option, int64_t value);
@@ -636,6 +637,13 @@ int mals_group_pending_entries(mals_group g, int side, int64_t n_rows, int64_t* 
  * on that device) and the ingest -- its records and its 52 bytes per record of workspace -- can be destroyed right away. */
 enum { MALS_INSTALL_COPY = 1 };
 int mals_ingest_install_group(mals_ingest g, mals_group grp, int32_t flags);
+/* ServerRecommender.recommend for model users on a group (arguments as mals_recommend): every member holds complete replicas
+ * of X and Y but only ITS users' rows of R / knownItemIDs, so a query is answered by the local member whose slice holds the
+ * user's row (consider_known_items: by any local member).  Callable from any number of request threads like mals_recommend:
+ * it only reads the group and enters the members' serving fronts.  MALS_INVALID_ARG for a user whose owner is a rank of
+ * another process (a one-process-per-GPU deployment routes the request to that process). */
+int mals_group_recommend(mals_group g, const int64_t* user_idx, int32_t n_queries, int32_t how_many, int32_t consider_known_items,
+                         int64_t* item_idx_out, float* score_out, int32_t* n_out);
 /* slice bounds of a side after its matrix was set: bounds_out[world+1] */
 int mals_group_bounds(mals_group g, int side, int64_t* bounds_out);
 

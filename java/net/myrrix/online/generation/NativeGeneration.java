@@ -48,6 +48,7 @@ public final class NativeGeneration implements AutoCloseable {
   private static native int nativeIngestCsr(long ingest, int side, long[] rowPtr, int[] colIdx, float[] val);
   private static native int nativeIngestKnownItems(long ingest, long[] ptr, int[] itemIdx);
   private static native int nativeIngestInstall(long ingest, long handle);
+  private static native int nativeIngestInstallGroup(long ingest, long group, int flags);
   private static native long nativeGroupHandle(long group, int member);
   private static native int nativeSetKnownItems(long handle, long[] rowPtr, int[] itemIdx);
   private static native int nativeRecommend(long handle, long[] userIdx, int howMany, boolean considerKnownItems,
@@ -55,6 +56,19 @@ public final class NativeGeneration implements AutoCloseable {
   private static native int nativeRecommendToMany(long handle, float[] vectors, long[] vectorPtr, int nQueries, int howMany,
                                                   long[] excludePtr, long[] excludeIdx, long[] items, float[] scores, int[] counts);
   private static native String nativeLastError(long handle);
+
+  /** The reference's own six arguments (InputFilesReader.java:64-69; call site DelegateGenerationManager.java:336): a switch by
+   *  class name only.  The device is the first of -Dmodel.als.gpus (default 0). */
+  public static NativeGeneration readInputFiles(FastByIDMap<FastIDSet> knownItemIDs,
+                                                FastByIDMap<FastByIDFloatMap> rbyRow,
+                                                FastByIDMap<FastByIDFloatMap> rbyColumn,
+                                                FastIDSet itemTagIDs,
+                                                FastIDSet userTagIDs,
+                                                File inputDir) throws IOException {
+    String gpus = System.getProperty("model.als.gpus", "0");
+    int device = Integer.parseInt(gpus.split(",")[0].trim());
+    return readInputFiles(knownItemIDs, rbyRow, rbyColumn, itemTagIDs, userTagIDs, inputDir, device);
+  }
 
   /** InputFilesReader.readInputFiles (IFR:64-211) with the work on device `device`; the object keeps the matrices in HBM
    *  until close() so that install() can hand them to a factorizer without a round trip. */
@@ -79,9 +93,15 @@ public final class NativeGeneration implements AutoCloseable {
       }
       long[] info = new long[8];   // lines, badLines, headerLines, skippedLines, records, users, items, nnz
       check(g.ingest, nativeReadInputDir(g.ingest, wide, info));   // "Too many bad lines" (IFR:96-98) arrives here
+      // Java arrays end at 2^31 - 1 elements: an input with more users, items or entries than that cannot become the reference's
+      // maps here (nor could the reference hold it) -- such inputs go to the factorizer with install() / installGroup() instead
+      if (info[5] > Integer.MAX_VALUE || info[6] > Integer.MAX_VALUE || info[7] > Integer.MAX_VALUE) {
+        throw new IOException("input too large for Java maps (" + info[5] + " users, " + info[6] + " items, " + info[7]
+            + " entries): read it with NativeGeneration.readInputFiles(inputDir, device) and install() it");
+      }
       int nUsers = (int) info[5];
       int nItems = (int) info[6];
-      int nnz = (int) info[7];      // beyond 2^31 entries skip the maps: install() is the path for such inputs
+      int nnz = (int) info[7];
       g.userIDs = new long[nUsers];
       g.itemIDs = new long[nItems];
       check(g.ingest, nativeIngestIds(g.ingest, 0, g.userIDs));
@@ -90,6 +110,9 @@ public final class NativeGeneration implements AutoCloseable {
       fill(g, 1, nItems, nnz, g.itemIDs, g.userIDs, rbyColumn);
       long[] sizes = new long[3];
       check(g.ingest, nativeIngestSetSizes(g.ingest, sizes));
+      if (sizes[0] > Integer.MAX_VALUE || sizes[1] > Integer.MAX_VALUE || sizes[2] > Integer.MAX_VALUE) {
+        throw new IOException("input too large for Java sets (" + sizes[0] + " / " + sizes[1] + " tag ids, " + sizes[2] + " known items)");
+      }
       addAll(g.ingest, 0, (int) sizes[0], itemTagIDs);
       addAll(g.ingest, 1, (int) sizes[1], userTagIDs);
       if (knownItemIDs != null && sizes[2] >= 0) {
@@ -149,6 +172,13 @@ public final class NativeGeneration implements AutoCloseable {
    *  (mals_ingest_install); the handle borrows them: keep this object open while it factorizes and serves. */
   public void install(long handle) throws IOException {
     check(ingest, nativeIngestInstall(ingest, handle));
+  }
+
+  /** The same for a multi-GPU factorizer (mals_ingest_install_group): both matrices cut at the group's cost-balanced bounds, every
+   *  member its slices device to device, its users' knownItemIDs and the userTagIDs mask.  copy = true: the members own copies
+   *  and this object may be closed right away; false: members on this object's device borrow, keep it open. */
+  public void installGroup(long group, boolean copy) throws IOException {
+    check(ingest, nativeIngestInstallGroup(ingest, group, copy ? 1 : 0));
   }
 
   public long[] getUserIDs() {

@@ -185,6 +185,13 @@ JNIEXPORT jint JNICALL JNI_FN(nativeIngestInstall)(JNIEnv* env, jclass cls, jlon
   return mals_ingest_install(as_ingest(g), as_handle(handle));
 }
 
+/* ... or to every member of a factorizer group, cut at its bounds, device to device (mals_ingest_install_group; flags:
+ * MALS_INSTALL_COPY = the members own copies and the ingest may be closed) */
+JNIEXPORT jint JNICALL JNI_FN(nativeIngestInstallGroup)(JNIEnv* env, jclass cls, jlong g, jlong group, jint flags) {
+  (void)env; (void)cls;
+  return mals_ingest_install_group(as_ingest(g), (mals_group)(intptr_t)group, (int32_t)flags);
+}
+
 /* ---- top-N (ServerRecommender.java:366-508, RecommendIterator.java:62-109, TopN.java:49-128) ------------------------- */
 
 /* the single-GPU handle of member `member` of a factorizer group (HipAlternatingLeastSquares keeps the group): its factors and

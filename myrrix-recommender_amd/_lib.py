@@ -205,6 +205,7 @@ SYMBOLS = {
     "mals_group_append_rows": (ctypes.c_int, [_H, ctypes.c_int, _I64, _P, _P]),
     "mals_group_end_matrix": (ctypes.c_int, [_H, ctypes.c_int]),
     "mals_group_bounds": (ctypes.c_int, [_H, ctypes.c_int, _P]),
+    "mals_group_recommend": (ctypes.c_int, [_H, _P, _I32, _I32, _I32, _P, _P, _P]),
     "mals_group_half_iteration": (ctypes.c_int, [_H, ctypes.c_int]),
     "mals_group_factorize": (ctypes.c_int, [_H, ctypes.c_double, _I32, _I32, _I32, _P, _I32, _P, _I32,
                                             ctypes.POINTER(_I32), ctypes.POINTER(ctypes.c_double)]),

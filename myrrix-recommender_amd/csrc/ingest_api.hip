@@ -21,7 +21,7 @@ using namespace mals;
 
 constexpr int64_t MALS_INGEST_MAX_RECORDS = (int64_t)1 << 36;       // (the record arrays alone are 1.6 TB there)
 constexpr int64_t MALS_INGEST_ONE_SHOT_MAX = (int64_t)0x7fffff00;   // what one sort pipeline holds (32-bit positions)
-constexpr int64_t MALS_INGEST_DEFAULT_PART = (int64_t)1 << 28;      // records per user range beyond that (ingest_big_host.h)
+constexpr int64_t MALS_INGEST_MIN_PART = (int64_t)1 << 26;          // smallest user range the automatic choice makes (ingest_big_host.h)
 
 struct mals_ingest_s {
   int device = 0;
@@ -465,7 +465,7 @@ static int finish_impl(mals_ingest g, hipEvent_t e0) {
   }
   // more records than one sort pipeline holds (or than the caller wants it to hold): user range by user range
   if (n > MALS_INGEST_ONE_SHOT_MAX || (g->part_cap > 0 && n > g->part_cap))
-    return finish_big(g, e0, g->part_cap > 0 ? g->part_cap : MALS_INGEST_DEFAULT_PART);
+    return finish_big(g, e0, g->part_cap);   // 0: ranges as large as the free memory holds
   FinishTmp t;
   Scratch s;
   unsigned n_u_all = 0, n_i_all = 0, n_users = 0, n_items = 0, nnz = 0;

@@ -372,6 +372,7 @@ std::vector<int64_t> big_pick_splitters(const std::vector<int64_t>& sample, int 
 static int setup_workspace(mals_ingest g, Scratch& s, FinishTmp& t, int64_t n, int64_t scan_extra);
 static int finish_tags(mals_ingest g, Scratch& s, FinishTmp& t, int64_t sort_cap);
 
+// part_cap = 0: as many records per range as the device's free memory holds (fewer ranges = fewer sweeps over the records)
 static int finish_big(mals_ingest g, hipEvent_t e0, int64_t part_cap) {
   using namespace mals;
   const int64_t n = g->n;
@@ -381,21 +382,34 @@ static int finish_big(mals_ingest g, hipEvent_t e0, int64_t part_cap) {
   Scratch s;
   FinishTmp t;
   const auto t_ws = std::chrono::steady_clock::now();
-  // the workspace of one partition; the scans over all records run on tiles of 2048 (one count per tile) and the dense item
-  // index is a scan over at most 2^31 items: both inside the same tile-sum buffer
-  if (int rc = setup_workspace(g, s, t, std::max<int64_t>(part_cap, n_sample), std::max<int64_t>((n + BIG_TILE - 1) / BIG_TILE, (int64_t)1 << 31))) return rc;
-  ICHK(g, hipMalloc(&B.part, (size_t)n + 8));
-  ICHK(g, hipMalloc(&B.pu, sizeof(int64_t) * (size_t)part_cap));
-  ICHK(g, hipMalloc(&B.pi, sizeof(int64_t) * (size_t)part_cap));
-  ICHK(g, hipMalloc(&B.pv, sizeof(float) * (size_t)part_cap));
-  ICHK(g, hipMalloc(&B.d_split, sizeof(int64_t) * 256));
   // results that are filled range by range: R by user with room for every record (entries <= records), knownItemIDs likewise
+  ICHK(g, hipMalloc(&B.part, (size_t)n + 8));
+  ICHK(g, hipMalloc(&B.d_split, sizeof(int64_t) * 256));
   ICHK(g, hipMalloc(&g->col[0], sizeof(int32_t) * (size_t)n));
   ICHK(g, hipMalloc(&g->val[0], sizeof(float) * (size_t)n));
   if (g->want_known) ICHK(g, hipMalloc(&g->known_idx, sizeof(int32_t) * (size_t)n));
   // ... and R by item likewise, now: a 20 GB hipMalloc in the middle of the pipeline is a second of host time on some boxes
   ICHK(g, hipMalloc(&g->col[1], sizeof(int32_t) * (size_t)n));
   ICHK(g, hipMalloc(&g->val[1], sizeof(float) * (size_t)n));
+  if (part_cap <= 0) {
+    // A range costs 76 bytes per record (24 in the partition buffer, 52 of sort workspace).  Of what is free now -- plus the
+    // arena an earlier finish left, which is reused -- 70 % go to it: the id tables, the ranges' item tables and the row
+    // bounds of R^T (8-16 bytes per user / item) come out of the rest.
+    size_t free_b = 0, total_b = 0;
+    ICHK(g, hipMemGetInfo(&free_b, &total_b));
+    size_t arena = 0;
+    for (int b = 0; b < mals_ingest_s::N_WS; ++b) arena += g->ws_bytes[b];
+    const double budget = 0.7 * ((double)free_b + (double)arena);
+    part_cap = (int64_t)std::min<double>((double)MALS_INGEST_ONE_SHOT_MAX, std::max<double>((double)MALS_INGEST_MIN_PART, budget / 76.0));
+    // (no point in a range larger than the whole input spread over two ranges)
+    part_cap = std::min<int64_t>(part_cap, std::max<int64_t>(MALS_INGEST_MIN_PART, n / 2 + n / 8));
+  }
+  // the workspace of one partition; the scans over all records run on tiles of 2048 (one count per tile) and the dense item
+  // index is a scan over at most 2^31 items: both inside the same tile-sum buffer
+  if (int rc = setup_workspace(g, s, t, std::max<int64_t>(part_cap, n_sample), std::max<int64_t>((n + BIG_TILE - 1) / BIG_TILE, (int64_t)1 << 31))) return rc;
+  ICHK(g, hipMalloc(&B.pu, sizeof(int64_t) * (size_t)part_cap));
+  ICHK(g, hipMalloc(&B.pi, sizeof(int64_t) * (size_t)part_cap));
+  ICHK(g, hipMalloc(&B.pv, sizeof(float) * (size_t)part_cap));
   g->last_workspace_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ws).count();
   ICHK(g, hipEventRecord(e0, g->stream));
 

@@ -899,6 +899,35 @@ int mals_ingest_install_group(mals_ingest in, mals_group g, int32_t flags) {
   return MALS_OK;
 }
 
+// ServerRecommender.recommend(userID, ...) on a group: every member holds full replicas of X and Y but only its own users' rows
+// of R / knownItemIDs, so a user is answered by the member whose slice holds its row.
+int mals_group_recommend(mals_group g, const int64_t* user_idx, int32_t n_queries, int32_t how_many, int32_t consider_known_items,
+                         int64_t* item_idx_out, float* score_out, int32_t* n_out) {
+  if (!g) return MALS_INVALID_ARG;
+  if (n_queries < 0 || how_many <= 0 || (n_queries > 0 && (!user_idx || !item_idx_out || !score_out))) return MALS_INVALID_ARG;
+  if (g->bounds[MALS_SIDE_X].empty()) return MALS_INVALID_ARG;   // (no message: request threads share the group's error string)
+  const std::vector<int64_t>& b = g->bounds[MALS_SIDE_X];
+  // runs of consecutive queries with the same owner go to that member in one call (a one-user call is one run)
+  for (int32_t q0 = 0; q0 < n_queries;) {
+    const int64_t u = user_idx[q0];
+    if (u < 0 || u >= b.back()) return MALS_INVALID_ARG;
+    const int owner = (int)(std::upper_bound(b.begin(), b.end(), u) - b.begin()) - 1;
+    int32_t q1 = q0 + 1;
+    while (q1 < n_queries && user_idx[q1] >= b[(size_t)owner] && user_idx[q1] < b[(size_t)owner + 1]) ++q1;
+    const Member* mb = nullptr;
+    for (const Member& m : g->m)
+      if (m.rank == owner) mb = &m;
+    // consider_known_items: any member can answer (the replicas are complete); else only the owner knows the user's items
+    if (!mb && consider_known_items) mb = &g->m[0];
+    if (!mb) return MALS_INVALID_ARG;   // the owner is another process's rank
+    if (int rc = mals_recommend(mb->h, user_idx + q0, q1 - q0, how_many, consider_known_items, item_idx_out + (size_t)q0 * how_many,
+                                score_out + (size_t)q0 * how_many, n_out ? n_out + q0 : nullptr))
+      return rc;
+    q0 = q1;
+  }
+  return MALS_OK;
+}
+
 int mals_group_begin_matrix(mals_group g, int side, int64_t n_rows, const int64_t* row_ptr) {
   GSIDE(g, side);
   if (n_rows < 0 || !row_ptr || row_ptr[0] != 0) return gfail(g, MALS_INVALID_ARG, "bad matrix arguments");

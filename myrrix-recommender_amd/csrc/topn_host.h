@@ -119,7 +119,8 @@ struct TopnCand {
   uint32_t key;
   int64_t idx;
 };
-void topn_emit(std::vector<TopnCand>& cand, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
+// false: a non-finite score among the results (the reference: Preconditions.checkState(isFinite(result)), RecommendIterator.java:105)
+bool topn_emit(std::vector<TopnCand>& cand, int how_many, int64_t* item_idx_out, float* score_out, int32_t* n_out) {
   // best score first; equal scores in ascending item index (the reference's order among ties is its hash order)
   std::sort(cand.begin(), cand.end(), [](const TopnCand& a, const TopnCand& b) { return a.key != b.key ? a.key > b.key : a.idx < b.idx; });
   const int n = (int)std::min<size_t>(cand.size(), (size_t)how_many);
@@ -133,6 +134,8 @@ void topn_emit(std::vector<TopnCand>& cand, int how_many, int64_t* item_idx_out,
       score_out[j] = -std::numeric_limits<float>::infinity();
     }
   }
+  // (NaN sorts above +inf in score_key: a non-finite score, if there is one, is the first result)
+  return n == 0 || std::isfinite(score_out[0]);
 }
 
 // The pass's vectors, offsets, known-item rows and exclusion lists on the device: assembled in the slot's pinned input
@@ -268,7 +271,8 @@ int topn_pass_dense(mals_handle h, TopnWorkspace* w, TopnSlot& sl, const TopnReq
       for (uint32_t p = 0; p < ties_stored; ++p) cand.push_back({o[2 * (how_many + p) + 1], (int64_t)o[2 * (how_many + p)]});
     }
     const TopnOut o_q = topn_out(rq, (size_t)(ps.q0 + q));
-    topn_emit(cand, how_many, o_q.items, o_q.scores, o_q.n);
+    if (!topn_emit(cand, how_many, o_q.items, o_q.scores, o_q.n))
+      return fail(h, MALS_INVALID_ARG, "Bad recommendation value: a non-finite score (non-finite factors; RecommendIterator.java:105 throws IllegalStateException)");
   }
   return MALS_OK;
 }
@@ -404,7 +408,7 @@ int topn_pass_filter_launch(mals_handle h, TopnSlot& sl, const TopnRequest& rq, 
   // (the filter's waves scatter their own hits into the per-query candidate lists: no kernel in between)
   if (int rc = topn_launch_stream<1>(h, sl, p.S, nt, y.F, n_items, k, nq, 1, p.cap, &n_fw)) return rc;
   hipLaunchKernelGGL(topn_rescore_kernel, dim3(8, (unsigned)nq), dim3(64), sizeof(float) * 64 * (size_t)(k + 1), st, y.F, k, sl.d_vecs, sl.d_vrow, sl.d_vptr, sl.d_count, p.cap,
-                     sl.d_cand, k_ptr, k_idx, d_rows, d_eptr, d_eidx, h->tag_bits, sl.d_pairs);
+                     sl.d_cand, k_ptr, k_idx, d_rows, d_eptr, d_eidx, h->tag_bits, sl.d_pairs, d_overflow);
   uint8_t* o = sl.h_stage;
   const size_t o_cnt = sizeof(uint64_t) * (size_t)TOPN_FILTER_QUERIES * (size_t)how_many, o_tau = o_cnt + sizeof(unsigned) * TOPN_FILTER_QUERIES,
                o_ovf = o_tau + sizeof(float) * TOPN_FILTER_QUERIES;

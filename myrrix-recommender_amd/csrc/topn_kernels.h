@@ -355,15 +355,19 @@ __global__ __launch_bounds__(256, 2) void topn_stream_kernel(const float* __rest
         int32_t mx = mj[0];
 #pragma unroll
         for (int j = 1; j < QT; ++j) mx = max(mx, mj[j]);
-        if (__ballot(mx >= 0)) {
+        // (TOPN_HIT: also the NaNs with the sign bit set -- as signed integers they lie above -inf's pattern 0xff800000, every
+        // finite negative float at or below it.  A non-finite candidate is not dropped silently: its exact score sends the
+        // pass to the dense path, which reports it like the reference's checkState(isFinite), RecommendIterator.java:105)
+        constexpr int32_t TOPN_HIT = (int32_t)0xff800000;
+        if (__ballot(mx > TOPN_HIT)) {
 #pragma unroll
           for (int j = 0; j < QT; ++j) {
-            if (!__ballot(mj[j] >= 0)) continue;
+            if (!__ballot(mj[j] > TOPN_HIT)) continue;
             const int q = 16 * (4 * j + w) + c;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int64_t it = i0 + 4 * g + r;
-              const bool hit = (int32_t)__float_as_uint(acc[j][r]) >= 0 && it < n_items && q < n_queries;
+              const bool hit = (int32_t)__float_as_uint(acc[j][r]) > TOPN_HIT && it < n_items && q < n_queries;
               const uint64_t hm = __ballot(hit);
               if (hm) {
                 const unsigned at = n_hits + (unsigned)__popcll(hm & ((1ull << lane) - 1ull));
@@ -567,7 +571,8 @@ __global__ __launch_bounds__(64) void topn_rescore_kernel(const float* __restric
                                                           const uint32_t* __restrict__ cand, const int64_t* __restrict__ row_ptr,
                                                           const int32_t* __restrict__ col, const int64_t* __restrict__ query_row,
                                                           const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_idx,
-                                                          const uint32_t* __restrict__ tag_bits, uint64_t* __restrict__ pairs) {
+                                                          const uint32_t* __restrict__ tag_bits, uint64_t* __restrict__ pairs,
+                                                          unsigned* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   float* ys = reinterpret_cast<float*>(smem);  // [64][k + 1]
   __shared__ uint32_t sk[1024];
@@ -650,6 +655,7 @@ __global__ __launch_bounds__(64) void topn_rescore_kernel(const float* __restric
       uint64_t out = 0;
       if (!struck) {
         const float sc = topn_ref_score(ys + lane * pitch, vecs, vrow, v0, v1, k);
+        if (!(fabsf(sc) < __builtin_huge_valf())) atomicAdd(overflow, 1u);   // NaN / infinite: the dense path decides and reports
         out = ((uint64_t)score_key(sc) << 32) | (uint64_t)(0xffffffffu - it);
       }
       pairs[(int64_t)q * cap + p] = out;
@@ -739,7 +745,10 @@ __global__ __launch_bounds__(256) void topn_exact_dense_kernel(const float* __re
       const float* y = ys + lane * pitch;
       for (int q = w; q < n_queries; q += 4) {
         const int v0 = __builtin_amdgcn_readfirstlane(vptr[q]), v1 = __builtin_amdgcn_readfirstlane(vptr[q + 1]);
-        scores[(int64_t)q * n_items + i0 + lane] = topn_ref_score(y, vecs, vrow, v0, v1, k);
+        const float sc = topn_ref_score(y, vecs, vrow, v0, v1, k);
+        // (a NaN of either sign as THE NaN that score_key sorts above +inf: a non-finite score is then the first result of its
+        // query, where topn_emit looks for it -- RecommendIterator.java:105)
+        scores[(int64_t)q * n_items + i0 + lane] = sc != sc ? __builtin_nanf("") : sc;
       }
     }
   }

@@ -231,6 +231,16 @@ class GroupALS:
             self._chk(self._L.mals_group_append_rows(self._g, side, r1 - r0, cc.ctypes.data_as(ctypes.c_void_p), vv.ctypes.data_as(ctypes.c_void_p)))
         self._chk(self._L.mals_group_end_matrix(self._g, side))
 
+    def recommend(self, user_idx, how_many, consider_known_items=False):
+        """ServerRecommender.recommend on the group: every query answered by the member that holds the user's row."""
+        u = np.ascontiguousarray(user_idx, dtype=np.int64)
+        idx = np.empty((len(u), how_many), dtype=np.int64)
+        sc = np.empty((len(u), how_many), dtype=np.float32)
+        cnt = np.empty(len(u), dtype=np.int32)
+        self._chk(self._L.mals_group_recommend(self._g, u.ctypes.data_as(ctypes.c_void_p), len(u), int(how_many), 1 if consider_known_items else 0,
+                                               idx.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
+        return idx, sc, cnt
+
     def bounds(self, side):
         out = np.zeros(self.world + 1, dtype=np.int64)
         self._chk(self._L.mals_group_bounds(self._g, side, out.ctypes.data_as(ctypes.c_void_p)))

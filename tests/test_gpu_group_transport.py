@@ -114,6 +114,74 @@ def _one_rank_gloo(rank, world, k, chunks, port, out_q):
         out_q.put((rank, "error", repr(e)))
 
 
+def _one_rank_ingest(rank, world, k, data, uid_q, out_q):
+    """One process per rank, every rank ingests the SAME input text itself and installs it into its rank of the group
+    (mals_ingest_install_group is collective like mals_group_set_matrix): nothing of the matrices crosses a host."""
+    try:
+        import myrrix_recommender_amd as pkg
+        from myrrix_recommender_amd import _lib, ingest
+        pkg.GroupALS.use_transport(MOCK)
+        if rank == 0:
+            uid = pkg.GroupALS.unique_id()
+            for _ in range(world - 1):
+                uid_q.put(uid)
+        else:
+            uid = uid_q.get(timeout=120)
+        with ingest.Ingest(0) as g, pkg.GroupALS.from_unique_id(k, 0, world, rank, uid, exchange_chunks=2) as grp:
+            g.set_option(_lib.INGEST_OPT_KNOWN_ITEMS, 1)
+            g.append_text(data, True)
+            g.finish()
+            c = g.counts()
+            g.install_group(grp, copy=True)
+            g.close()
+            Y0 = (np.random.default_rng(k).standard_normal((c["items"], k)) / np.sqrt(k)).astype(np.float32)
+            grp.set_factors(pkg.SIDE_Y, Y0)
+            grp.iterate(2)
+            core = grp.local(0)[0]
+            X, Y = core.get_factors(pkg.SIDE_X), core.get_factors(pkg.SIDE_Y)
+            bounds = grp.bounds(pkg.SIDE_X).tolist()
+            mine = np.arange(bounds[rank], min(bounds[rank + 1], bounds[rank] + 10), dtype=np.int64)
+            rec = core.recommend(mine, 5) if len(mine) else None      # this rank's users: their known items are here
+            tags = core.tag_item_count()
+        out_q.put((rank, "ok", X, Y, bounds, mine, rec, tags))
+    except Exception as e:  # noqa: BLE001
+        out_q.put((rank, "error", repr(e)))
+
+
+def test_ingest_installs_into_a_group_of_one_rank_per_process():
+    from oracle import ingest_text_oracle as to
+    from oracle import oracle, topn_oracle
+    from tests.test_gpu_ingest_group import corpus
+    world, k = 3, 32
+    data = corpus(21, 700, 260, 30000)
+    ctx = mp.get_context("spawn")
+    uid_q, out_q = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_one_rank_ingest, args=(r, world, k, data, uid_q, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out_q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), [r[:3] for r in res if r[1] != "ok"]
+    res.sort(key=lambda r: r[0])
+    want = to.expected([data])
+    (uid, rp, col, val), (iid, cp, ccol, cval) = want["csr_x"], want["csr_y"]
+    Xo, Yo = None, (np.random.default_rng(k).standard_normal((len(iid), k)) / np.sqrt(k)).astype(np.float32)
+    for _ in range(2):
+        Xo = oracle.half_iteration(rp, col, val, Yo, threads=4)
+        Yo = oracle.half_iteration(cp, ccol, cval, Xo, threads=4)
+    pos = np.searchsorted(iid, want["user_tag_ids"])
+    tag_idx = pos[(pos < len(iid)) & (iid[np.minimum(pos, len(iid) - 1)] == want["user_tag_ids"])]
+    for rank, _, X, Y, bounds, mine, rec, tags in res:
+        assert bounds == res[0][4] and bounds[-1] == len(uid) and tags == len(tag_idx)
+        assert np.array_equal(X, res[0][2]) and np.array_equal(Y, res[0][3])
+        assert rel(X, Xo) < REL_TOL and rel(Y, Yo) < REL_TOL, (rank, rel(X, Xo), rel(Y, Yo))
+        for q, u in enumerate(mine):
+            known = want["known_idx"][want["known_ptr"][u]:want["known_ptr"][u + 1]]
+            oidx, osc = topn_oracle.recommend(Y, X[u], 5, known, tag_idx)
+            assert np.array_equal(rec[0][q, :len(oidx)], oidx) and np.array_equal(rec[1][q, :len(oidx)].view(np.uint32), np.asarray(osc, np.float32).view(np.uint32))
+
+
 def _oracle(k, seed):
     from oracle import oracle
     r_csr, c_csr, Y0 = _problem(k, seed)

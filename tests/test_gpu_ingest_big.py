@@ -163,7 +163,7 @@ def test_two_and_a_half_billion_records_keep_their_properties():
         torch.cuda.empty_cache()
         g.finish()
         c, st, parts = g.counts(), g.stats(), g.partitions()
-        assert c["records"] == n and parts[0] >= 5 and parts[1] >= 2, (c, parts)
+        assert c["records"] == n and parts[0] >= 2 and parts[1] >= 2, (c, parts)
         assert c["users"] == int((by_user > 0).sum()) and c["items"] == int((by_item > 0).sum())
         assert c["nnz"] > 2 ** 31, c          # (the pairs are drawn with repeats: fewer entries than records, still beyond 2^31)
         uid = torch.as_tensor(g.ids(pkg.SIDE_X), device=dev)

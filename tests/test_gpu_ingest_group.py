@@ -90,11 +90,21 @@ def test_text_to_group_two_iterations_match_the_oracle(world, k, force_copy):
                 oidx, osc = topn_oracle.recommend(Y, X[u], 8, known, tag_idx)
                 assert cnt[q] == len(oidx) and np.array_equal(idx[q, :cnt[q]], oidx), (rank, u)
                 assert np.array_equal(sc[q, :cnt[q]].view(np.uint32), np.asarray(osc, np.float32).view(np.uint32))
+            # the same users through the group's router: answered by whichever member holds them
+            r_idx, r_sc, r_cnt = grp.recommend(users, 8)
+            assert np.array_equal(r_idx, idx) and np.array_equal(r_sc.view(np.uint32), sc.view(np.uint32)) and np.array_equal(r_cnt, cnt)
             # a user of ANOTHER member's slice: this member does not hold its known items and says so
             other = int(bx[(rank + 1) % world]) if world > 1 and bx[(rank + 1) % world] < len(uid) and not (bx[rank] <= bx[(rank + 1) % world] < bx[rank + 1]) else None
             if other is not None:
                 with pytest.raises(pkg.MalsError):
                     core.recommend(np.array([other], np.int64), 8)
+        # users of ALL slices in one call, in mixed order: the router cuts the call into runs per owner
+        mixed = np.random.default_rng(world).permutation(len(uid))[:50].astype(np.int64)
+        m_idx, m_sc, m_cnt = grp.recommend(mixed, 8)
+        for q, u in enumerate(mixed):
+            known = want["known_idx"][want["known_ptr"][u]:want["known_ptr"][u + 1]]
+            oidx, osc = topn_oracle.recommend(Y, X[u], 8, known, tag_idx)
+            assert m_cnt[q] == len(oidx) and np.array_equal(m_idx[q, :m_cnt[q]], oidx)
     Xo, Yo = None, Y0
     for _ in range(2):
         Xo = oracle.half_iteration(rp, col, val, Yo, threads=4)

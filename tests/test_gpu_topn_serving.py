@@ -186,3 +186,32 @@ def test_known_items_of_an_old_matrix_do_not_survive_a_new_one():
         idx, sc, _ = core.recommend(np.array([0], np.int64), 3)
         oidx, osc = to.recommend(Y, X[0], 3, np.array([1, 2]))
         same_ranking(idx[0], sc[0], oidx, osc)
+
+
+@pytest.mark.parametrize("n_items", [3000, 150_000])      # the dense path / the filter path
+@pytest.mark.parametrize("bad", [np.nan, -np.nan, np.inf])
+def test_a_non_finite_score_fails_the_call_like_the_reference(n_items, bad):
+    """RecommendIterator.java:105: Preconditions.checkState(isFinite(result), "Bad recommendation value") -- a model with a
+    non-finite factor does not produce a quietly wrong top-N (the filter's signed-integer hit test let a NaN with
+    the sign bit set through unnoticed)."""
+    k = 32
+    rng = np.random.default_rng(8)
+    Y = (rng.standard_normal((n_items, k)) / np.sqrt(k)).astype(np.float32)
+    X = (rng.standard_normal((4, k)) / np.sqrt(k)).astype(np.float32)
+    X[:, 3] = np.abs(X[:, 3])                                  # (+inf times these is +inf, not -inf)
+    with pkg.ALSCore(k) as core:
+        core.set_factor_rows(pkg.SIDE_Y, n_items)
+        core.set_factors(pkg.SIDE_Y, Y)
+        idx, sc, cnt = core.recommend_vectors(X, 5)
+        oidx, osc = to.recommend(Y, X[0], 5)
+        same_ranking(idx[0], sc[0], oidx, osc)
+        Y[n_items // 2, 3] = np.float32(bad)
+        core.set_factors(pkg.SIDE_Y, Y)
+        with pytest.raises(pkg.MalsError, match="Bad recommendation value"):
+            core.recommend_vectors(X, 5)
+        # the item excluded for every query: the reference never scores it (RecommendIterator.java:75-82), nothing to report
+        idx, sc, cnt = core.recommend_vectors(X, 5, exclude=[[n_items // 2]] * 4)
+        Yc = Y.copy()
+        Yc[n_items // 2] = 0
+        oidx, osc = to.recommend(Yc, X[0], 5, [n_items // 2])
+        same_ranking(idx[0], sc[0], oidx, osc)

@@ -15,10 +15,10 @@ def last_json(name):
 
 
 def test_headline_line_has_the_contract_fields_and_consistent_arithmetic():
-    d = last_json("r5_c4_bench.json")
+    d = last_json("r6_c4_bench.json")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline", "ms_per_step_without_check", "value_without_check", "roofline_fp32",
-                "roofline_unplanted", "gather_scale"):
+                "roofline_unplanted", "roofline_split24", "gather_scale"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["unit"] == "rows/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
@@ -36,13 +36,15 @@ def test_headline_line_has_the_contract_fields_and_consistent_arithmetic():
     assert d["dtype"].startswith("f32 storage; per-row Gramian: f16x2-split")
     f = d["roofline_fp32"]
     assert f["ms_per_step"] > d["ms_per_step"] and abs(f["slower_than_split_f16_by"] - (f["ms_per_step"] / d["ms_per_step"] - 1.0)) < 1e-6
+    t3 = d["roofline_split24"]      # three f16 terms per operand: between the two
+    assert d["ms_per_step"] < t3["ms_per_step"] < f["ms_per_step"] and f["frac"] < t3["frac"] < d["roofline"]["frac"]
 
 
 def test_kernel_trace_summary_agrees_with_the_line():
-    d = last_json("r5_c4_bench_traced.json")
+    d = last_json("r6_c4_bench_traced.json")
     tally = d["roofline"]["all_launches_in_process"]
-    text = open(os.path.join(PROF, "r5_c4_bench_kernel_stats.txt")).read()
-    m = re.search(r"als_persistent_kernel_h<4, 0, true>\(mals::SolveParams\)\s+(\d+)\s+([\d.]+)\s+([\d.]+)", text)
+    text = open(os.path.join(PROF, "r6_c4_bench_kernel_stats.txt")).read()
+    m = re.search(r"als_persistent_kernel_h<4, 0, true, 2>\(mals::SolveParams\)\s+(\d+)\s+([\d.]+)\s+([\d.]+)", text)
     assert m, "the dominant kernel is in the trace summary"
     calls, avg_ms = int(m.group(1)), float(m.group(3))
     assert calls == tally["launches"]
@@ -50,41 +52,55 @@ def test_kernel_trace_summary_agrees_with_the_line():
 
 
 def test_documents_quote_this_bundle():
-    d = last_json("r5_c4_bench.json")
+    d = last_json("r6_c4_bench.json")
     ms, frac, itf = "%.1f" % d["ms_per_step"], "%.3f" % d["roofline"]["frac"], "%.3f" % d["roofline"]["iteration_frac"]
     for doc in ("DESIGN.md", "BASELINE.md", "README.md"):
         text = open(os.path.join(ROOT, doc)).read()
         assert ms in text and frac in text and itf in text, (doc, ms, frac, itf)
     for wl in ("c5rank", "c2", "c3", "k30", "c4rank"):
-        w = last_json("r5_%s_bench.json" % wl)
+        w = last_json("r6_%s_bench.json" % wl)
         q = ("%.1f" if w["ms_per_step"] >= 100 else "%.2f" if w["ms_per_step"] < 20 else "%.1f") % w["ms_per_step"]
         for doc in ("DESIGN.md", "BASELINE.md"):
             assert q in open(os.path.join(ROOT, doc)).read(), (doc, wl, q)
 
 
 def test_the_next_rows_carry_roofline_and_cpu_baseline_too():
-    t = last_json("r5_topn_1M_bench.json")
+    t = last_json("r6_topn_1M_bench.json")
     assert t["unit"] == "queries/s" and t["value"] == t["batches"]["4096"]["queries_per_s"]
     r = t["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert set(t["by_queries_per_pass"]) >= {"64", "128"} and r["best_over_queries_per_pass"]["frac"] >= r["frac"] * 0.95
     assert t["cpu_baseline"]["kind"] == "port" and t["cpu_baseline"]["value"] > 0
-    stats = open(os.path.join(PROF, "r5_topn_1M_kernel_stats.txt")).read()
+    stats = open(os.path.join(PROF, "r6_topn_1M_kernel_stats.txt")).read()
     assert "topn_stream_kernel" in stats and "topn_rescore_kernel" in stats
-    for name, unit in (("r5_ingest_text_1e9_bench.json", "lines/s"), ("r5_ingest_1e9_bench.json", "records/s")):
+    for name, unit in (("r6_ingest_text_1e9_bench.json", "lines/s"), ("r6_ingest_1e9_bench.json", "records/s")):
         i = last_json(name)
         assert i["unit"] == unit and i["value"] > 1e9 and 0.0 < i["roofline"]["frac"] < 1.0
         assert i["cpu_baseline"]["kind"] == "port" and i["cpu_baseline"]["value"] > 0
-    i = last_json("r5_ingest_text_1e9_bench.json")
+    i = last_json("r6_ingest_text_1e9_bench.json")
     assert abs(i["value"] - i["lines"] / (i["ms"] * 1e-3)) / i["value"] < 1e-6 and i["full_parser_lines"] >= 0
 
 
+def test_the_round_6_rows_are_in_the_bundle():
+    t = last_json("r6_topn_1M_bench.json")
+    c = t["callers"]["depth_2"]["32"]
+    assert c["threads"] == 32 and c["queries_per_s"] > 5e4 and c["latency_us"]["p50"] < c["latency_us"]["p99"] and c["queries_per_pass"] > 1.5
+    rc = t["roofline_callers"]
+    assert rc["bound"] == "hbm" and abs(rc["frac"] - c["Y_stream_frac"]) < 1e-9 and rc["frac"] >= 0.30      # VERDICT r5's target for one-user callers
+    i = last_json("r6_ingest_text_5e9_bench.json")
+    assert i["lines"] == 5_000_000_000 and i["unit"] == "lines/s" and i["value"] > 1e9 and i["user_ranges"] >= 2 and i["item_ranges"] >= 2
+    assert abs(i["value"] - i["lines"] / (i["ms"] * 1e-3)) / i["value"] < 1e-6 and i["nnz"] > 2 ** 32 and i["cpu_baseline"]["kind"] == "port"
+    assert 0.0 < i["roofline"]["frac"] < 1.0 and i["hbm_GB_in_use_after_finish"] < 288
+    stats = open(os.path.join(PROF, "r6_ingest_big_2p5e9_kernel_stats.txt")).read()
+    assert "big_select_items_kernel" in stats and "big_compact_part_kernel" in stats and "rs_scatter_kernel" in stats
+
+
 def test_documents_quote_the_next_rows_of_this_bundle():
-    i = last_json("r5_ingest_text_1e9_bench.json")
+    i = last_json("r6_ingest_text_1e9_bench.json")
     ms = "%.0f ms" % i["ms"]
     for doc in ("DESIGN.md", "BASELINE.md", "README.md"):
         assert ms in open(os.path.join(ROOT, doc)).read(), (doc, ms)
-    t = last_json("r5_topn_1M_bench.json")
+    t = last_json("r6_topn_1M_bench.json")
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
     for pp in ("64", "128"):
         v = t["by_queries_per_pass"][pp]
