@@ -625,6 +625,12 @@ struct TopnTicket {
   std::atomic<bool> blocked{false};
   std::mutex mu;
   std::condition_variable cv;
+  // Waking the callers of a finished pass is a futex call each (they block): 28 of them were 110 us of the leader's time
+  // per pass at 128 callers, more than the pass takes on the device.  The leader wakes ONE caller of the pass and leaves it
+  // the list of the others (to_wake); that caller wakes them on its way out.  A ticket on such a list has visit_pending set
+  // until its waker has let go of it, and does not return before.
+  std::vector<TopnTicket*> to_wake;
+  std::atomic<bool> visit_pending{false};
 };
 enum { TOPN_SIG_DONE = 1, TOPN_SIG_LEAD = 2 };
 
@@ -693,13 +699,53 @@ int topn_front_enqueue(mals_handle h, TopnWorkspace* w, int s, TopnFrontPass& fp
 }
 
 void topn_front_complete(TopnFrontPass& fp, int rc, const std::string& err) {  // mutex held
+  TopnTicket* waker = nullptr;
+  size_t waiting = 0;
   for (TopnTicket* t : fp.tickets) {
     t->rc = rc;
     if (rc != MALS_OK) t->err = err;
     t->done = true;
-    if (!t->is_leader) topn_signal(t, TOPN_SIG_DONE);   // (after this the ticket may be gone)
+    if (!t->is_leader) ++waiting;
+  }
+  if (waiting >= 16) {
+    // groups of 8: the leader wakes the first caller of every group and leaves it the other seven (measured at 128 callers,
+    // ~37 per pass: 2.4e5 -> 4.3e5 queries/s, p50 510 -> 260 us; below 16 per pass the leader's own wake-ups cost less than the
+    // extra hop adds to the tail, so small passes are woken directly)
+    size_t in_group = 0;
+    std::vector<TopnTicket*> wakers;
+    for (TopnTicket* t : fp.tickets) {
+      if (t->is_leader) continue;
+      if (in_group == 0) {
+        waker = t;
+        waker->to_wake.reserve(7);
+        wakers.push_back(waker);
+      } else {
+        t->visit_pending.store(true, std::memory_order_seq_cst);   // before the answer becomes visible
+        waker->to_wake.push_back(t);
+        t->sig.fetch_or(TOPN_SIG_DONE, std::memory_order_seq_cst);  // (a caller that is polling sees it at once; one that blocks is woken by its group's first)
+      }
+      in_group = (in_group + 1) % 8;
+    }
+    for (TopnTicket* w : wakers) topn_signal(w, TOPN_SIG_DONE);
+  } else {
+    for (TopnTicket* t : fp.tickets)
+      if (!t->is_leader) topn_signal(t, TOPN_SIG_DONE);   // (after this the ticket may be gone)
   }
   fp.tickets.clear();
+}
+
+// a caller on its way out: the pass-mates the leader left to it, then its own ticket's last visitors
+void topn_ticket_leave(TopnTicket& me) {
+  for (TopnTicket* m : me.to_wake) {
+    {
+      std::lock_guard<std::mutex> lk(m->mu);
+      if (m->blocked.load(std::memory_order_seq_cst)) m->cv.notify_one();
+    }
+    m->visit_pending.store(false, std::memory_order_release);   // the last touch of m
+  }
+  me.to_wake.clear();
+  while (me.visit_pending.load(std::memory_order_acquire)) std::this_thread::yield();
+  { std::lock_guard<std::mutex> own(me.mu); }   // the leader has let go of the ticket
 }
 
 // The calling thread leads until its own ticket is answered.
@@ -839,6 +885,6 @@ int topn_front_submit(mals_handle h, TopnTicket& me) {
   const int rc = me.rc;
   if (rc != MALS_OK) h->err = me.err;
   lk.unlock();
-  { std::lock_guard<std::mutex> own(me.mu); }   // the leader has let go of the ticket
+  topn_ticket_leave(me);
   return rc;
 }
