@@ -789,11 +789,17 @@ int mals_group_set_matrix(mals_group g, int side, int64_t n_rows, int64_t nnz, c
     } else {
       if (mb.d_row_ptr[side]) (void)hipFree(mb.d_row_ptr[side]);
       mb.d_row_ptr[side] = nullptr;
+      // (slices an earlier mals_ingest_install_group copied for this member are not this matrix: let them go once the handle
+      // has taken the new arrays below -- mals_set_matrix synchronises the member's stream before it drops the old ones)
       GHIP(g, hipMalloc(&mb.d_row_ptr[side], sizeof(int64_t) * local.size()));
       GHIP(g, hipMemcpy(mb.d_row_ptr[side], local.data(), sizeof(int64_t) * local.size(), hipMemcpyHostToDevice));
       rc = mals_set_matrix(mb.h, side, r0, r1 - r0, e1 - e0, mb.d_row_ptr[side], col_idx + e0, val + e0, MALS_MEM_DEVICE);
     }
     if (rc) return mfail(g, mb, rc);
+    if (mb.own_col[side]) (void)hipFree(mb.own_col[side]);
+    if (mb.own_val[side]) (void)hipFree(mb.own_val[side]);
+    mb.own_col[side] = nullptr;
+    mb.own_val[side] = nullptr;
   }
   return finish_matrix(g, side);
 }

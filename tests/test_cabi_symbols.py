@@ -119,6 +119,28 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.mals_set_refine_limit(None, 1024.0) == _lib.INVALID_ARG
 
 
+def test_round6_entry_points_reject_null_handles_without_a_gpu():
+    """The serving front, tag items, the group install and router, the ingest's range option: null handles and bad arguments
+    are status codes, not crashes (no device work)."""
+    L = _lib.load()
+    n = ctypes.c_int64(-1)
+    out4 = (ctypes.c_int64 * 4)()
+    assert L.mals_features(None) == 0
+    assert L.mals_recommend_front_stats(None, out4) == _lib.INVALID_ARG
+    assert L.mals_recommend_set_depth(None, 2) == _lib.INVALID_ARG
+    assert L.mals_recommend_set_spin_us(None, 0) == _lib.INVALID_ARG
+    assert L.mals_set_tag_items(None, 0, None, _lib.MEM_HOST) == _lib.INVALID_ARG
+    assert L.mals_get_tag_item_count(None, ctypes.byref(n)) == _lib.INVALID_ARG
+    assert L.mals_ingest_install_group(None, None, 0) == _lib.INVALID_ARG
+    assert L.mals_group_recommend(None, None, 0, 10, 0, None, None, None) == _lib.INVALID_ARG
+    dev, a, b = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    assert L.mals_ingest_device(None, ctypes.byref(dev)) == _lib.INVALID_ARG
+    assert L.mals_ingest_partitions(None, ctypes.byref(a), ctypes.byref(b)) == _lib.INVALID_ARG
+    assert L.mals_ingest_get_tag_items(None, None) == _lib.INVALID_ARG
+    assert L.mals_ingest_set_option(None, _lib.INGEST_OPT_PARTITION_RECORDS, 1000) == _lib.INVALID_ARG
+    assert _lib.INSTALL_COPY == 1 and _lib.GRAMIAN_SPLIT3_F16 == 3 and _lib.INGEST_OPT_PARTITION_RECORDS == 4
+
+
 def test_round3_entry_points_reject_bad_arguments_without_a_gpu():
     """Host-only argument checks of the entry points added in round 3 (no device work)."""
     L = _lib.load()
