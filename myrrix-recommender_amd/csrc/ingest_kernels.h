@@ -85,10 +85,16 @@ __global__ __launch_bounds__(256) void rs_histogram_kernel(const K* __restrict__
   for (int i = lane; i < 256; i += 64) h[w][i] = 0;
   // wave-private LDS rows while counting: no barrier needed, a wave executes in lock step
   const int64_t b = (int64_t)blockIdx.x * RS_BLOCK_TILE + w * RS_WAVE_TILE;
+  // (all sixteen loads of the wave's quarter are issued before the first count: one memory latency per tile, not sixteen)
+  K kk[RS_WAVE_TILE / 64];
+#pragma unroll
   for (int r = 0; r < RS_WAVE_TILE / 64; ++r) {
     const int64_t i = b + 64 * r + lane;
-    if (i < n) atomicAdd(&h[w][(int)((keys[i] >> shift) & 255)], 1u);
+    kk[r] = i < n ? keys[i] : (K)0;
   }
+#pragma unroll
+  for (int r = 0; r < RS_WAVE_TILE / 64; ++r)
+    if (b + 64 * r + lane < n) atomicAdd(&h[w][(int)((kk[r] >> shift) & 255)], 1u);
   __syncthreads();
   const int d = threadIdx.x;
   counts[(int64_t)d * n_blocks + blockIdx.x] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
