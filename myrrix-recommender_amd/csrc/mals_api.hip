@@ -2620,18 +2620,33 @@ int mals_recommend_to_many(mals_handle h, const float* vectors, const int64_t* v
     return topn_fail(h, MALS_INVALID_ARG, "the tag items were set for another item count: call mals_set_tag_items again");
   if (hipSetDevice(h->cfg.device) != hipSuccess) return topn_fail(h, MALS_HIP_ERROR, "hipSetDevice failed");
   TopnRequest rq;
-  rq.n_queries = n_queries;
-  rq.how_many = how_many;
-  rq.vectors = vectors;
-  rq.vec_ptr = vector_ptr;
-  rq.excl_ptr = exclude_ptr;
-  rq.excl_idx = exclude_idx;
-  rq.item_idx_out = item_idx_out;
-  rq.score_out = score_out;
-  rq.n_out = n_out;
   TopnTicket t;
-  t.bulk = &rq;
   t.how_many = how_many;
+  const int64_t n_vec = vector_ptr ? vector_ptr[n_queries] : (int64_t)n_queries;
+  const int64_t n_ex = (exclude_ptr && exclude_idx) ? exclude_ptr[n_queries] - exclude_ptr[0] : 0;
+  if (n_queries < TOPN_FRONT_BULK && how_many <= TOPN_FILTER_MAX_N && n_vec <= 4 * TOPN_FRONT_BULK && n_ex <= (1 << 16) &&
+      (!exclude_ptr || exclude_ptr[0] == 0)) {
+    // a small call (an anonymous user, recommendToMany for a handful of users): folded into a pass with the other callers'
+    t.vectors = vectors;
+    t.vec_ptr = vector_ptr;
+    t.excl_ptr = exclude_ptr;
+    t.excl_idx = exclude_idx;
+    t.n = n_queries;
+    t.item_out = item_idx_out;
+    t.score_out = score_out;
+    t.n_out = n_out;
+  } else {
+    rq.n_queries = n_queries;
+    rq.how_many = how_many;
+    rq.vectors = vectors;
+    rq.vec_ptr = vector_ptr;
+    rq.excl_ptr = exclude_ptr;
+    rq.excl_idx = exclude_idx;
+    rq.item_idx_out = item_idx_out;
+    rq.score_out = score_out;
+    rq.n_out = n_out;
+    t.bulk = &rq;
+  }
   return topn_front_submit(h, t);
 }
 

@@ -610,6 +610,12 @@ struct TopnTicket {
   int64_t* item_out = nullptr;
   float* score_out = nullptr;
   int32_t* n_out = nullptr;
+  // ... or a small call with the caller's own vectors (recommendToAnonymous, recommendToMany: SR:366-441,561-606): n queries,
+  // query q owns vectors [vec_ptr[q], vec_ptr[q+1]) (NULL: one each), optional exclusion lists
+  const float* vectors = nullptr;
+  const int64_t* vec_ptr = nullptr;
+  const int64_t* excl_ptr = nullptr;
+  const int64_t* excl_idx = nullptr;
   // ... or a whole request of its own
   const TopnRequest* bulk = nullptr;
   int rc = MALS_OK;
@@ -667,6 +673,9 @@ struct TopnFrontPass {
   std::vector<int64_t> users;
   std::vector<uint8_t> skip;
   std::vector<TopnOut> outs;
+  // a pass of by-vector calls: the callers' vectors and exclusion lists back to back
+  std::vector<float> vecs;
+  std::vector<int64_t> vptr, eptr, eidx;
   TopnRequest rq;
   TopnPass ps;
   TopnFilterPlan plan;
@@ -780,8 +789,15 @@ void topn_front_lead(mals_handle h, TopnFront* f, std::unique_lock<std::mutex>& 
       } else {
         one.rq.n_queries = head->n;
         one.rq.how_many = head->how_many;
-        one.rq.user_idx = head->user_idx;
-        one.rq.skip_known = head->skip_known;
+        if (head->vectors) {
+          one.rq.vectors = head->vectors;
+          one.rq.vec_ptr = head->vec_ptr;
+          one.rq.excl_ptr = head->excl_ptr;
+          one.rq.excl_idx = head->excl_idx;
+        } else {
+          one.rq.user_idx = head->user_idx;
+          one.rq.skip_known = head->skip_known;
+        }
         one.rq.item_idx_out = head->item_out;
         one.rq.score_out = head->score_out;
         one.rq.n_out = head->n_out;
@@ -798,24 +814,49 @@ void topn_front_lead(mals_handle h, TopnFront* f, std::unique_lock<std::mutex>& 
       const int s = f->next_slot;
       TopnFrontPass& fp = f->inflight[s];
       const int cap = 16 * k_tiles;
+      const int kf = h->cfg.features;
       fp.tickets.clear(); fp.users.clear(); fp.skip.clear(); fp.outs.clear();
+      fp.vecs.clear(); fp.vptr.assign(1, 0); fp.eptr.assign(1, 0); fp.eidx.clear();
       const int how_many = head->how_many;
+      const bool by_vector = head->vectors != nullptr;   // a pass holds by-user calls or by-vector calls, not both (where its
+                                                         // query vectors come from -- X on the device or an uploaded block -- is per pass)
+      bool any_excl = false;
       while (!f->queue.empty()) {
         TopnTicket* t = f->queue.front();
-        if (t->bulk || t->how_many != how_many || (int)fp.users.size() + t->n > cap) break;
+        if (t->bulk || t->how_many != how_many || (t->vectors != nullptr) != by_vector || (int)fp.outs.size() + t->n > cap) break;
         f->queue.pop_front();
         fp.tickets.push_back(t);
         for (int q = 0; q < t->n; ++q) {
-          fp.users.push_back(t->user_idx[q]);
-          fp.skip.push_back(t->skip_known ? 1 : 0);
+          if (by_vector) {
+            const int64_t v0 = t->vec_ptr ? t->vec_ptr[q] : q, v1 = t->vec_ptr ? t->vec_ptr[q + 1] : q + 1;
+            fp.vecs.insert(fp.vecs.end(), t->vectors + v0 * kf, t->vectors + v1 * kf);
+            fp.vptr.push_back(fp.vptr.back() + (v1 - v0));
+            if (t->excl_ptr && t->excl_idx) {
+              fp.eidx.insert(fp.eidx.end(), t->excl_idx + t->excl_ptr[q], t->excl_idx + t->excl_ptr[q + 1]);
+              any_excl = any_excl || t->excl_ptr[q + 1] > t->excl_ptr[q];
+            }
+            fp.eptr.push_back((int64_t)fp.eidx.size());
+          } else {
+            fp.users.push_back(t->user_idx[q]);
+            fp.skip.push_back(t->skip_known ? 1 : 0);
+          }
           fp.outs.push_back({t->item_out + (size_t)q * how_many, t->score_out + (size_t)q * how_many, t->n_out ? t->n_out + q : nullptr});
         }
       }
       fp.rq = TopnRequest();
-      fp.rq.n_queries = (int)fp.users.size();
+      fp.rq.n_queries = (int)fp.outs.size();
       fp.rq.how_many = how_many;
-      fp.rq.user_idx = fp.users.data();
-      fp.rq.skip_known_q = fp.skip.data();
+      if (by_vector) {
+        fp.rq.vectors = fp.vecs.data();
+        fp.rq.vec_ptr = fp.vptr.data();
+        if (any_excl) {
+          fp.rq.excl_ptr = fp.eptr.data();
+          fp.rq.excl_idx = fp.eidx.data();
+        }
+      } else {
+        fp.rq.user_idx = fp.users.data();
+        fp.rq.skip_known_q = fp.skip.data();
+      }
       fp.rq.out_q = fp.outs.data();
       fp.ps = TopnPass();
       fp.ps.q0 = 0;

@@ -215,3 +215,35 @@ def test_a_non_finite_score_fails_the_call_like_the_reference(n_items, bad):
         Yc[n_items // 2] = 0
         oidx, osc = to.recommend(Yc, X[0], 5, [n_items // 2])
         same_ranking(idx[0], sc[0], oidx, osc)
+
+
+def test_anonymous_and_to_many_callers_are_folded_too():
+    """recommendToAnonymous / recommendToMany from request threads (SR:366-441, 561-606): small by-vector calls -- one vector
+    with the anonymous user's items excluded, or a few users' vectors as one query -- share passes like the by-user calls, each
+    answered as if alone (multi-vector score = the reference's mean of dots, RecommendIterator.java:93-104)."""
+    k, n_items, n_users = 32, 150_000, 64
+    core, X, Y, rp, col = big_core(k, n_items, n_users, 25, 4711)
+    with core:
+        before = core.recommend_front_stats()
+        bad = []
+
+        def worker(t):
+            rng = np.random.default_rng(900 + t)
+            for it in range(150):
+                if (t + it) % 2 == 0:
+                    u = int(rng.integers(0, n_users))
+                    ex = col[rp[u]:rp[u + 1]].astype(np.int64)
+                    idx, sc, cnt = core.recommend_vectors(X[u:u + 1], 10, exclude=[ex])
+                    oidx, osc = to.recommend(Y, X[u], 10, ex)
+                else:
+                    us = rng.choice(n_users, int(rng.integers(2, 4)), replace=False)
+                    idx, sc, cnt = core.recommend_to_many([X[us]], 10)
+                    oidx, osc = to.recommend(Y, X[us], 10)
+                if not (cnt[0] == len(oidx) and np.array_equal(idx[0, :len(oidx)], oidx)
+                        and np.array_equal(sc[0, :len(oidx)].view(np.uint32), np.asarray(osc, np.float32).view(np.uint32))):
+                    bad.append((t, it))
+        run_threads(16, worker)
+        assert not bad, bad[:5]
+        st = core.recommend_front_stats()
+        assert st["calls"] - before["calls"] == 16 * 150 and st["exclusive"] == before["exclusive"]   # none of them ran alone
+        assert st["passes"] - before["passes"] <= 16 * 150
