@@ -331,7 +331,8 @@ int mals_recommend(mals_handle h, const int64_t* user_idx, int32_t n_queries, in
  * (by-user calls together, calls with their own vectors -- an anonymous user, recommendToMany -- together), enqueues it,
  * decodes finished passes, wakes their callers -- and hands leadership on when its own answer is there.
  * At most `passes_in_flight` passes (default 2, environment MALS_TOPN_FRONT_DEPTH at mals_create) are on the device at a
- * time; what arrives meanwhile forms the next one.  Larger calls run exclusively, in queue order.  Every result is what the call alone would have returned (bit-identical).  mals_recommend_front_stats:
+ * time; what arrives meanwhile forms the next one.  Larger calls run exclusively, in queue order.  Every result is what the
+ * call alone would have returned (bit-identical).  mals_recommend_front_stats:
  * out4 = {calls, queries, coalesced passes, exclusive calls} since mals_create. */
 int mals_recommend_front_stats(mals_handle h, int64_t* out4);
 int mals_recommend_set_depth(mals_handle h, int32_t passes_in_flight);   /* 1..6; not while calls are in flight */
